@@ -1,0 +1,150 @@
+// Internal declarations shared by the HIP translation units of libsapcu_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/sapcu.h"
+
+namespace sapcu {
+
+void set_error(const char* fmt, ...);
+
+#define SAPCU_CHECK_ARG(cond, ...)                      \
+    do {                                                \
+        if (!(cond)) {                                  \
+            ::sapcu::set_error(__VA_ARGS__);            \
+            return SAPCU_ERR_ARG;                       \
+        }                                               \
+    } while (0)
+
+#define SAPCU_CHECK_HIP(expr)                                                            \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            ::sapcu::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                               __FILE__, __LINE__);                                      \
+            return SAPCU_ERR_HIP;                                                        \
+        }                                                                                \
+    } while (0)
+
+#define SAPCU_CHECK_LAUNCH() SAPCU_CHECK_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------------------------------------
+// Neuron arithmetic.  Every product/sum is an explicitly rounded f32 operation in the op order of
+// fn/snn_coder.py:125-146 (ATen evaluates each Python operator as its own rounded kernel), so the
+// compiler must not contract mul+add into FMA here.
+// ---------------------------------------------------------------------------------------------
+struct NeuronP {   // clamped per-channel parameters
+    float decay, adapt, rdecay, theta0;
+    float dT, rh;  // EIF only
+};
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+__device__ __forceinline__ NeuronP load_lif(const float* __restrict__ p4, int stride, int c) {
+    // p4: [4][stride] raw membrane_decay, threshold_adapt, refractory_decay, threshold_base
+    NeuronP p;
+    p.decay = clampf(p4[c], 0.1f, 0.99f);
+    p.adapt = clampf(p4[stride + c], 0.001f, 0.1f);
+    p.rdecay = clampf(p4[2 * stride + c], 0.1f, 0.95f);
+    p.theta0 = p4[3 * stride + c];
+    p.dT = 0.f;
+    p.rh = 0.f;
+    return p;
+}
+
+__device__ __forceinline__ NeuronP load_eif(const float* __restrict__ p6, int stride, int c) {
+    NeuronP p = load_lif(p6, stride, c);
+    p.dT = clampf(p6[4 * stride + c], 0.1f, 5.0f);
+    p.rh = clampf(p6[5 * stride + c], 0.1f, 2.0f);
+    return p;
+}
+
+// eval-mode spike surrogate: 0.5*N(x) + 0.5*sigmoid(10 x), x clamped to +-10 (fn:135-146)
+__device__ __forceinline__ float soft_spike(float d) {
+    const float x = clampf(d, -10.0f, 10.0f);
+    const float g = __fdiv_rn(expf(__fdiv_rn(-__fmul_rn(x, x), 2.0f)), 2.5066282746310002f);
+    const float s = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-__fmul_rn(10.0f, x))));
+    return __fadd_rn(__fmul_rn(0.5f, g), __fmul_rn(0.5f, s));
+}
+
+struct NeuronS {
+    float m, th, r;
+};
+
+__device__ __forceinline__ NeuronS neuron_init(const NeuronP& p) { return NeuronS{0.f, p.theta0, 0.f}; }
+
+// One step.  EIF adds dT*exp(clamp((m_prev-rh)/(dT+1e-6),+-5)) un-gated (fd:245-252).
+template <bool EIF>
+__device__ __forceinline__ float neuron_step(float x, NeuronS& s, const NeuronP& p) {
+    float extra = 0.f;
+    if (EIF) {
+        const float a = clampf(__fdiv_rn(__fsub_rn(s.m, p.rh), __fadd_rn(p.dT, 1e-6f)), -5.0f, 5.0f);
+        extra = __fmul_rn(p.dT, expf(a));
+    }
+    const float xin = (s.r <= 0.f) ? x : __fmul_rn(x, 0.f);
+    float m = __fadd_rn(__fmul_rn(__fmul_rn(s.m, p.decay), __fsub_rn(1.0f, s.r)), xin);
+    if (EIF) m = __fadd_rn(m, extra);
+    const float sp = soft_spike(__fsub_rn(m, s.th));
+    s.m = __fmul_rn(m, __fsub_rn(1.0f, sp));
+    s.r = __fadd_rn(__fmul_rn(s.r, p.rdecay), sp);
+    const float th = __fadd_rn(s.th, __fmul_rn(p.adapt, sp));
+    s.th = __fadd_rn(p.theta0, __fmul_rn(__fsub_rn(th, p.theta0), 0.95f));
+    return sp;
+}
+
+// `for t in range(T): x, *st = snn(x, *st)` — spikes fed back as the next input (fn:319-320).
+// State lives in registers for all T steps.
+__device__ __forceinline__ float lif_selfloop(float x, const NeuronP& p, int T) {
+    NeuronS s = neuron_init(p);
+    for (int t = 0; t < T; ++t) x = neuron_step<false>(x, s, p);
+    return x;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {   // nn.GELU() default (exact erf form)
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float lrelu02(float x) { return x >= 0.f ? x : 0.2f * x; }
+
+// ---------------------------------------------------------------------------------------------
+// GEMM (gemm_f32.hip):  C[r,n] = epi( pro(A)[r,k] * W[n,k]^T + bias[n] )
+// ---------------------------------------------------------------------------------------------
+enum GemmEpi { EPI_BIAS = 0, EPI_LIF = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_LRELU = 4, EPI_RESID_GELU = 5 };
+enum GemmPro { PRO_PLAIN = 0, PRO_ATTN_IN = 1 };
+
+struct GemmArgs {
+    const float* a;      // [r, lda]
+    int64_t r;
+    int k, lda;
+    const float* w;      // [n, k] row-major (k % 32 == 0)
+    int n;
+    const float* bias;   // [n] or null
+    float* c;            // [r, ldc]
+    int ldc;
+    int epi, pro;
+    // EPI_LIF: raw neuron params [4][n], T self-loop steps
+    const float* lif;
+    int lif_T;
+    // EPI_RESID: c = acc + bias + resid[r, ldr]
+    const float* resid;
+    int ldr;
+    // PRO_ATTN_IN: a = pe; A[row,:] = pe[row,:] + q[row / kk,:] - kf[(row / (m*kk))*m + idx[row],:]
+    const float* q;      // q rows at qkv + 0, kf at qkv + k (the GEMM K == d), ld = ldq
+    const float* kf;
+    int ldq;
+    const int32_t* idx;  // [r] flattened [b,m,kk]
+    int kk, mpts;
+};
+int launch_gemm(const GemmArgs& g, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// knn / geometry (knn_outer.hip, geom.hip)
+// ---------------------------------------------------------------------------------------------
+int launch_knn_outer(const double* cloud, int64_t n, const double* q, int64_t b, int k, int64_t* idx,
+                     double* dist, float* patch, hipStream_t st);
+int launch_gather_rotate(const double* cloud, int64_t n, const double* q, int64_t b, const int64_t* idx,
+                         int k, const float* normals, float* patch, hipStream_t st);
+int launch_displace(const double* q, const float* nrm, const float* d, int64_t b, double* out, hipStream_t st);
+
+}  // namespace sapcu

@@ -1,0 +1,585 @@
+// Model handles and forward orchestration (host code) + the extern "C" ABI of include/sapcu.h.
+//
+// A forward is a fixed sequence of launches on the caller's stream over caller-owned workspace:
+// the 1x1 convolutions / Linears are batched over ALL rows of a chunk of patches and run on the
+// MFMA GEMM (gemm_f32.hip) with the neuron loop fused as its epilogue; the irregular parts
+// (in-patch kNN, gathers, softmax over neighbours, pooling) are the small kernels of
+// patch_ops.hip.  Intermediates of a chunk ([rows, d] f32) live in HBM/Infinity Cache between
+// launches — 288 GB of HBM is what lets [b*m*k, d] tensors exist at all (the reference must keep
+// b <= 400 for them); the chunk size bounds the footprint.
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include <new>
+#include <vector>
+
+#include "common.h"
+#include "ops.h"
+
+namespace sapcu {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------- slot tables (== packing.py)
+enum FnSlot {
+    FN_STEM_W = 0, FN_STEM_B, FN_STEM_LIF,
+    FN_BLK0 = 3,   // 21 slots per block, 3 blocks
+    FN_FINAL_W = FN_BLK0 + 63, FN_FINAL_B, FN_FINAL_LIF,
+    FN_FCOUT_W, FN_FCOUT_B,
+    FN_MLP0_W, FN_MLP0_B, FN_MLP1_W, FN_MLP1_B, FN_MLP2_W, FN_MLP2_B,
+    FN_HEAD_W, FN_HEAD_B, FN_LN_W, FN_LN_B,
+    FN_SLOTS
+};
+enum FnBlkSlot {
+    B_FC1_W = 0, B_FC1_B, B_SNN1,
+    B_QKV_W, B_QKV_B, B_QKV_LIF,
+    B_DELTA_W, B_DELTA_B, B_DELTA_LIF,
+    B_DELTA2_W, B_DELTA2_B, B_DELTA2_LIF,
+    B_GAMMA_W, B_GAMMA_B, B_GAMMA_LIF,
+    B_GAMMA2_W, B_GAMMA2_B,
+    B_OUT_W, B_OUT_B,
+    B_FC2_W, B_FC2_B,
+    B_SLOTS
+};
+static_assert(B_SLOTS == 21, "fn block slot count");
+static_assert(FN_SLOTS == 81, "fn slot count");
+
+enum FdSlot {
+    FD_E0_W = 0, FD_E0_B,
+    FD_FUSE_W, FD_FUSE_B, FD_SNN0,
+    FD_EDGE1_W, FD_EDGE1_SHIFT, FD_SNN1,
+    FD_EDGE2_W, FD_EDGE2_SHIFT, FD_SNN2,
+    FD_EDGE3_W, FD_EDGE3_SHIFT, FD_SNN3,
+    FD_MSC_W, FD_MSC_B,
+    FD_TI_W, FD_SNNFC,
+    FD_FCIN_W, FD_FCIN_B,
+    FD_R0_FC0_W, FD_R0_FC0_B, FD_R0_FC4_W, FD_R0_FC4_B, FD_R0_PROJ_W, FD_R0_PROJ_B,
+    FD_R1_FC0_W, FD_R1_FC0_B, FD_R1_FC4_W, FD_R1_FC4_B, FD_R1_PROJ_W, FD_R1_PROJ_B,
+    FD_QKV_W, FD_QKV_B,
+    FD_WO_T, FD_BO, FD_LN_W, FD_LN_B, FD_WH_T, FD_BH, FD_WD, FD_BD,
+    FD_SLOTS
+};
+static_assert(FD_SLOTS == 42, "fd slot count");
+
+}  // namespace sapcu
+
+struct sapcu_model {
+    int kind;
+    // fn
+    int kv[3];
+    // fd
+    int k, nscale;
+    int ks[8];
+    int32_t* ks_dev;
+    int* gate_dev;
+    // common
+    int emb, T, heads;
+    int64_t chunk;
+    float* blob;
+    int64_t blob_floats;
+    std::vector<int64_t> dir;
+    const float* p(int slot) const { return blob + dir[slot]; }
+};
+
+namespace sapcu {
+
+struct Arena {
+    char* base;
+    int64_t cap, off;
+    template <typename T>
+    T* take(int64_t count) {
+        const int64_t bytes = ((count * (int64_t)sizeof(T)) + 255) & ~(int64_t)255;
+        T* p = reinterpret_cast<T*>(base + off);
+        off += bytes;
+        return p;
+    }
+};
+
+static inline int64_t imax(int64_t a, int64_t b) { return a > b ? a : b; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+
+static int gemm(const float* a, int64_t r, int k, int lda, const float* w, int n, const float* bias, float* c, int ldc,
+                int epi, hipStream_t st, const float* lif = nullptr, int lifT = 0, const float* resid = nullptr,
+                int ldr = 0) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a = a; g.r = r; g.k = k; g.lda = lda; g.w = w; g.n = n; g.bias = bias; g.c = c; g.ldc = ldc;
+    g.epi = epi; g.pro = PRO_PLAIN; g.lif = lif; g.lif_T = lifT; g.resid = resid; g.ldr = ldr;
+    return launch_gemm(g, st);
+}
+
+#define SAPCU_TRY(expr)                 \
+    do {                                \
+        int _rc = (expr);               \
+        if (_rc != SAPCU_OK) return _rc; \
+    } while (0)
+
+static int tap_copy(void* const* taps, int which, int64_t dst_off_bytes, const void* src, int64_t bytes,
+                    hipStream_t st) {
+    if (!taps || !taps[which] || bytes == 0) return SAPCU_OK;
+    SAPCU_CHECK_HIP(hipMemcpyAsync((char*)taps[which] + dst_off_bytes, src, (size_t)bytes, hipMemcpyDeviceToDevice, st));
+    return SAPCU_OK;
+}
+
+// ============================================================================ fn
+struct FnPlan {
+    int64_t cb;       // patches per chunk
+    int kk[3];
+    int64_t edge_floats;   // per-chunk size of one [rows, d] edge buffer
+};
+
+static FnPlan fn_plan(const sapcu_model* m, int64_t b, int mp) {
+    FnPlan pl;
+    pl.cb = b < m->chunk ? b : m->chunk;
+    if (pl.cb < 1) pl.cb = 1;
+    int64_t per_patch = (int64_t)mp * m->emb;
+    for (int l = 0; l < 3; ++l) {
+        pl.kk[l] = imin(m->kv[l], mp);
+        per_patch = imax(per_patch, (int64_t)mp * pl.kk[l] * (128 << l));
+    }
+    pl.edge_floats = per_patch * pl.cb;
+    return pl;
+}
+
+static int64_t fn_ws_bytes(const sapcu_model* m, int64_t b, int mp) {
+    const FnPlan pl = fn_plan(m, b, mp);
+    const int64_t P = pl.cb * mp;
+    int64_t fl = 0;
+    auto add = [&](int64_t n, int64_t esz) { fl += ((n * esz) + 255) & ~(int64_t)255; };
+    for (int l = 0; l < 3; ++l) add(P * pl.kk[l], 4);          // idx
+    add(P * 64, 4); add(P * 192, 4); add(P * 512, 4); add(P * 1536, 4); add(P * 512, 4);
+    add(pl.edge_floats, 4); add(pl.edge_floats, 4); add(pl.edge_floats, 4);
+    add(pl.cb * m->emb, 4); add(pl.cb * 2048, 4); add(pl.cb * 1024, 4); add(pl.cb * 512, 4); add(pl.cb * 256, 4);
+    add(pl.cb * 3, 4);
+    return fl + 256;
+}
+
+static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int mp, const int32_t* knn_in,
+                      int32_t* knn_out, float* normals, void* ws, int64_t ws_bytes, void* const* taps,
+                      hipStream_t st) {
+    const FnPlan pl = fn_plan(m, b, mp);
+    if (ws_bytes < fn_ws_bytes(m, b, mp)) {
+        set_error("fn_forward: workspace %lld B < required %lld B", (long long)ws_bytes, (long long)fn_ws_bytes(m, b, mp));
+        return SAPCU_ERR_WORKSPACE;
+    }
+    // offsets of the three tables inside knn_in / knn_out ([b,m,k0] | [b,m,k1] | [b,m,k2])
+    int64_t tab_off[3];
+    tab_off[0] = 0;
+    tab_off[1] = b * mp * pl.kk[0];
+    tab_off[2] = tab_off[1] + b * mp * pl.kk[1];
+
+    for (int64_t s = 0; s < b; s += pl.cb) {
+        const int64_t cb = (b - s) < pl.cb ? (b - s) : pl.cb;
+        const int64_t P = cb * mp;
+        Arena A{(char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), ws_bytes, 0};
+        int32_t* idx[3];
+        for (int l = 0; l < 3; ++l) idx[l] = A.take<int32_t>(pl.cb * mp * pl.kk[l]);
+        float* feat0 = A.take<float>(pl.cb * mp * 64);
+        float* cat = A.take<float>(pl.cb * mp * 192);
+        float* X = A.take<float>(pl.cb * mp * 512);
+        float* QKV = A.take<float>(pl.cb * mp * 1536);
+        float* RES = A.take<float>(pl.cb * mp * 512);
+        float* B1 = A.take<float>(pl.edge_floats);
+        float* B2 = A.take<float>(pl.edge_floats);
+        float* B3 = A.take<float>(pl.edge_floats);
+        float* pooled = A.take<float>(pl.cb * m->emb);
+        float* enc = A.take<float>(pl.cb * 2048);
+        float* h1 = A.take<float>(pl.cb * 1024);
+        float* h2 = A.take<float>(pl.cb * 512);
+        float* h3 = A.take<float>(pl.cb * 256);
+        float* logits = A.take<float>(pl.cb * 3);
+        const float* pc = patch + s * mp * 3;
+
+        // in-patch neighbour tables: replayed (reference KNNCache) or computed from this chunk
+        for (int l = 0; l < 3; ++l) {
+            const int64_t cnt = P * pl.kk[l];
+            if (knn_in) {
+                SAPCU_CHECK_HIP(hipMemcpyAsync(idx[l], knn_in + tab_off[l] + s * mp * pl.kk[l], cnt * 4,
+                                               hipMemcpyDeviceToDevice, st));
+            } else {
+                SAPCU_TRY(launch_patch_knn(pc, cb, mp, 3, 3, pl.kk[l], idx[l], st));
+            }
+            if (knn_out)
+                SAPCU_CHECK_HIP(hipMemcpyAsync(knn_out + tab_off[l] + s * mp * pl.kk[l], idx[l], cnt * 4,
+                                               hipMemcpyDeviceToDevice, st));
+        }
+        SAPCU_TRY(launch_fn_stem(pc, P, m->p(FN_STEM_W), m->p(FN_STEM_B), m->p(FN_STEM_LIF), m->T, feat0, st));
+        SAPCU_TRY(tap_copy(taps, SAPCU_FN_TAP_STEM, s * mp * 64 * 4, feat0, P * 64 * 4, st));
+
+        const float* fin = feat0;
+        int ldin = 64;
+        for (int l = 0; l < 3; ++l) {
+            const int d = 128 << l;
+            const int kk = pl.kk[l];
+            const int64_t R = P * kk;
+            const int sb = FN_BLK0 + l * B_SLOTS;
+            // x = LIF(fc1(feat))                                                    fn:317-320
+            SAPCU_TRY(gemm(fin, P, 64, ldin, m->p(sb + B_FC1_W), d, m->p(sb + B_FC1_B), X, d, EPI_LIF, st,
+                           m->p(sb + B_SNN1), 4));
+            // q|k|v = LIF(w_qs|w_ks|w_vs (x))                                       fn:322-335
+            SAPCU_TRY(gemm(X, P, d, d, m->p(sb + B_QKV_W), 3 * d, m->p(sb + B_QKV_B), QKV, 3 * d, EPI_LIF, st,
+                           m->p(sb + B_QKV_LIF), 4));
+            // pe1 = LIF(fc_delta(x_i - x_j))                                        fn:310,355-358
+            SAPCU_TRY(launch_fn_pe1(pc, idx[l], R, mp, kk, d, m->p(sb + B_DELTA_W), m->p(sb + B_DELTA_B),
+                                    m->p(sb + B_DELTA_LIF), 4, B1, st));
+            // pe = LIF(fc_delta2(pe1))                                              fn:360-363
+            SAPCU_TRY(gemm(B1, R, d, d, m->p(sb + B_DELTA2_W), d, m->p(sb + B_DELTA2_B), B2, d, EPI_LIF, st,
+                           m->p(sb + B_DELTA2_LIF), 4));
+            // g = LIF(fc_gamma(q_i - k_j + pe))                                     fn:367-376
+            {
+                GemmArgs g;
+                memset(&g, 0, sizeof(g));
+                g.a = B2; g.r = R; g.k = d; g.lda = d; g.w = m->p(sb + B_GAMMA_W); g.n = d;
+                g.bias = m->p(sb + B_GAMMA_B); g.c = B3; g.ldc = d; g.epi = EPI_LIF; g.pro = PRO_ATTN_IN;
+                g.lif = m->p(sb + B_GAMMA_LIF); g.lif_T = 4;
+                g.q = QKV; g.kf = QKV + d; g.ldq = 3 * d; g.idx = idx[l]; g.kk = kk; g.mpts = mp;
+                SAPCU_TRY(launch_gemm(g, st));
+            }
+            // a = fc_gamma2(g)                                                      fn:378
+            SAPCU_TRY(gemm(B3, R, d, d, m->p(sb + B_GAMMA2_W), d, m->p(sb + B_GAMMA2_B), B1, d, EPI_BIAS, st));
+            // res = sum_j softmax_j(a / sqrt(hd)) * (v_j + pe)                      fn:379-389
+            const float sqrt_hd = (float)sqrt((double)(d / m->heads));
+            SAPCU_TRY(launch_fn_softmax_agg(B1, B2, QKV + 2 * d, 3 * d, idx[l], P, mp, kk, d, sqrt_hd, RES, st));
+            // out_proj, fc2 + residual                                              fn:393-394
+            SAPCU_TRY(gemm(RES, P, d, d, m->p(sb + B_OUT_W), d, m->p(sb + B_OUT_B), X, d, EPI_BIAS, st));
+            SAPCU_TRY(gemm(X, P, d, d, m->p(sb + B_FC2_W), 64, m->p(sb + B_FC2_B), cat + 64 * l, 192, EPI_RESID, st,
+                           nullptr, 0, fin, ldin));
+            if (taps && taps[SAPCU_FN_TAP_BLOCK1 + l]) {
+                SAPCU_CHECK_HIP(hipMemcpy2DAsync((char*)taps[SAPCU_FN_TAP_BLOCK1 + l] + s * mp * 64 * 4, 64 * 4,
+                                                 cat + 64 * l, 192 * 4, 64 * 4, (size_t)P, hipMemcpyDeviceToDevice, st));
+            }
+            fin = cat + 64 * l;
+            ldin = 192;
+        }
+        // conv_final + LIF x T_enc, max over points, fc_out                          fn:465-475
+        SAPCU_TRY(gemm(cat, P, 192, 192, m->p(FN_FINAL_W), m->emb, m->p(FN_FINAL_B), B1, m->emb, EPI_LIF, st,
+                       m->p(FN_FINAL_LIF), m->T));
+        SAPCU_TRY(launch_rowgroup_max(B1, cb, mp, m->emb, pooled, st));
+        SAPCU_TRY(tap_copy(taps, SAPCU_FN_TAP_POOLED, s * m->emb * 4, pooled, cb * m->emb * 4, st));
+        SAPCU_TRY(gemm(pooled, cb, m->emb, m->emb, m->p(FN_FCOUT_W), 2048, m->p(FN_FCOUT_B), enc, 2048, EPI_BIAS, st));
+        SAPCU_TRY(tap_copy(taps, SAPCU_FN_TAP_ENC, s * 2048 * 4, enc, cb * 2048 * 4, st));
+        // decoder MLP (Linear+BN+GELU) x3, Linear(256,3), LayerNorm(3), normalize    fn:542-549
+        SAPCU_TRY(gemm(enc, cb, 2048, 2048, m->p(FN_MLP0_W), 1024, m->p(FN_MLP0_B), h1, 1024, EPI_GELU, st));
+        SAPCU_TRY(gemm(h1, cb, 1024, 1024, m->p(FN_MLP1_W), 512, m->p(FN_MLP1_B), h2, 512, EPI_GELU, st));
+        SAPCU_TRY(gemm(h2, cb, 512, 512, m->p(FN_MLP2_W), 256, m->p(FN_MLP2_B), h3, 256, EPI_GELU, st));
+        SAPCU_TRY(launch_fn_tail(h3, cb, 256, m->p(FN_HEAD_W), m->p(FN_HEAD_B), m->p(FN_LN_W), m->p(FN_LN_B), logits,
+                                 normals + s * 3, st));
+        SAPCU_TRY(tap_copy(taps, SAPCU_FN_TAP_LOGITS, s * 3 * 4, logits, cb * 3 * 4, st));
+    }
+    return SAPCU_OK;
+}
+
+// ============================================================================ fd
+struct FdPlan {
+    int64_t cb;
+    int kmax0, kk;
+};
+
+static FdPlan fd_plan(const sapcu_model* m, int64_t b, int mp) {
+    FdPlan pl;
+    // fd intermediates are ~1.4 MB per patch and T-strided; cap the chunk so the agg buffer stays small
+    pl.cb = b < m->chunk ? b : m->chunk;
+    if (pl.cb < 1) pl.cb = 1;
+    int kmax = 1;
+    for (int i = 0; i < m->nscale; ++i) kmax = kmax > m->ks[i] ? kmax : m->ks[i];
+    pl.kmax0 = imin(kmax, mp);
+    pl.kk = imin(m->k, mp);
+    return pl;
+}
+
+static int64_t fd_ws_bytes(const sapcu_model* m, int64_t b, int mp) {
+    const FdPlan pl = fd_plan(m, b, mp);
+    const int64_t P = pl.cb * mp;
+    int64_t fl = 0;
+    auto add = [&](int64_t n, int64_t esz) { fl += ((n * esz) + 255) & ~(int64_t)255; };
+    add(P * pl.kmax0, 4); add(3 * P * pl.kk, 4);
+    add(P * 64 * m->nscale, 4); add(P * 64, 4);
+    add((int64_t)m->T * P * 960, 4); add(P * 1024, 4); add((int64_t)m->T * P * m->emb, 4);
+    add((int64_t)m->T * pl.cb * m->emb, 4); add(pl.cb * m->emb, 4);
+    add(pl.cb * 256, 4);
+    for (int i = 0; i < 3; ++i) add(pl.cb * 128, 4);
+    for (int i = 0; i < 3; ++i) add(pl.cb * 64, 4);
+    add(pl.cb * 192, 4); add(pl.cb * 64, 4);
+    return fl + 256;
+}
+
+static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int mp, const int32_t* knn_force,
+                      float* dist, void* ws, int64_t ws_bytes, void* const* taps, hipStream_t st) {
+    const FdPlan pl = fd_plan(m, b, mp);
+    if (ws_bytes < fd_ws_bytes(m, b, mp)) {
+        set_error("fd_forward: workspace %lld B < required %lld B", (long long)ws_bytes, (long long)fd_ws_bytes(m, b, mp));
+        return SAPCU_ERR_WORKSPACE;
+    }
+    const int T = m->T, emb = m->emb;
+    static const int cin[4] = {0, 64, 128, 256}, cout[4] = {64, 128, 256, 512}, coff[4] = {0, 64, 192, 448};
+    for (int64_t s = 0; s < b; s += pl.cb) {
+        const int64_t cb = (b - s) < pl.cb ? (b - s) : pl.cb;
+        const int64_t P = cb * mp;
+        Arena A{(char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), ws_bytes, 0};
+        int32_t* idx0 = A.take<int32_t>(pl.cb * mp * pl.kmax0);
+        int32_t* idxb = A.take<int32_t>(3 * pl.cb * mp * pl.kk);
+        float* E0 = A.take<float>(pl.cb * mp * 64 * m->nscale);
+        float* FUSED = A.take<float>(pl.cb * mp * 64);
+        float* SPK = A.take<float>((int64_t)T * pl.cb * mp * 960);
+        float* AB = A.take<float>(pl.cb * mp * 1024);
+        float* AGG = A.take<float>((int64_t)T * pl.cb * mp * emb);
+        float* POOLED = A.take<float>((int64_t)T * pl.cb * emb);
+        float* ENC = A.take<float>(pl.cb * emb);
+        float* D1 = A.take<float>(pl.cb * 256);
+        float* D2a = A.take<float>(pl.cb * 128);
+        float* D2b = A.take<float>(pl.cb * 128);
+        float* D2c = A.take<float>(pl.cb * 128);
+        float* D3a = A.take<float>(pl.cb * 64);
+        float* D3b = A.take<float>(pl.cb * 64);
+        float* D3c = A.take<float>(pl.cb * 64);
+        float* QKV = A.take<float>(pl.cb * 192);
+        float* ATT = A.take<float>(pl.cb * 64);
+        const float* pc = patch + s * mp * 3;
+
+        // block 0: xyz kNN (all scales are prefixes of the sorted top-kmax list), EdgeConv x S,
+        // scale fusion, EIF over T steps                                           fd:411-444
+        SAPCU_TRY(launch_patch_knn(pc, cb, mp, 3, 3, pl.kmax0, idx0, st));
+        SAPCU_TRY(launch_fd_edge0(pc, idx0, pl.kmax0, P, mp, m->nscale, m->ks_dev, m->p(FD_E0_W), m->p(FD_E0_B), E0, st));
+        SAPCU_TRY(gemm(E0, P, 64 * m->nscale, 64 * m->nscale, m->p(FD_FUSE_W), 64, m->p(FD_FUSE_B), FUSED, 64,
+                       EPI_LRELU, st));
+        SAPCU_TRY(tap_copy(taps, SAPCU_FD_TAP_FUSED0, s * mp * 64 * 4, FUSED, P * 64 * 4, st));
+        SAPCU_TRY(launch_fd_neuron(true, 0, FUSED, 64, nullptr, 0, mp, nullptr, P, 64, m->p(FD_SNN0), T, SPK, 960, 0,
+                                   nullptr, m->gate_dev, st));
+        // blocks 1..3: feature-space kNN on the t=0 spikes, factored EdgeConv, neuron  fd:447-474
+        for (int l = 1; l <= 3; ++l) {
+            int32_t* idl = idxb + (int64_t)(l - 1) * pl.cb * mp * pl.kk;
+            const float* F = SPK + coff[l - 1];   // t = 0 slab, row stride 960
+            if (knn_force) {
+                SAPCU_CHECK_HIP(hipMemcpyAsync(idl, knn_force + ((int64_t)(l - 1) * b + s) * mp * pl.kk, P * pl.kk * 4,
+                                               hipMemcpyDeviceToDevice, st));
+            } else {
+                SAPCU_TRY(launch_patch_knn_strided(F, cb, (int64_t)mp * 960, mp, cin[l], 960, pl.kk, idl, st));
+            }
+            if (taps && taps[SAPCU_FD_TAP_KNN])
+                SAPCU_CHECK_HIP(hipMemcpyAsync((int32_t*)taps[SAPCU_FD_TAP_KNN] + ((int64_t)(l - 1) * b + s) * mp * pl.kk,
+                                               idl, P * pl.kk * 4, hipMemcpyDeviceToDevice, st));
+            const int ew = FD_EDGE1_W + 3 * (l - 1);
+            SAPCU_TRY(gemm(F, P, cin[l], 960, m->p(ew), 2 * cout[l], nullptr, AB, 2 * cout[l], EPI_BIAS, st));
+            SAPCU_TRY(launch_fd_neuron(l == 1, 1, AB, 2 * cout[l], idl, pl.kk, mp, m->p(ew + 1), P, cout[l], m->p(ew + 2),
+                                       T, SPK, 960, coff[l], nullptr, m->gate_dev, st));
+        }
+        if (taps && taps[SAPCU_FD_TAP_SPIKES]) {
+            for (int t = 0; t < T; ++t)
+                SAPCU_CHECK_HIP(hipMemcpyAsync((float*)taps[SAPCU_FD_TAP_SPIKES] + ((int64_t)t * b + s) * mp * 960,
+                                               SPK + (int64_t)t * P * 960, P * 960 * 4, hipMemcpyDeviceToDevice, st));
+        }
+        // multi_scale_conv + BN + LeakyReLU over all T*P rows, max over points        fd:476-480
+        SAPCU_TRY(gemm(SPK, (int64_t)T * P, 960, 960, m->p(FD_MSC_W), emb, m->p(FD_MSC_B), AGG, emb, EPI_LRELU, st));
+        SAPCU_TRY(launch_rowgroup_max(AGG, (int64_t)T * cb, mp, emb, POOLED, st));
+        if (taps && taps[SAPCU_FD_TAP_POOLED]) {
+            for (int t = 0; t < T; ++t)
+                SAPCU_CHECK_HIP(hipMemcpyAsync((float*)taps[SAPCU_FD_TAP_POOLED] + ((int64_t)t * b + s) * emb,
+                                               POOLED + (int64_t)t * cb * emb, cb * emb * 4, hipMemcpyDeviceToDevice, st));
+        }
+        SAPCU_TRY(launch_fd_temporal(POOLED, T, cb, emb, m->p(FD_TI_W), m->p(FD_SNNFC), ENC, st));
+        SAPCU_TRY(tap_copy(taps, SAPCU_FD_TAP_ENC, s * emb * 4, ENC, cb * emb * 4, st));
+        // decoder                                                                    fd:711-725
+        SAPCU_TRY(gemm(ENC, cb, emb, emb, m->p(FD_FCIN_W), 256, m->p(FD_FCIN_B), D1, 256, EPI_GELU, st));
+        SAPCU_TRY(gemm(D1, cb, 256, 256, m->p(FD_R0_FC0_W), 128, m->p(FD_R0_FC0_B), D2a, 128, EPI_GELU, st));
+        SAPCU_TRY(gemm(D1, cb, 256, 256, m->p(FD_R0_PROJ_W), 128, m->p(FD_R0_PROJ_B), D2b, 128, EPI_BIAS, st));
+        SAPCU_TRY(gemm(D2a, cb, 128, 128, m->p(FD_R0_FC4_W), 128, m->p(FD_R0_FC4_B), D2c, 128, EPI_RESID_GELU, st,
+                       nullptr, 0, D2b, 128));
+        SAPCU_TRY(gemm(D2c, cb, 128, 128, m->p(FD_R1_FC0_W), 64, m->p(FD_R1_FC0_B), D3a, 64, EPI_GELU, st));
+        SAPCU_TRY(gemm(D2c, cb, 128, 128, m->p(FD_R1_PROJ_W), 64, m->p(FD_R1_PROJ_B), D3b, 64, EPI_BIAS, st));
+        SAPCU_TRY(gemm(D3a, cb, 64, 64, m->p(FD_R1_FC4_W), 64, m->p(FD_R1_FC4_B), D3c, 64, EPI_RESID_GELU, st, nullptr,
+                       0, D3b, 64));
+        SAPCU_TRY(gemm(D3c, cb, 64, 64, m->p(FD_QKV_W), 192, m->p(FD_QKV_B), QKV, 192, EPI_BIAS, st));
+        SAPCU_TRY(launch_fd_tail(D3c, QKV, cb, m->heads, m->p(FD_WO_T), m->p(FD_BO), m->p(FD_LN_W), m->p(FD_LN_B),
+                                 m->p(FD_WH_T), m->p(FD_BH), m->p(FD_WD), m->p(FD_BD), ATT, dist + s, st));
+    }
+    return SAPCU_OK;
+}
+
+}  // namespace sapcu
+
+// ================================================================================== C ABI
+using namespace sapcu;
+
+extern "C" {
+
+int sapcu_abi_version(void) { return SAPCU_ABI_VERSION; }
+const char* sapcu_last_error(void) { return g_err; }
+
+int sapcu_knn_gather_f64(const double* cloud, int64_t n, const double* queries, int64_t b, int k, int64_t* idx_out,
+                         double* dist_out, float* patch_out, void* stream) {
+    SAPCU_CHECK_ARG(cloud && queries && idx_out, "knn_gather: null pointer");
+    SAPCU_CHECK_ARG(n >= 1 && b >= 0 && k >= 1 && k <= 128 && k <= n, "knn_gather: need 1 <= k <= min(128, n) (n=%lld k=%d)",
+                    (long long)n, k);
+    SAPCU_CHECK_ARG(n < 0x7fffffffLL, "knn_gather: n too large");
+    return launch_knn_outer(cloud, n, queries, b, k, idx_out, dist_out, patch_out, (hipStream_t)stream);
+}
+
+int sapcu_gather_rotate_f64(const double* cloud, int64_t n, const double* queries, int64_t b, const int64_t* idx, int k,
+                            const float* normals, float* patch_out, void* stream) {
+    SAPCU_CHECK_ARG(cloud && queries && idx && patch_out, "gather_rotate: null pointer");
+    SAPCU_CHECK_ARG(n >= 1 && b >= 0 && k >= 1, "gather_rotate: bad sizes");
+    return launch_gather_rotate(cloud, n, queries, b, idx, k, normals, patch_out, (hipStream_t)stream);
+}
+
+int sapcu_displace_f64(const double* queries, const float* normals, const float* dist, int64_t b, double* out,
+                       void* stream) {
+    SAPCU_CHECK_ARG(queries && normals && dist && out && b >= 0, "displace: bad argument");
+    return launch_displace(queries, normals, dist, b, out, (hipStream_t)stream);
+}
+
+int sapcu_neuron_selfloop(const float* x, int64_t rows, int channels, int steps, const float* membrane_decay,
+                          const float* threshold_adapt, const float* refractory_decay, const float* threshold_base,
+                          const float* delta_T, const float* theta_rh, float* spikes_out, float* membrane_out,
+                          float* threshold_out, float* refractory_out, void* stream) {
+    SAPCU_CHECK_ARG(x && membrane_decay && threshold_adapt && refractory_decay && threshold_base, "neuron: null pointer");
+    SAPCU_CHECK_ARG((delta_T == nullptr) == (theta_rh == nullptr), "neuron: delta_T and theta_rh go together");
+    SAPCU_CHECK_ARG(rows >= 0 && channels >= 1 && steps >= 1, "neuron: bad sizes");
+    return launch_neuron_selfloop(x, rows, channels, steps, membrane_decay, threshold_adapt, refractory_decay,
+                                  threshold_base, delta_T, theta_rh, spikes_out, membrane_out, threshold_out,
+                                  refractory_out, (hipStream_t)stream);
+}
+
+int sapcu_patch_knn(const float* feat, int64_t b, int m, int c, int ld, int k, int32_t* idx_out, void* stream) {
+    SAPCU_CHECK_ARG(feat && idx_out && b >= 0 && ld >= c, "patch_knn: bad argument");
+    return launch_patch_knn(feat, b, m, c, ld, k, idx_out, (hipStream_t)stream);
+}
+
+int sapcu_l2_normalize3(const float* in, float* out, int64_t b, void* stream) {
+    SAPCU_CHECK_ARG(in && out && b >= 0, "l2_normalize3: bad argument");
+    return launch_l2_normalize3(in, out, b, (hipStream_t)stream);
+}
+
+int sapcu_gemm_f32(const float* a, int64_t r, int k, int lda, const float* w, int n, const float* bias, float* c,
+                   int ldc, void* stream) {
+    SAPCU_CHECK_ARG(a && w && c && r >= 0 && n >= 1, "gemm: bad argument");
+    return gemm(a, r, k, lda, w, n, bias, c, ldc, EPI_BIAS, (hipStream_t)stream);
+}
+
+int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob, int64_t blob_floats,
+                       const int64_t* dir_host, int n_dir, sapcu_model_t* out) {
+    SAPCU_CHECK_ARG(hp && blob && dir_host && out && blob_floats > 0, "model_create: null pointer");
+    sapcu_model* m = new (std::nothrow) sapcu_model();
+    SAPCU_CHECK_ARG(m != nullptr, "model_create: out of host memory");
+    m->kind = kind;
+    m->ks_dev = nullptr;
+    m->gate_dev = nullptr;
+    m->blob = nullptr;
+    const char* ce = getenv("SAPCU_CHUNK");
+    m->chunk = ce ? atoll(ce) : 512;
+    if (m->chunk < 1) m->chunk = 1;
+    int rc = SAPCU_OK;
+    if (kind == SAPCU_KIND_FN) {
+        if (n_hp != 6 || n_dir != FN_SLOTS) {
+            set_error("model_create(fn): need 6 hparams and %d slots (got %d, %d)", (int)FN_SLOTS, n_hp, n_dir);
+            rc = SAPCU_ERR_ARG;
+        } else {
+            m->kv[0] = hp[0]; m->kv[1] = hp[1]; m->kv[2] = hp[2];
+            m->emb = hp[3]; m->T = hp[4]; m->heads = hp[5];
+            if (m->kv[0] < 1 || m->kv[1] < 1 || m->kv[2] < 1 || m->emb < 32 || m->emb % 32 || m->T < 1 || m->heads < 1 ||
+                128 % m->heads) {
+                set_error("model_create(fn): unsupported hyper-parameters");
+                rc = SAPCU_ERR_ARG;
+            }
+        }
+    } else if (kind == SAPCU_KIND_FD) {
+        if (n_hp < 6 || n_dir != FD_SLOTS || hp[4] < 1 || hp[4] > 8 || n_hp != 5 + hp[4]) {
+            set_error("model_create(fd): need [k,emb,T,heads,S,ks...] and %d slots", (int)FD_SLOTS);
+            rc = SAPCU_ERR_ARG;
+        } else {
+            m->k = hp[0]; m->emb = hp[1]; m->T = hp[2]; m->heads = hp[3]; m->nscale = hp[4];
+            for (int i = 0; i < m->nscale; ++i) m->ks[i] = hp[5 + i];
+            if (m->k < 1 || m->emb < 32 || m->emb % 32 || m->T < 1 || m->T > 64 || m->heads < 1) {
+                set_error("model_create(fd): unsupported hyper-parameters");
+                rc = SAPCU_ERR_ARG;
+            }
+        }
+    } else {
+        set_error("model_create: unknown kind %d", kind);
+        rc = SAPCU_ERR_ARG;
+    }
+    if (rc == SAPCU_OK) {
+        m->dir.assign(dir_host, dir_host + n_dir);
+        for (int i = 0; i < n_dir; ++i)
+            if (m->dir[i] < 0 || m->dir[i] >= blob_floats || (m->dir[i] & 3)) {
+                set_error("model_create: slot %d offset %lld out of range / unaligned", i, (long long)m->dir[i]);
+                rc = SAPCU_ERR_ARG;
+                break;
+            }
+    }
+    auto hip_ok = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == SAPCU_OK) {
+            set_error("model_create: %s failed: %s", what, hipGetErrorString(e));
+            rc = SAPCU_ERR_HIP;
+        }
+    };
+    if (rc == SAPCU_OK) {
+        m->blob_floats = blob_floats;
+        hip_ok(hipMalloc((void**)&m->blob, (size_t)blob_floats * 4), "hipMalloc(blob)");
+        if (rc == SAPCU_OK) hip_ok(hipMemcpy(m->blob, blob, (size_t)blob_floats * 4, hipMemcpyDeviceToDevice), "copy blob");
+        if (rc == SAPCU_OK && kind == SAPCU_KIND_FD) {
+            hip_ok(hipMalloc((void**)&m->ks_dev, 8 * sizeof(int32_t)), "hipMalloc(ks)");
+            if (rc == SAPCU_OK) hip_ok(hipMemcpy(m->ks_dev, m->ks, 8 * sizeof(int32_t), hipMemcpyHostToDevice), "copy ks");
+            if (rc == SAPCU_OK) hip_ok(hipMalloc((void**)&m->gate_dev, sizeof(int)), "hipMalloc(gate)");
+            if (rc == SAPCU_OK) hip_ok(hipMemset(m->gate_dev, 0, sizeof(int)), "memset gate");
+        }
+    }
+    if (rc != SAPCU_OK) {
+        if (m->blob) (void)hipFree(m->blob);
+        if (m->ks_dev) (void)hipFree(m->ks_dev);
+        if (m->gate_dev) (void)hipFree(m->gate_dev);
+        delete m;
+        return rc;
+    }
+    *out = m;
+    return SAPCU_OK;
+}
+
+int sapcu_model_destroy(sapcu_model_t m) {
+    if (!m) return SAPCU_OK;
+    if (m->blob) (void)hipFree(m->blob);
+    if (m->ks_dev) (void)hipFree(m->ks_dev);
+    if (m->gate_dev) (void)hipFree(m->gate_dev);
+    delete m;
+    return SAPCU_OK;
+}
+
+int64_t sapcu_workspace_bytes(sapcu_model_t m, int64_t b, int m_pts) {
+    if (!m || b < 0 || m_pts < 1 || m_pts > 128) {
+        set_error("workspace_bytes: bad argument");
+        return SAPCU_ERR_ARG;
+    }
+    return m->kind == SAPCU_KIND_FN ? fn_ws_bytes(m, b, m_pts) : fd_ws_bytes(m, b, m_pts);
+}
+
+int sapcu_model_gate_violations(sapcu_model_t m, int* count_host) {
+    SAPCU_CHECK_ARG(m && count_host, "gate_violations: null pointer");
+    *count_host = 0;
+    if (m->gate_dev) SAPCU_CHECK_HIP(hipMemcpy(count_host, m->gate_dev, sizeof(int), hipMemcpyDeviceToHost));
+    return SAPCU_OK;
+}
+
+int sapcu_fn_forward(sapcu_model_t m, const float* patch, int64_t b, int m_pts, const int32_t* knn_in, int32_t* knn_out,
+                     float* normals_out, void* workspace, int64_t ws_bytes, void* const* taps_host, void* stream) {
+    SAPCU_CHECK_ARG(m && m->kind == SAPCU_KIND_FN, "fn_forward: not an fn model handle");
+    SAPCU_CHECK_ARG(patch && normals_out && workspace, "fn_forward: null pointer");
+    SAPCU_CHECK_ARG(b >= 0 && m_pts >= 1 && m_pts <= 128, "fn_forward: need 1 <= m_pts <= 128 (got %d)", m_pts);
+    return fn_forward(m, patch, b, m_pts, knn_in, knn_out, normals_out, workspace, ws_bytes, taps_host,
+                      (hipStream_t)stream);
+}
+
+int sapcu_fd_forward(sapcu_model_t m, const float* patch, int64_t b, int m_pts, const int32_t* knn_force, float* dist_out,
+                     void* workspace, int64_t ws_bytes, void* const* taps_host, void* stream) {
+    SAPCU_CHECK_ARG(m && m->kind == SAPCU_KIND_FD, "fd_forward: not an fd model handle");
+    SAPCU_CHECK_ARG(patch && dist_out && workspace, "fd_forward: null pointer");
+    SAPCU_CHECK_ARG(b >= 0 && m_pts >= 1 && m_pts <= 128, "fd_forward: need 1 <= m_pts <= 128 (got %d)", m_pts);
+    return fd_forward(m, patch, b, m_pts, knn_force, dist_out, workspace, ws_bytes, taps_host, (hipStream_t)stream);
+}
+
+}  // extern "C"

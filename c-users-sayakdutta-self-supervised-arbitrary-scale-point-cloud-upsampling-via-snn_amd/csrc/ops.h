@@ -1,0 +1,34 @@
+// Launchers of patch_ops.hip (host side), used by model.hip and api.hip.
+#pragma once
+#include "common.h"
+
+namespace sapcu {
+
+int launch_patch_knn_strided(const float* feat, int64_t b, int64_t pstride, int m, int c, int ld, int k,
+                             int32_t* idx, hipStream_t st);
+int launch_patch_knn(const float* feat, int64_t b, int m, int c, int ld, int k, int32_t* idx, hipStream_t st);
+int launch_neuron_selfloop(const float* x, int64_t rows, int ch, int T, const float* md, const float* ta,
+                           const float* rd, const float* tb, const float* dT, const float* rh, float* so, float* mo,
+                           float* to, float* ro, hipStream_t st);
+int launch_fn_stem(const float* patch, int64_t rows, const float* w, const float* bias, const float* lif, int T,
+                   float* out, hipStream_t st);
+int launch_fn_pe1(const float* patch, const int32_t* idx, int64_t rows, int m, int kk, int d, const float* w,
+                  const float* bias, const float* lif, int T, float* out, hipStream_t st);
+int launch_fn_softmax_agg(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx, int64_t pts,
+                          int m, int kk, int d, float sqrt_hd, float* res, hipStream_t st);
+int launch_rowgroup_max(const float* in, int64_t groups, int m, int c, float* out, hipStream_t st);
+int launch_fn_tail(const float* h, int64_t b, int kdim, const float* w, const float* bias, const float* lnw,
+                   const float* lnb, float* logits, float* normals, hipStream_t st);
+int launch_l2_normalize3(const float* in, float* out, int64_t b, hipStream_t st);
+int launch_fd_edge0(const float* patch, const int32_t* idx, int kmax, int64_t pts, int m, int nscale,
+                    const int32_t* ks_dev, const float* w, const float* bias, float* out, hipStream_t st);
+int launch_fd_neuron(bool eif, int mode, const float* in, int ldi, const int32_t* idx, int kk, int m,
+                     const float* shift, int64_t pts, int C, const float* prm, int T, float* spk, int ldo, int coff,
+                     float* pre_out, int* gate_violations, hipStream_t st);
+int launch_fd_temporal(const float* pooled, int T, int64_t b, int emb, const float* tw, const float* lif, float* out,
+                       hipStream_t st);
+int launch_fd_tail(const float* x, const float* qkv, int64_t b, int heads, const float* wo_t, const float* bo,
+                   const float* lnw, const float* lnb, const float* wh_t, const float* bh, const float* wd,
+                   const float* bd, float* attn_out, float* dist, hipStream_t st);
+
+}  // namespace sapcu

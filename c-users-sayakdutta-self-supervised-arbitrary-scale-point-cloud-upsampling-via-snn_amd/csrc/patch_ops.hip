@@ -1,0 +1,565 @@
+// Per-patch and element-wise kernels around the GEMMs: in-patch kNN, neuron loops, positional
+// encoding, vector-attention softmax/aggregation, pooling, EdgeConv max, network tails.
+// Everything here is HBM/VALU work with channel-fastest ([row][channel]) layouts so that a
+// wavefront's 64 lanes touch 256 contiguous bytes.
+#include "common.h"
+#include "ops.h"
+
+namespace sapcu {
+
+// =============================================================================================
+// In-patch kNN  (fn/snn_coder.py:31-39, fd/snn_coder.py:25-32)
+//   score[i][j] = (-xx[j] - (-2 * <xi,xj>)) - xx[i],  <.,.> = c-ascending f32 FMA chain (bitwise
+//   what torch's matmul produces for c = 3), xx = sequential sum of rounded squares.
+//   top-k by descending score, equal scores by ascending index.
+// One 256-thread workgroup per patch; scores live in LDS.
+// =============================================================================================
+constexpr int PK_CH = 32;   // channel chunk staged in LDS
+
+__global__ __launch_bounds__(256) void patch_knn_kernel(const float* __restrict__ feat, int64_t pstride, int m,
+                                                        int c, int ld, int k, int32_t* __restrict__ idx_out) {
+    extern __shared__ float sm[];
+    float* S = sm;                      // [m][m+1]
+    float* xx = S + m * (m + 1);        // [m]
+    float* F = xx + m;                  // [m][PK_CH+1]
+    const int tid = threadIdx.x;
+    const float* base = feat + (int64_t)blockIdx.x * pstride;
+    const int npairs = m * m;
+    constexpr int MAXP = 64;            // m <= 128 -> <= 64 pairs per thread
+    float acc[MAXP];
+#pragma unroll
+    for (int t = 0; t < MAXP; ++t) acc[t] = 0.f;
+    float myxx = 0.f;
+    for (int c0 = 0; c0 < c; c0 += PK_CH) {
+        const int cw = min(PK_CH, c - c0);
+        __syncthreads();
+        for (int e = tid; e < m * cw; e += 256) {
+            const int i = e / cw, cc = e % cw;
+            F[i * (PK_CH + 1) + cc] = base[(int64_t)i * ld + c0 + cc];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < MAXP; ++t) {
+            const int p = tid + 256 * t;
+            if (p < npairs) {
+                const int i = p / m, j = p % m;
+                const float* fi = F + i * (PK_CH + 1);
+                const float* fj = F + j * (PK_CH + 1);
+                float a = acc[t];
+                if (c0 == 0) {
+                    a = __fmul_rn(fi[0], fj[0]);
+                    for (int cc = 1; cc < cw; ++cc) a = __fmaf_rn(fi[cc], fj[cc], a);
+                } else {
+                    for (int cc = 0; cc < cw; ++cc) a = __fmaf_rn(fi[cc], fj[cc], a);
+                }
+                acc[t] = a;
+            }
+        }
+        if (tid < m) {
+            const float* fi = F + tid * (PK_CH + 1);
+            for (int cc = 0; cc < cw; ++cc) {
+                const float sq = __fmul_rn(fi[cc], fi[cc]);
+                myxx = (c0 == 0 && cc == 0) ? sq : __fadd_rn(myxx, sq);
+            }
+        }
+    }
+    if (tid < m) xx[tid] = myxx;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < MAXP; ++t) {
+        const int p = tid + 256 * t;
+        if (p < npairs) {
+            const int i = p / m, j = p % m;
+            const float inner = __fmul_rn(-2.0f, acc[t]);
+            S[i * (m + 1) + j] = __fsub_rn(__fsub_rn(-xx[j], inner), xx[i]);
+        }
+    }
+    __syncthreads();
+    // rank by counting: one wave per row, lane owns columns lane and lane+64
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int i = wave; i < m; i += 4) {
+        const float* row = S + i * (m + 1);
+        const int j0 = lane, j1 = lane + 64;
+        const float s0 = j0 < m ? row[j0] : 0.f;
+        const float s1 = j1 < m ? row[j1] : 0.f;
+        int r0 = 0, r1 = 0;
+        for (int jp = 0; jp < m; ++jp) {
+            const float sv = row[jp];
+            r0 += (sv > s0) || (sv == s0 && jp < j0);
+            r1 += (sv > s1) || (sv == s1 && jp < j1);
+        }
+        int32_t* o = idx_out + ((int64_t)blockIdx.x * m + i) * k;
+        if (j0 < m && r0 < k) o[r0] = j0;
+        if (j1 < m && r1 < k) o[r1] = j1;
+    }
+}
+
+int launch_patch_knn_strided(const float* feat, int64_t b, int64_t pstride, int m, int c, int ld, int k,
+                             int32_t* idx, hipStream_t st) {
+    if (b == 0) return SAPCU_OK;
+    SAPCU_CHECK_ARG(m >= 1 && m <= 128 && k >= 1 && k <= m && c >= 1, "patch_knn: need 1<=k<=m<=128 (m=%d k=%d c=%d)",
+                    m, k, c);
+    const size_t lds = (size_t)(m * (m + 1) + m + m * (PK_CH + 1)) * sizeof(float);
+    hipLaunchKernelGGL(patch_knn_kernel, dim3((unsigned)b), dim3(256), lds, st, feat, pstride, m, c, ld, k, idx);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+int launch_patch_knn(const float* feat, int64_t b, int m, int c, int ld, int k, int32_t* idx, hipStream_t st) {
+    return launch_patch_knn_strided(feat, b, (int64_t)m * ld, m, c, ld, k, idx, st);
+}
+
+// =============================================================================================
+// Neuron unit kernel (parity tests of the step arithmetic; fn:87-153, fd:198-275)
+// =============================================================================================
+template <bool EIF>
+__global__ __launch_bounds__(256) void neuron_selfloop_kernel(const float* __restrict__ x, int64_t total, int ch,
+                                                              int T, const float* md, const float* ta,
+                                                              const float* rd, const float* tb, const float* dT,
+                                                              const float* rh, float* so, float* mo, float* to,
+                                                              float* ro) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int c = (int)(t % ch);
+    NeuronP p;
+    p.decay = clampf(md[c], 0.1f, 0.99f);
+    p.adapt = clampf(ta[c], 0.001f, 0.1f);
+    p.rdecay = clampf(rd[c], 0.1f, 0.95f);
+    p.theta0 = tb[c];
+    p.dT = EIF ? clampf(dT[c], 0.1f, 5.0f) : 0.f;
+    p.rh = EIF ? clampf(rh[c], 0.1f, 2.0f) : 0.f;
+    NeuronS s = neuron_init(p);
+    float v = x[t];
+    for (int i = 0; i < T; ++i) v = neuron_step<EIF>(v, s, p);
+    if (so) so[t] = v;
+    if (mo) mo[t] = s.m;
+    if (to) to[t] = s.th;
+    if (ro) ro[t] = s.r;
+}
+
+int launch_neuron_selfloop(const float* x, int64_t rows, int ch, int T, const float* md, const float* ta,
+                           const float* rd, const float* tb, const float* dT, const float* rh, float* so, float* mo,
+                           float* to, float* ro, hipStream_t st) {
+    const int64_t total = rows * ch;
+    if (total == 0) return SAPCU_OK;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (dT)
+        hipLaunchKernelGGL(neuron_selfloop_kernel<true>, dim3(grid), dim3(256), 0, st, x, total, ch, T, md, ta, rd, tb,
+                           dT, rh, so, mo, to, ro);
+    else
+        hipLaunchKernelGGL(neuron_selfloop_kernel<false>, dim3(grid), dim3(256), 0, st, x, total, ch, T, md, ta, rd,
+                           tb, dT, rh, so, mo, to, ro);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+// =============================================================================================
+// fn: stem conv1(3->64)+BN -> LIF x T_enc   (fn/snn_coder.py:453-457)
+//     rows = b*m points, thread per (row, channel)
+// =============================================================================================
+__global__ __launch_bounds__(256) void fn_stem_kernel(const float* __restrict__ patch, int64_t rows,
+                                                      const float* __restrict__ w /*[64][3]*/,
+                                                      const float* __restrict__ bias, const float* __restrict__ lif,
+                                                      int T, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * 64) return;
+    const int c = (int)(t & 63);
+    const int64_t r = t >> 6;
+    const float x = patch[r * 3], y = patch[r * 3 + 1], z = patch[r * 3 + 2];
+    float a = __fmul_rn(w[c * 3], x);
+    a = __fmaf_rn(w[c * 3 + 1], y, a);
+    a = __fmaf_rn(w[c * 3 + 2], z, a);
+    a = __fadd_rn(a, bias[c]);
+    out[t] = lif_selfloop(a, load_lif(lif, 64, c), T);
+}
+
+int launch_fn_stem(const float* patch, int64_t rows, const float* w, const float* bias, const float* lif, int T,
+                   float* out, hipStream_t st) {
+    if (rows == 0) return SAPCU_OK;
+    hipLaunchKernelGGL(fn_stem_kernel, dim3((unsigned)((rows * 64 + 255) / 256)), dim3(256), 0, st, patch, rows, w,
+                       bias, lif, T, out);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+// =============================================================================================
+// fn: positional encoding stage 1: fc_delta(3->d)+BN on (x_i - x_j) -> LIF x 4  (fn:310,355-358)
+//     rows = b*m*kk edges, thread per (edge, channel); output [rows, d]
+// =============================================================================================
+__global__ __launch_bounds__(256) void fn_pe1_kernel(const float* __restrict__ patch, const int32_t* __restrict__ idx,
+                                                     int64_t rows, int m, int kk, int d,
+                                                     const float* __restrict__ w /*[d][3]*/,
+                                                     const float* __restrict__ bias, const float* __restrict__ lif,
+                                                     int T, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * d) return;
+    const int c = (int)(t % d);
+    const int64_t r = t / d;
+    const int64_t pt = r / kk;
+    const int64_t patch_i = pt / m;
+    const float* pi = patch + pt * 3;
+    const float* pj = patch + (patch_i * m + idx[r]) * 3;
+    const float dx = __fsub_rn(pi[0], pj[0]), dy = __fsub_rn(pi[1], pj[1]), dz = __fsub_rn(pi[2], pj[2]);
+    float a = __fmul_rn(w[c * 3], dx);
+    a = __fmaf_rn(w[c * 3 + 1], dy, a);
+    a = __fmaf_rn(w[c * 3 + 2], dz, a);
+    a = __fadd_rn(a, bias[c]);
+    out[t] = lif_selfloop(a, load_lif(lif, d, c), T);
+}
+
+int launch_fn_pe1(const float* patch, const int32_t* idx, int64_t rows, int m, int kk, int d, const float* w,
+                  const float* bias, const float* lif, int T, float* out, hipStream_t st) {
+    if (rows == 0) return SAPCU_OK;
+    const int64_t total = rows * d;
+    SAPCU_CHECK_ARG((total + 255) / 256 < 0x7fffffffLL, "pe1: too many elements");
+    hipLaunchKernelGGL(fn_pe1_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, patch, idx, rows, m, kk,
+                       d, w, bias, lif, T, out);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+// =============================================================================================
+// fn: per-channel softmax over the kk neighbours and aggregation (fn:379-389)
+//     attn = softmax(a / sqrt(hd));  res[pt,c] = sum_j attn_j * (v[nbr_j, c] + pe[edge_j, c])
+//     thread per (point, channel)
+// =============================================================================================
+__global__ __launch_bounds__(256) void fn_softmax_agg_kernel(const float* __restrict__ a, const float* __restrict__ pe,
+                                                             const float* __restrict__ v, int ldv,
+                                                             const int32_t* __restrict__ idx, int64_t pts, int m,
+                                                             int kk, int d, float sqrt_hd, float* __restrict__ res) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pts * d) return;
+    const int c = (int)(t % d);
+    const int64_t pt = t / d;
+    const int64_t patch_i = pt / m;
+    const float* ar = a + pt * kk * d + c;
+    const float* pr = pe + pt * kk * d + c;
+    const int32_t* ir = idx + pt * kk;
+    float mx = -__builtin_huge_valf();
+    for (int j = 0; j < kk; ++j) mx = fmaxf(mx, __fdiv_rn(ar[(int64_t)j * d], sqrt_hd));
+    float den = 0.f;
+    for (int j = 0; j < kk; ++j) den = __fadd_rn(den, expf(__fsub_rn(__fdiv_rn(ar[(int64_t)j * d], sqrt_hd), mx)));
+    float acc = 0.f;
+    for (int j = 0; j < kk; ++j) {
+        const float w = __fdiv_rn(expf(__fsub_rn(__fdiv_rn(ar[(int64_t)j * d], sqrt_hd), mx)), den);
+        const float vv = __fadd_rn(v[(patch_i * m + ir[j]) * ldv + c], pr[(int64_t)j * d]);
+        acc = __fmaf_rn(w, vv, acc);
+    }
+    res[t] = acc;
+}
+
+int launch_fn_softmax_agg(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx, int64_t pts,
+                          int m, int kk, int d, float sqrt_hd, float* res, hipStream_t st) {
+    if (pts == 0) return SAPCU_OK;
+    hipLaunchKernelGGL(fn_softmax_agg_kernel, dim3((unsigned)((pts * d + 255) / 256)), dim3(256), 0, st, a, pe, v, ldv,
+                       idx, pts, m, kk, d, sqrt_hd, res);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+// =============================================================================================
+// max over groups of m consecutive rows: in [groups*m, c] -> out [groups, c]  (fn:472, fd:479)
+// =============================================================================================
+__global__ __launch_bounds__(256) void rowgroup_max_kernel(const float* __restrict__ in, int64_t groups, int m, int c,
+                                                           float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= groups * c) return;
+    const int cc = (int)(t % c);
+    const int64_t g = t / c;
+    const float* p = in + g * m * c + cc;
+    float mx = p[0];
+    for (int i = 1; i < m; ++i) mx = fmaxf(mx, p[(int64_t)i * c]);
+    out[t] = mx;
+}
+
+int launch_rowgroup_max(const float* in, int64_t groups, int m, int c, float* out, hipStream_t st) {
+    if (groups == 0) return SAPCU_OK;
+    hipLaunchKernelGGL(rowgroup_max_kernel, dim3((unsigned)((groups * c + 255) / 256)), dim3(256), 0, st, in, groups,
+                       m, c, out);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+// =============================================================================================
+// fn tail: Linear(256->3) -> LayerNorm(3, eps 1e-5) -> F.normalize (fn:545-548); one wave per row
+// =============================================================================================
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void fn_tail_kernel(const float* __restrict__ h, int64_t b, int kdim,
+                                                      const float* __restrict__ w /*[3][kdim]*/,
+                                                      const float* __restrict__ bias, const float* __restrict__ lnw,
+                                                      const float* __restrict__ lnb, float* __restrict__ logits,
+                                                      float* __restrict__ normals) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= b) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int k = lane; k < kdim; k += 64) {
+        const float x = h[row * kdim + k];
+        s0 = fmaf(x, w[k], s0);
+        s1 = fmaf(x, w[kdim + k], s1);
+        s2 = fmaf(x, w[2 * kdim + k], s2);
+    }
+    s0 = wave_sum(s0) + bias[0];
+    s1 = wave_sum(s1) + bias[1];
+    s2 = wave_sum(s2) + bias[2];
+    if (lane != 0) return;
+    if (logits) {
+        logits[row * 3] = s0;
+        logits[row * 3 + 1] = s1;
+        logits[row * 3 + 2] = s2;
+    }
+    const float mean = (s0 + s1 + s2) / 3.0f;
+    const float d0 = s0 - mean, d1 = s1 - mean, d2 = s2 - mean;
+    const float var = (d0 * d0 + d1 * d1 + d2 * d2) / 3.0f;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float y0 = d0 * rstd * lnw[0] + lnb[0];
+    const float y1 = d1 * rstd * lnw[1] + lnb[1];
+    const float y2 = d2 * rstd * lnw[2] + lnb[2];
+    const float nn = fmaxf(sqrtf(y0 * y0 + y1 * y1 + y2 * y2), 1e-12f);
+    normals[row * 3] = y0 / nn;
+    normals[row * 3 + 1] = y1 / nn;
+    normals[row * 3 + 2] = y2 / nn;
+}
+
+int launch_fn_tail(const float* h, int64_t b, int kdim, const float* w, const float* bias, const float* lnw,
+                   const float* lnb, float* logits, float* normals, hipStream_t st) {
+    if (b == 0) return SAPCU_OK;
+    hipLaunchKernelGGL(fn_tail_kernel, dim3((unsigned)((b + 3) / 4)), dim3(256), 0, st, h, b, kdim, w, bias, lnw, lnb,
+                       logits, normals);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+__global__ __launch_bounds__(256) void l2_normalize3_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            int64_t b) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b) return;
+    const float x = in[t * 3], y = in[t * 3 + 1], z = in[t * 3 + 2];
+    const float nn = fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);
+    out[t * 3] = x / nn;
+    out[t * 3 + 1] = y / nn;
+    out[t * 3 + 2] = z / nn;
+}
+
+int launch_l2_normalize3(const float* in, float* out, int64_t b, hipStream_t st) {
+    if (b == 0) return SAPCU_OK;
+    hipLaunchKernelGGL(l2_normalize3_kernel, dim3((unsigned)((b + 255) / 256)), dim3(256), 0, st, in, out, b);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+// =============================================================================================
+// fd block 0: multi-scale EdgeConv(6->64)+BN+LeakyReLU, max over the ks nearest (fd:413-420)
+//     feature = cat(x_j - x_i, x_j); LeakyReLU is monotone so it is applied once after the max.
+//     thread per (point, scale*64 + channel); out [pts, 64*S]
+// =============================================================================================
+__global__ __launch_bounds__(256) void fd_edge0_kernel(const float* __restrict__ patch, const int32_t* __restrict__ idx,
+                                                       int kmax, int64_t pts, int m, int nscale,
+                                                       const int32_t* __restrict__ ks /*[S] device*/,
+                                                       const float* __restrict__ w /*[S][64][6]*/,
+                                                       const float* __restrict__ bias /*[S][64]*/,
+                                                       float* __restrict__ out) {
+    const int cs = 64 * nscale;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pts * cs) return;
+    const int col = (int)(t % cs);
+    const int64_t pt = t / cs;
+    const int64_t patch_i = pt / m;
+    const int s = col >> 6;
+    const float* ww = w + (int64_t)col * 6;
+    const float xi = patch[pt * 3], yi = patch[pt * 3 + 1], zi = patch[pt * 3 + 2];
+    const int kuse = min(ks[s], m);
+    const int32_t* ir = idx + pt * kmax;
+    float mx = -__builtin_huge_valf();
+    for (int j = 0; j < kuse; ++j) {
+        const float* pj = patch + (patch_i * m + ir[j]) * 3;
+        const float xj = pj[0], yj = pj[1], zj = pj[2];
+        float a = __fmul_rn(ww[0], __fsub_rn(xj, xi));
+        a = __fmaf_rn(ww[1], __fsub_rn(yj, yi), a);
+        a = __fmaf_rn(ww[2], __fsub_rn(zj, zi), a);
+        a = __fmaf_rn(ww[3], xj, a);
+        a = __fmaf_rn(ww[4], yj, a);
+        a = __fmaf_rn(ww[5], zj, a);
+        mx = fmaxf(mx, a);
+    }
+    out[t] = lrelu02(__fadd_rn(mx, bias[col]));
+}
+
+int launch_fd_edge0(const float* patch, const int32_t* idx, int kmax, int64_t pts, int m, int nscale,
+                    const int32_t* ks_dev, const float* w, const float* bias, float* out, hipStream_t st) {
+    if (pts == 0) return SAPCU_OK;
+    const int64_t total = pts * 64 * nscale;
+    hipLaunchKernelGGL(fd_edge0_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, patch, idx, kmax, pts,
+                       m, nscale, ks_dev, w, bias, out);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+// =============================================================================================
+// fd neuron stage with external input over T outer steps (fd:408-474).
+//   pre-activation at t = 0 comes from memory; for t >= 1 the refractory gate `x * (r <= 0)` is
+//   closed (eval-mode spikes are > 0), so the EdgeConv input is multiplied by zero and the state
+//   simply evolves; a violated gate increments *gate_violations (checked by the tests).
+//   MODE 0: pre = in[row, c]                                  (block 0, after scale_fusion GEMM)
+//   MODE 1: pre = lrelu(max_j AB[nbr_j, c] - AB[row, C + c] + shift[c])   (blocks 1..3, factored
+//           EdgeConv: W.cat(xj - xi, xj) = (W1 + W2) xj - W1 xi, BN scale folded into W)
+//   spikes of step t go to spk[(t*pts + row) * ldo + coff + c]
+// =============================================================================================
+template <bool EIF, int MODE>
+__global__ __launch_bounds__(256) void fd_neuron_kernel(const float* __restrict__ in, int ldi,
+                                                        const int32_t* __restrict__ idx, int kk, int m,
+                                                        const float* __restrict__ shift, int64_t pts, int C,
+                                                        const float* __restrict__ prm, int T, float* __restrict__ spk,
+                                                        int ldo, int coff, float* __restrict__ pre_out,
+                                                        int* __restrict__ gate_violations) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pts * C) return;
+    const int c = (int)(t % C);
+    const int64_t row = t / C;
+    float pre;
+    if (MODE == 0) {
+        pre = in[row * ldi + c];
+    } else {
+        const int64_t patch_i = row / m;
+        const int32_t* ir = idx + row * kk;
+        float mx = -__builtin_huge_valf();
+        for (int j = 0; j < kk; ++j) mx = fmaxf(mx, in[(patch_i * m + ir[j]) * ldi + c]);
+        pre = lrelu02(__fadd_rn(__fsub_rn(mx, in[row * ldi + C + c]), shift[c]));
+    }
+    if (pre_out) pre_out[t] = pre;
+    const NeuronP p = EIF ? load_eif(prm, C, c) : load_lif(prm, C, c);
+    NeuronS s = neuron_init(p);
+    for (int step = 0; step < T; ++step) {
+        float x = 0.f;
+        if (step == 0) x = pre;
+        else if (s.r <= 0.f) atomicAdd(gate_violations, 1);
+        const float sp = neuron_step<EIF>(x, s, p);
+        spk[((int64_t)step * pts + row) * ldo + coff + c] = sp;
+    }
+}
+
+int launch_fd_neuron(bool eif, int mode, const float* in, int ldi, const int32_t* idx, int kk, int m,
+                     const float* shift, int64_t pts, int C, const float* prm, int T, float* spk, int ldo, int coff,
+                     float* pre_out, int* gate_violations, hipStream_t st) {
+    if (pts == 0) return SAPCU_OK;
+    const dim3 grid((unsigned)((pts * C + 255) / 256)), blk(256);
+#define SAPCU_FDN(E, M)                                                                                            \
+    hipLaunchKernelGGL((fd_neuron_kernel<E, M>), grid, blk, 0, st, in, ldi, idx, kk, m, shift, pts, C, prm, T, spk, \
+                       ldo, coff, pre_out, gate_violations)
+    if (eif && mode == 0) SAPCU_FDN(true, 0);
+    else if (eif) SAPCU_FDN(true, 1);
+    else if (mode == 0) SAPCU_FDN(false, 0);
+    else SAPCU_FDN(false, 1);
+#undef SAPCU_FDN
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+// =============================================================================================
+// fd: temporal integration softmax(w).pooled_t (fd:326-328,482-483) + one LIF step from the zero
+//     state (fd:485-490).  pooled [T, b, emb]; thread per (patch, feature)
+// =============================================================================================
+__global__ __launch_bounds__(256) void fd_temporal_kernel(const float* __restrict__ pooled, int T, int64_t b, int emb,
+                                                          const float* __restrict__ tw, const float* __restrict__ lif,
+                                                          float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b * emb) return;
+    const int f = (int)(t % emb);
+    float mx = tw[0];
+    for (int i = 1; i < T; ++i) mx = fmaxf(mx, tw[i]);
+    float den = 0.f;
+    for (int i = 0; i < T; ++i) den = __fadd_rn(den, expf(__fsub_rn(tw[i], mx)));
+    float acc = 0.f;
+    for (int i = 0; i < T; ++i) {
+        const float w = __fdiv_rn(expf(__fsub_rn(tw[i], mx)), den);
+        acc = __fmaf_rn(w, pooled[(int64_t)i * b * emb + t], acc);
+    }
+    const NeuronP p = load_lif(lif, emb, f);
+    NeuronS s = neuron_init(p);
+    out[t] = neuron_step<false>(acc, s, p);
+}
+
+int launch_fd_temporal(const float* pooled, int T, int64_t b, int emb, const float* tw, const float* lif, float* out,
+                       hipStream_t st) {
+    if (b == 0) return SAPCU_OK;
+    hipLaunchKernelGGL(fd_temporal_kernel, dim3((unsigned)((b * emb + 255) / 256)), dim3(256), 0, st, pooled, T, b,
+                       emb, tw, lif, out);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+// =============================================================================================
+// fd decoder tail (fd:777-798, 721-725): single-token "attention" over HEADS, to_out, residual,
+// LayerNorm(64), fc_hidden(64->32)+BN+GELU, fc_distance(32->1), Softplus(beta 5, threshold 20).
+// dim = 64 = one wavefront per row, lane = channel.  Transposed weights ([in][out]) are packed so
+// a lane reads consecutive addresses.
+// =============================================================================================
+__global__ __launch_bounds__(256) void fd_tail_kernel(const float* __restrict__ x /*[b,64]*/,
+                                                      const float* __restrict__ qkv /*[b,192]*/, int64_t b, int heads,
+                                                      const float* __restrict__ wo_t /*[64][64] in-major*/,
+                                                      const float* __restrict__ bo, const float* __restrict__ lnw,
+                                                      const float* __restrict__ lnb,
+                                                      const float* __restrict__ wh_t /*[64][32]*/,
+                                                      const float* __restrict__ bh, const float* __restrict__ wd /*[32]*/,
+                                                      const float* __restrict__ bd, float* __restrict__ attn_out,
+                                                      float* __restrict__ dist) {
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= b) return;   // whole wave exits together; no block-wide barrier below
+    const int hd = 64 / heads;
+    const float q = qkv[row * 192 + lane], k = qkv[row * 192 + 64 + lane], v = qkv[row * 192 + 128 + lane];
+    // per-head dot product: reduce q*k over the hd lanes of a head
+    float dot = q * k;
+    for (int o = 1; o < hd; o <<= 1) dot += __shfl_xor(dot, o);
+    const float logit = dot * (1.0f / sqrtf((float)hd));
+    // softmax over heads (each head's logit is replicated on its hd lanes)
+    float mx = logit;
+    for (int o = hd; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float e = expf(logit - mx);
+    float den = e;
+    for (int o = hd; o < 64; o <<= 1) den += __shfl_xor(den, o);
+    const float o_c = (e / den) * v;
+    sh[wave][lane] = o_c;
+    __builtin_amdgcn_wave_barrier();
+    float acc = bo[lane];
+    for (int i = 0; i < 64; ++i) acc = fmaf(sh[wave][i], wo_t[i * 64 + lane], acc);
+    const float y = acc + x[row * 64 + lane];
+    const float mean = wave_sum(y) / 64.0f;
+    const float dc = y - mean;
+    const float var = wave_sum(dc * dc) / 64.0f;
+    const float z = dc * (1.0f / sqrtf(var + 1e-5f)) * lnw[lane] + lnb[lane];
+    if (attn_out) attn_out[row * 64 + lane] = z;
+    __builtin_amdgcn_wave_barrier();
+    sh[wave][lane] = z;
+    __builtin_amdgcn_wave_barrier();
+    float hsum = 0.f;
+    if (lane < 32) {
+        hsum = bh[lane];
+        for (int i = 0; i < 64; ++i) hsum = fmaf(sh[wave][i], wh_t[i * 32 + lane], hsum);
+        hsum = gelu_erf(hsum) * wd[lane];
+    }
+    const float tot = wave_sum(hsum) + bd[0];
+    if (lane == 0) {
+        const float bx = 5.0f * tot;
+        dist[row] = bx > 20.0f ? tot : log1pf(expf(bx)) / 5.0f;
+    }
+}
+
+int launch_fd_tail(const float* x, const float* qkv, int64_t b, int heads, const float* wo_t, const float* bo,
+                   const float* lnw, const float* lnb, const float* wh_t, const float* bh, const float* wd,
+                   const float* bd, float* attn_out, float* dist, hipStream_t st) {
+    if (b == 0) return SAPCU_OK;
+    SAPCU_CHECK_ARG(heads >= 1 && heads <= 64 && (heads & (heads - 1)) == 0, "fd tail: heads must be a power of two <= 64");
+    hipLaunchKernelGGL(fd_tail_kernel, dim3((unsigned)((b + 3) / 4)), dim3(256), 0, st, x, qkv, b, heads, wo_t, bo, lnw,
+                       lnb, wh_t, bh, wd, bd, attn_out, dist);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+}  // namespace sapcu

@@ -1,0 +1,55 @@
+"""Multi-GPU: shard the query points, one process per GPU, one all-gather of the refined cloud.
+
+The path shards embarrassingly: every seed is independent given the replicated
+input cloud (<= 120 KB) and weights (33 MB).  Rank r refines the contiguous range
+``seeds[r*ceil(n/G) : (r+1)*ceil(n/G)]``; the only exchange is ONE all-gather of the refined
+points per cloud (``[ceil(n/G), 3]`` f64 per rank, last rank padded, trimmed after).  On the
+fully connected xGMI mesh that is ~1 MB per rank — latency bound; it is issued once, not per batch.
+``torch.distributed`` backend "nccl" is RCCL on ROCm; "gloo" runs the same code on CPU tensors
+(tests).
+
+fn's shape-keyed neighbour cache (fn/snn_coder.py:47-59) makes reference-mode results depend on
+which batch a process sees first, so a sharded run cannot reproduce a single-process reference run
+bit for bit; sharded runs therefore use ``knn_cache_mode='fresh'`` (stated in DESIGN.md).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, rank, world):
+    """Contiguous [start, end) of rank's share of n items; equal ceil(n/world) slabs, last ones short."""
+    per = -(-n // world) if world > 0 else n
+    s = min(n, rank * per)
+    return s, min(n, s + per)
+
+
+def gather_refined(local, n_total, group=None):
+    """All-gather row slabs of a [n_local, C] tensor sharded by ``shard_range`` -> [n_total, C] on every rank."""
+    world = dist.get_world_size(group)
+    per = -(-n_total // world)
+    padded = local.new_zeros((per,) + tuple(local.shape[1:]))
+    padded[: local.shape[0]] = local
+    out = local.new_empty((world * per,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    return out[:n_total]
+
+
+def upsample_sharded(generator, cloud_dev, seeds_dev, group=None):
+    """Refine this rank's shard with ``generator.refine`` and all-gather the refined cloud.
+    Returns (refined [n,3] f64 on every rank, (start, end) of the local shard)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n = seeds_dev.shape[0]
+    s, e = shard_range(n, rank, world)
+    model = generator.model1
+    old = getattr(model, "knn_cache_mode", None)
+    if old is not None:
+        model.knn_cache_mode = "fresh"
+    try:
+        if e > s:
+            local, _, _ = generator.refine(cloud_dev, seeds_dev[s:e])
+        else:
+            local = seeds_dev.new_empty((0, 3))
+    finally:
+        if old is not None:
+            model.knn_cache_mode = old
+    return gather_refined(local, n, group), (s, e)

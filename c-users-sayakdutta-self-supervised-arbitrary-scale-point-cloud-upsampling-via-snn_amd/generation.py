@@ -1,0 +1,173 @@
+"""``Generator3D6`` — the reference's upsampling pipeline with its hot loops on the GPU.
+
+Mirrors /root/reference/generation.py:50-187 (same constructor, same ``upsample(data)`` ->
+``ndarray [M',3] float64``): outer kNN -> centred patches -> fn normals -> Rodrigues rotation ->
+fd distances -> displacement ``p + n*d`` -> kNN-30 outlier filter.  Differences in mechanics,
+not in results:
+
+* both reference loops run as ONE device pass: the outer kNN is computed once and its index
+  table reused for the fd pass (the reference queries the KD-tree twice for identical answers,
+  generation.py:127,153);
+* the cloud, seeds and every intermediate stay in HBM; only the refined cloud returns to the host;
+* batches follow ``np.array_split(seeds, max(1, n // batch_size))`` exactly, because fn's
+  shape-keyed neighbour cache makes results depend on the batch shapes (``knn_cache_mode``).
+
+Seed generation (generation.py:112-118: the ``./dense`` subprocess and its text files) is outside
+the hot path; ``upsample`` shells out exactly like the reference, while
+``upsample_seeds`` takes the seed array directly.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def split_batches(n, batch_size):
+    """(start, end) of each chunk of np.array_split(range(n), max(1, n // batch_size))."""
+    pp = max(1, n // batch_size)
+    base, extra = divmod(n, pp)
+    out, s = [], 0
+    for i in range(pp):
+        e = s + base + (1 if i < extra else 0)
+        out.append((s, e))
+        s = e
+    return out
+
+
+def knn_gather(cloud_dev, queries_dev, k, want_dist=False, want_patch=True):
+    """Outer kNN on the device: (idx int64 [b,k], dist f64 [b,k] | None, patch f32 [b,k,3] | None)."""
+    lib = _lib.load()
+    b, n = queries_dev.shape[0], cloud_dev.shape[0]
+    dev = cloud_dev.device
+    idx = torch.empty((b, k), dtype=torch.int64, device=dev)
+    dist = torch.empty((b, k), dtype=torch.float64, device=dev) if want_dist else None
+    patch = torch.empty((b, k, 3), dtype=torch.float32, device=dev) if want_patch else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.sapcu_knn_gather_f64(_lib.ptr(cloud_dev), n, _lib.ptr(queries_dev), b, k, _lib.ptr(idx),
+                                            _lib.ptr(dist), _lib.ptr(patch), _lib.current_stream()))
+    return idx, dist, patch
+
+
+def gather_rotate(cloud_dev, queries_dev, idx, normals):
+    lib = _lib.load()
+    b, k = idx.shape
+    patch = torch.empty((b, k, 3), dtype=torch.float32, device=cloud_dev.device)
+    with torch.cuda.device(cloud_dev.device):
+        _lib.check(lib.sapcu_gather_rotate_f64(_lib.ptr(cloud_dev), cloud_dev.shape[0], _lib.ptr(queries_dev), b,
+                                               _lib.ptr(idx), k, _lib.ptr(normals), _lib.ptr(patch),
+                                               _lib.current_stream()))
+    return patch
+
+
+def displace(queries_dev, normals, dist):
+    lib = _lib.load()
+    out = torch.empty_like(queries_dev)
+    with torch.cuda.device(queries_dev.device):
+        _lib.check(lib.sapcu_displace_f64(_lib.ptr(queries_dev), _lib.ptr(normals), _lib.ptr(dist),
+                                          queries_dev.shape[0], _lib.ptr(out), _lib.current_stream()))
+    return out
+
+
+def l2_normalize3(x):
+    lib = _lib.load()
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.sapcu_l2_normalize3(_lib.ptr(x), _lib.ptr(out), x.shape[0], _lib.current_stream()))
+    return out
+
+
+class Generator3D6(object):
+    def __init__(self, model1, model2, device, k_neighbors=100, dense_spacing=0.004, outlier_threshold=1.5,
+                 batch_size=400):
+        self.model1 = model1        # fn: normals
+        self.model2 = model2        # fd: distances
+        self.device = torch.device(device)
+        self.k_neighbors = k_neighbors
+        self.dense_spacing = dense_spacing
+        self.outlier_threshold = outlier_threshold
+        self.batch_size = batch_size
+        self.model1.eval()
+        self.model2.eval()
+        if self.device.type != "cuda":
+            raise RuntimeError("Generator3D6 needs a ROCm device (got %s): no CPU path exists" % self.device)
+        if not (1 <= k_neighbors <= 128):
+            raise ValueError("k_neighbors must be in 1..128")
+
+    # -- public, as the reference -------------------------------------------------------------
+    def upsample(self, data):
+        return self.generateiopoint(data)
+
+    def generateiopoint(self, data):
+        data = np.squeeze(data, 0) if np.ndim(data) == 3 else np.asarray(data)
+        seeds = self._dense_seeds(data)
+        return self.upsample_seeds(data, seeds)
+
+    # -- seed generation: the reference's subprocess, verbatim behaviour (generation.py:112-118)
+    def _dense_seeds(self, data):
+        if not os.path.exists("./dense"):
+            raise FileNotFoundError("./dense not found in the working directory: the reference shells out to it "
+                                    "(generation.py:114-116); build it or call upsample_seeds(data, seeds)")
+        os.system("./dense %s %d" % (self.dense_spacing, data.shape[0]))
+        return np.loadtxt("target.xyz")[:, 0:3]
+
+    # -- the hot path --------------------------------------------------------------------------
+    def refine(self, cloud_dev, seeds_dev):
+        """Device pipeline on resident tensors: cloud f64 [N,3], seeds f64 [n,3] ->
+        (refined f64 [n,3], normals f32 [n,3], dist f32 [n]).  Batch boundaries as the reference."""
+        n = seeds_dev.shape[0]
+        k = self.k_neighbors
+        out = torch.empty((n, 3), dtype=torch.float64, device=cloud_dev.device)
+        normals = torch.empty((n, 3), dtype=torch.float32, device=cloud_dev.device)
+        dists = torch.empty((n,), dtype=torch.float32, device=cloud_dev.device)
+        for (s, e) in split_batches(n, self.batch_size):
+            q = seeds_dev[s:e]
+            idx, _, patch = knn_gather(cloud_dev, q, k)
+            if hasattr(self.model1, "reset_states"):
+                self.model1.reset_states()
+            nrm = l2_normalize3(self.model1(patch))              # generation.py:138-139
+            rot = gather_rotate(cloud_dev, q, idx, nrm)          # generation.py:154-160
+            if hasattr(self.model2, "reset_states"):
+                self.model2.reset_states()
+            d = self.model2(rot)                                 # generation.py:169
+            out[s:e] = displace(q, nrm, d)                       # generation.py:171-172
+            normals[s:e] = nrm
+            dists[s:e] = d
+        return out, normals, dists
+
+    def outlier_filter(self, pts_dev):
+        """Keep points whose mean distance to their 30 nearest (self included) is below
+        outlier_threshold x the global mean (generation.py:176-183)."""
+        kk = min(30, pts_dev.shape[0])
+        _, dist, _ = knn_gather(pts_dev, pts_dev, kk, want_dist=True, want_patch=False)
+        # the two means are host numpy on purpose: they decide membership by a float64 comparison and
+        # must round exactly like np.mean does in the reference (this row is post-processing, §8f-3)
+        dist = dist.cpu().numpy()
+        keep = np.mean(dist, axis=1) < np.mean(dist) * self.outlier_threshold
+        return keep
+
+    def upsample_seeds(self, data, seeds, return_unfiltered=False):
+        cloud_dev = torch.as_tensor(np.ascontiguousarray(data, dtype=np.float64), device=self.device)
+        seeds_dev = torch.as_tensor(np.ascontiguousarray(seeds, dtype=np.float64), device=self.device)
+        with torch.no_grad():
+            refined, _, _ = self.refine(cloud_dev, seeds_dev)
+            keep = self.outlier_filter(refined)
+        refined = refined.cpu().numpy()
+        if return_unfiltered:
+            return refined[keep], refined
+        return refined[keep]
+
+
+class SNNPointCloudGenerator(Generator3D6):
+    """Multi-pass wrapper (generation.py:191-220)."""
+
+    def __init__(self, model1, model2, device, **kwargs):
+        self.upsampling_ratio = kwargs.pop("upsampling_ratio", 4)
+        super().__init__(model1, model2, device, **kwargs)
+
+    def multi_scale_upsample(self, data, num_passes=1):
+        result = data
+        for _ in range(num_passes):
+            result = self.upsample(np.expand_dims(result, 0) if result.ndim == 2 else result)
+        return result

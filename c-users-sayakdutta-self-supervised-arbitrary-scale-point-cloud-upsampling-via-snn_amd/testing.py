@@ -1,0 +1,117 @@
+"""Deterministic synthetic weights and inputs (no trained checkpoint ships with the reference).
+
+Shared by the golden-fixture generator, the parity tests and ``bench.py`` so that every box
+rebuilds bit-identical weights from ``(tensor name, shape, seed)`` alone — numpy's PCG64
+stream is platform independent, torch's initialisers are not used.
+
+Why "conditioned": under torch's default initialisation both reference networks are
+input-insensitive (every pre-activation sits far below threshold 1.0), so
+golden vectors from default weights would make any parity test pass trivially.  The recipe
+below moves BatchNorm statistics so that pre-activations straddle the spike threshold.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+_NEURON_INIT = {
+    "membrane_decay": 0.9, "threshold_adapt": 0.01, "refractory_decay": 0.5,
+    "threshold_base": 1.0, "delta_T": 1.0, "theta_rh": 0.8,
+}
+
+
+def _rng(seed, name):
+    return np.random.default_rng([int(seed), zlib.crc32(name.encode())])
+
+
+BN_GAIN = 0.5                      # scale on BatchNorm gamma (keeps per-layer noise gain < 1)
+FN_LOGIT_BIAS = (2.0, -1.0, 0.6)   # decoder.fc_out.bias: keeps LayerNorm(3) well conditioned
+
+
+def conditioned_state_dict(template, seed=0, w_gain=1.0, bn_stats=None, bn_gain=BN_GAIN):
+    """template: mapping name -> shape (or tensor).  Returns name -> torch tensor (cpu).
+
+    ``bn_stats``: optional mapping ``<bn>.running_mean`` / ``<bn>.running_var`` -> array.  The
+    golden fixtures carry statistics calibrated on 64 sphere patches (tests/golden/bn_calib_*.npz)
+    so every BatchNorm output is ~N(beta, (gamma*bn_gain)^2): pre-activations straddle the spike
+    threshold (the nets are input-sensitive) while fp32 rounding noise stays ~1e-5 at the outputs."""
+    shapes = {k: tuple(v.shape) if hasattr(v, "shape") else tuple(v) for k, v in template.items()}
+    out = {}
+    for name, shape in shapes.items():
+        r = _rng(seed, name)
+        leaf = name.rsplit(".", 1)[-1]
+        parent = name.rsplit(".", 1)[0] if "." in name else ""
+        is_bn = (parent + ".running_mean") in shapes
+        if leaf == "num_batches_tracked":
+            out[name] = torch.zeros(shape, dtype=torch.int64)
+            continue
+        if leaf in _NEURON_INIT:
+            a = _NEURON_INIT[leaf] * r.uniform(0.9, 1.1, shape)
+        elif bn_stats is not None and name in bn_stats:
+            a = np.asarray(bn_stats[name])
+        elif leaf == "running_mean":
+            a = r.normal(0.0, 0.05, shape)
+        elif leaf == "running_var":
+            a = r.uniform(0.005, 0.025, shape)
+        elif is_bn and leaf == "weight":
+            a = r.uniform(0.5, 1.5, shape) * bn_gain
+        elif name == "decoder.fc_out.bias" and shape == (3,):
+            a = np.asarray(FN_LOGIT_BIAS)
+        elif is_bn and leaf == "bias":
+            a = r.normal(0.6, 0.5, shape)
+        elif parent.endswith("norm_out") or parent.endswith("attention.norm"):
+            a = r.uniform(0.5, 1.5, shape) if leaf == "weight" else r.normal(0.0, 0.1, shape)
+        elif parent.endswith("temporal_integration"):
+            a = r.normal(1.0, 0.3, shape)
+        elif len(shape) >= 2:                                  # conv / linear weight
+            fan_in = int(np.prod(shape[1:]))
+            b = w_gain / np.sqrt(fan_in)
+            a = r.uniform(-b, b, shape)
+        else:                                                   # conv / linear bias
+            wshape = shapes.get(parent + ".weight")
+            fan_in = int(np.prod(wshape[1:])) if wshape else shape[0]
+            b = 1.0 / np.sqrt(fan_in)
+            a = r.uniform(-b, b, shape)
+        out[name] = torch.from_numpy(np.asarray(a, dtype=np.float32).reshape(shape))
+    return out
+
+
+def sphere_cloud(n=5000, seed=0):
+    """unit-normal directions * 0.5, rounded to 6 decimals, float64."""
+    rng = np.random.default_rng(seed)
+    v = rng.normal(size=(n, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    return np.round(v * 0.5, 6).astype(np.float64)
+
+
+def grid_queries(count=4096, seed=0, spacing=0.004, band=(0.011, 0.015), radius=0.5):
+    """Cell centres of the seed grid whose distance to the sphere lies in ``band`` (§8d)."""
+    rng = np.random.default_rng(seed)
+    cells = rng.integers(0, int(round(1.0 / spacing)), (200000, 3))
+    q = cells * spacing + spacing / 2 - 0.5
+    off = np.abs(np.linalg.norm(q, axis=1) - radius)
+    q = q[(off > band[0]) & (off < band[1])]
+    if q.shape[0] < count:
+        raise ValueError("not enough grid cells in the band: %d < %d" % (q.shape[0], count))
+    return np.ascontiguousarray(q[:count], dtype=np.float64)
+
+
+def analytic_cloud(kind, n=2048, seed=0):
+    """Small suite of analytic shapes in [-0.5,0.5]^3 (stand-ins for the absent ShapeNet data)."""
+    rng = np.random.default_rng(seed)
+    if kind == "sphere":
+        return sphere_cloud(n, seed)
+    if kind == "torus":
+        u, v = rng.uniform(0, 2 * np.pi, (2, n))
+        R, r = 0.33, 0.14
+        p = np.stack([(R + r * np.cos(v)) * np.cos(u), (R + r * np.cos(v)) * np.sin(u), r * np.sin(v)], 1)
+    elif kind == "cube":
+        p = rng.uniform(-0.45, 0.45, (n, 3))
+        ax = rng.integers(0, 3, n)
+        p[np.arange(n), ax] = np.where(rng.random(n) < 0.5, -0.45, 0.45)
+    elif kind == "cylinder":
+        u = rng.uniform(0, 2 * np.pi, n)
+        p = np.stack([0.3 * np.cos(u), 0.3 * np.sin(u), rng.uniform(-0.45, 0.45, n)], 1)
+    else:
+        raise ValueError(kind)
+    return np.round(p, 6).astype(np.float64)

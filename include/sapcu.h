@@ -1,0 +1,159 @@
+/*
+ * sapcu.h — C ABI of libsapcu_hip.so: the MI355X (gfx950) implementation of the reference's
+ * per-query-point inference hot path.
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - the caller owns all inputs, outputs and workspaces; the library owns only what sits
+ *     behind a sapcu_model_t handle; no *_forward call allocates;
+ *   - every entry point returns 0 on success and a negative sapcu_status otherwise; it never
+ *     throws and never exits; sapcu_last_error() returns the text of the calling thread's last
+ *     failure;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is
+ *     enqueued on it and nothing synchronises unless stated;
+ *   - a handle is immutable after create: concurrent forwards on different streams with
+ *     different workspaces are legal.
+ *
+ * Each entry point cites the reference lines (relative to /root/reference) it replaces.
+ */
+#ifndef SAPCU_H
+#define SAPCU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAPCU_ABI_VERSION 1
+
+typedef enum {
+    SAPCU_OK = 0,
+    SAPCU_ERR_ARG = -1,        /* bad pointer / size / hyper-parameter */
+    SAPCU_ERR_WORKSPACE = -2,  /* workspace too small (see *_workspace_bytes) */
+    SAPCU_ERR_HIP = -3,        /* a HIP runtime call or launch failed */
+    SAPCU_ERR_UNSUPPORTED = -4 /* legal in the reference, not built here (e.g. use_snn_decoder) */
+} sapcu_status;
+
+typedef struct sapcu_model* sapcu_model_t;
+
+int sapcu_abi_version(void);
+const char* sapcu_last_error(void);
+
+/* ---------------------------------------------------------------- geometry (float64) ---- */
+
+/* Outer kNN: replaces KDTree(data).query(q, k) — generation.py:110,127,153.
+ * cloud [n,3] f64, queries [b,3] f64 -> idx_out [b,k] int64 ascending (distance, index);
+ * distances are sum_c (q_c-p_c)^2 accumulated x,y,z in f64 without FMA contraction.
+ * dist_out [b,k] f64 (euclidean, i.e. sqrt) and patch_out [b,k,3] f32 are optional (NULL to
+ * skip); patch_out = f32(cloud[idx] - q), the subtraction done in f64 (generation.py:128-129,137).
+ * Requires 1 <= k <= 128 and k <= n. */
+int sapcu_knn_gather_f64(const double* cloud, int64_t n, const double* queries, int64_t b, int k,
+                         int64_t* idx_out, double* dist_out, float* patch_out, void* stream);
+
+/* Gather + centre (+ optional per-patch Rodrigues rotation of the normal onto +x) —
+ * generation.py:154-160,168 and rotation_matrix_from_vectors :30-47.
+ * normals [b,3] f32 or NULL (no rotation). patch_out [b,k,3] f32; maths in f64. */
+int sapcu_gather_rotate_f64(const double* cloud, int64_t n, const double* queries, int64_t b,
+                            const int64_t* idx, int k, const float* normals, float* patch_out,
+                            void* stream);
+
+/* Displacement out = p + n*d (f32 product promoted to f64) — generation.py:171-172. */
+int sapcu_displace_f64(const double* queries, const float* normals, const float* dist, int64_t b,
+                       double* out, void* stream);
+
+/* ---------------------------------------------------------------- neuron unit ----------- */
+
+/* Self-feeding T-step neuron loop `for t: x,*st = snn(x,*st)` — fn/snn_coder.py:87-153,
+ * 319-320 (LIF) and fd/snn_coder.py:198-275 (EIF when delta_T != NULL).
+ * x [rows, channels] f32 (channel = fastest axis); params are per-channel RAW parameters
+ * (clamped inside, as the reference does).  Outputs (each optional): spikes of the last step
+ * and the final membrane / threshold / refractory state. */
+int sapcu_neuron_selfloop(const float* x, int64_t rows, int channels, int steps,
+                          const float* membrane_decay, const float* threshold_adapt,
+                          const float* refractory_decay, const float* threshold_base,
+                          const float* delta_T, const float* theta_rh,
+                          float* spikes_out, float* membrane_out, float* threshold_out,
+                          float* refractory_out, void* stream);
+
+/* In-patch kNN `topk(-|xi|^2 + 2 xi.xj - |xj|^2)` — fn/snn_coder.py:31-39, fd/snn_coder.py:25-32.
+ * feat [b, m, ld] f32 (point-major, first c columns used), 1 <= m <= 128, k <= m.
+ * idx_out [b,m,k] int32, descending score, equal scores by ascending index. */
+int sapcu_patch_knn(const float* feat, int64_t b, int m, int c, int ld, int k, int32_t* idx_out,
+                    void* stream);
+
+/* ---------------------------------------------------------------- models ---------------- */
+
+#define SAPCU_KIND_FN 0 /* ImprovedSNNNormalEstimation   — fn/snn_coder.py:627-699 */
+#define SAPCU_KIND_FD 1 /* EnhancedSNNDistanceEstimation — fd/snn_coder.py:805-871 */
+
+/* hparams_host (int32):
+ *   fn: [k0, k1, k2, emb_dims, time_steps_enc, num_heads]
+ *   fd: [k, emb_dims, time_steps_enc, num_heads, n_scales, ks0, ks1, ...]
+ * blob: packed f32 parameters on the device (BatchNorm folded, see sapcu_amd/packing.py);
+ * dir_host: int64 offsets (in floats) into blob, one per slot of the kind's slot table
+ * (SAPCU_FN_SLOTS / SAPCU_FD_SLOTS entries, order fixed by packing.py and model.hip).
+ * The library copies the blob; the caller may free it after the call returns. */
+int sapcu_model_create(int kind, const int32_t* hparams_host, int n_hparams, const float* blob,
+                       int64_t blob_floats, const int64_t* dir_host, int n_dir, sapcu_model_t* out);
+int sapcu_model_destroy(sapcu_model_t m);
+
+/* Workspace bytes needed by a forward of b patches of m_pts points. */
+int64_t sapcu_workspace_bytes(sapcu_model_t m, int64_t b, int m_pts);
+
+/* Debug taps: `taps` is NULL or a host array of SAPCU_*_TAP_COUNT device pointers (each may be
+ * NULL); selected intermediates are copied out for stage-level parity tests. */
+enum {
+    SAPCU_FN_TAP_STEM = 0,   /* [b,m,64]  after snn_init            fn:453-457 */
+    SAPCU_FN_TAP_BLOCK1 = 1, /* [b,m,64]  trans1 output             fn:460     */
+    SAPCU_FN_TAP_BLOCK2 = 2, /* [b,m,64]                                       */
+    SAPCU_FN_TAP_BLOCK3 = 3, /* [b,m,64]                                       */
+    SAPCU_FN_TAP_POOLED = 4, /* [b,emb]   after max-pool            fn:472     */
+    SAPCU_FN_TAP_ENC = 5,    /* [b,2048]  encoder output            fn:475     */
+    SAPCU_FN_TAP_LOGITS = 6, /* [b,3]     before LayerNorm(3)       fn:545     */
+    SAPCU_FN_TAP_COUNT = 7
+};
+enum {
+    SAPCU_FD_TAP_FUSED0 = 0,  /* [b,m,64]      scale_fusion output at t=0      fd:421  */
+    SAPCU_FD_TAP_SPIKES = 1,  /* [T,b,m,960]   the four spike tensors, all t   fd:476  */
+    SAPCU_FD_TAP_KNN = 2,     /* [3][b,m,kk] int32 feature-space neighbours, blocks 1-3 (t=0) */
+    SAPCU_FD_TAP_POOLED = 3,  /* [T,b,emb]     pooled_t                        fd:479  */
+    SAPCU_FD_TAP_ENC = 4,     /* [b,emb]       encoder output                  fd:492  */
+    SAPCU_FD_TAP_COUNT = 5
+};
+
+/* fn forward — ImprovedSNNNormalEstimation.forward on [b,m,3] (fn/snn_coder.py:670-699)
+ * followed by nothing else (the caller's extra F.normalize, generation.py:139, is idempotent
+ * up to rounding and is applied by the Python layer).
+ * knn_in:  NULL, or the three in-patch neighbour tables [b,m,k0],[b,m,k1],[b,m,k2] int32
+ *          concatenated — the reference's shape-keyed KNNCache replay (fn:47-59);
+ * knn_out: NULL, or receives the tables this call used (same layout). */
+int sapcu_fn_forward(sapcu_model_t m, const float* patch, int64_t b, int m_pts,
+                     const int32_t* knn_in, int32_t* knn_out, float* normals_out, void* workspace,
+                     int64_t ws_bytes, void* const* taps_host, void* stream);
+
+/* fd forward — EnhancedSNNDistanceEstimation.forward on [b,m,3] (fd/snn_coder.py:853-871).
+ * knn_force: NULL, or [3][b,m,min(k,m)] int32 feature-space neighbour tables to use instead of
+ * the ones computed in-kernel (test protocol for near-tie flips; DESIGN.md "kNN flips"). */
+int sapcu_fd_forward(sapcu_model_t m, const float* patch, int64_t b, int m_pts,
+                     const int32_t* knn_force, float* dist_out, void* workspace, int64_t ws_bytes,
+                     void* const* taps_host, void* stream);
+
+/* Number of (element, step>=1) events in fd forwards of this handle where the refractory gate
+ * `x * (refractory <= 0)` (fd/snn_coder.py:133,249) was found OPEN.  The fd kernels rely on it
+ * being closed for t >= 1 (eval-mode spikes are strictly positive) to skip the
+ * dead EdgeConv stages; a non-zero count means an output may deviate.  Synchronises the device. */
+int sapcu_model_gate_violations(sapcu_model_t m, int* count_host);
+
+/* out = in / max(||in||_2, 1e-12) row-wise for [b,3] — the extra F.normalize of generation.py:139. */
+int sapcu_l2_normalize3(const float* in, float* out, int64_t b, void* stream);
+
+/* Plain fp32 GEMM with the library's MFMA kernel, exposed for tests and roofline runs:
+ * C[r,n] = A[r,k] * W[n,k]^T + bias[n].  k % 32 == 0. */
+int sapcu_gemm_f32(const float* a, int64_t r, int k, int lda, const float* w, int n,
+                   const float* bias, float* c, int ldc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAPCU_H */

@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in this directory by RUNNING THE REAL REFERENCE (CPU).
+
+Run in the build container only (needs /root/reference, which never travels):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_fixtures.py [--skip-e2e]
+
+What is committed is data: inputs, expected outputs and per-stage intermediates produced by
+``fn.snn_coder`` / ``fd.snn_coder`` / ``generation`` imported from /root/reference, plus
+BatchNorm statistics calibrated through the reference (see sapcu_amd/testing.py for why).
+No reference source text is stored.  Weights are NOT stored: every box rebuilds them from
+``testing.conditioned_state_dict(shapes, seed=0, bn_stats=<bn_calib_*.npz>)``.
+"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+sys.modules.setdefault("trimesh", types.ModuleType("trimesh"))   # imported, never used (generation.py:21)
+
+import sapcu_amd  # noqa: E402
+from sapcu_amd import testing as T  # noqa: E402
+from oracle import geom_path as G  # noqa: E402  (only for building input patches)
+
+from fn import snn_coder as ref_fn  # noqa: E402
+from fd import snn_coder as ref_fd  # noqa: E402
+import generation as ref_gen  # noqa: E402
+
+FN_KW = dict(k_values=[24, 18, 12], emb_dims=640, time_steps_enc=4, time_steps_dec=12, num_heads=8,
+             use_snn_decoder=False, decoder_dropout=0.1)
+FD_KW = dict(k=32, emb_dims=768, time_steps_enc=4, time_steps_dec=8, num_heads=8, dropout=0.1,
+             use_snn_decoder=False, k_scales=[8, 16, 32, 48])
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print("wrote %-24s %8.1f KiB" % (name, os.path.getsize(path) / 1024))
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def calibrate_bn(model, x):
+    """One eval forward with pre-hooks that set each BatchNorm's running stats to the statistics of
+    the activations it sees on first use (execution order => upstream layers already calibrated)."""
+    seen, hooks = set(), []
+
+    def mk(name):
+        def hook(mod, inp):
+            if name in seen:
+                return
+            seen.add(name)
+            a = inp[0]
+            dims = [d for d in range(a.dim()) if d != 1]
+            mod.running_mean.copy_(a.mean(dims))
+            mod.running_var.copy_(a.var(dims, unbiased=False).clamp_min(1e-8))
+        return hook
+
+    for name, mod in model.named_modules():
+        if isinstance(mod, (nn.BatchNorm1d, nn.BatchNorm2d)):
+            hooks.append(mod.register_forward_pre_hook(mk(name)))
+    with torch.no_grad():
+        model(x)
+    for h in hooks:
+        h.remove()
+    return {k: npy(v) for k, v in model.state_dict().items() if k.endswith("running_mean") or k.endswith("running_var")}
+
+
+def build_models(bn_fn=None, bn_fd=None, fn_kw=None, fd_kw=None):
+    fn = ref_fn.ImprovedSNNNormalEstimation(**(fn_kw or FN_KW)).eval()
+    fd = ref_fd.EnhancedSNNDistanceEstimation(**(fd_kw or FD_KW)).eval()
+    fn.load_state_dict(T.conditioned_state_dict(fn.state_dict(), 0, bn_stats=bn_fn), strict=True)
+    fd.load_state_dict(T.conditioned_state_dict(fd.state_dict(), 0, bn_stats=bn_fd), strict=True)
+    return fn, fd
+
+
+def sphere_patches(nq, k, n=5000, qseed=0):
+    cloud = T.sphere_cloud(n, 0)
+    q = T.grid_queries(nq, qseed)
+    idx = G.knn_bruteforce(cloud, q, k)
+    return torch.from_numpy(G.gather_centre(cloud, q, idx)).float()
+
+
+def hook_outputs(model, names):
+    store, hooks = {}, []
+    mods = dict(model.named_modules())
+    for n in names:
+        def mk(n):
+            def hook(mod, inp, out):
+                store.setdefault(n, []).append(out[0] if isinstance(out, tuple) else out)
+            return hook
+        hooks.append(mods[n].register_forward_hook(mk(n)))
+    return store, hooks
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-e2e", action="store_true")
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+
+    # ---- 0. key/shape parity of the drop-in shells with the reference modules
+    fn, fd = build_models()
+    my_fn = sapcu_amd.ImprovedSNNNormalEstimation(**FN_KW)
+    my_fd = sapcu_amd.EnhancedSNNDistanceEstimation(**FD_KW)
+    for ref_m, my_m in ((fn, my_fn), (fd, my_fd)):
+        a = {k: tuple(v.shape) for k, v in ref_m.state_dict().items()}
+        b = {k: tuple(v.shape) for k, v in my_m.state_dict().items()}
+        assert a == b, "state_dict layout differs from the reference"
+        assert list(a) == list(b), "state_dict key ORDER differs"
+    save("state_dict_layout.npz",
+         fn_keys=np.array(list(fn.state_dict())), fn_shapes=np.array([str(tuple(v.shape)) for v in fn.state_dict().values()]),
+         fd_keys=np.array(list(fd.state_dict())), fd_shapes=np.array([str(tuple(v.shape)) for v in fd.state_dict().values()]))
+
+    # ---- 1. BatchNorm calibration (64 sphere patches, queries 0..63 of grid_queries(…, seed 0))
+    calib = sphere_patches(64 + 16, 48)
+    bn_fn = calibrate_bn(fn, calib[:64])
+    bn_fd = calibrate_bn(fd, calib[:64])
+    save("bn_calib_fn.npz", **bn_fn)
+    save("bn_calib_fd.npz", **bn_fd)
+    fn, fd = build_models(bn_fn, bn_fd)
+    test = calib[64:]           # 16 patches the calibration never saw
+
+    # ---- 2. neuron unit vectors: LIF (fn class) and EIF (fd class), self-feeding loop
+    C = 8
+    rng = np.random.default_rng(7)
+    x = np.concatenate([np.linspace(-12, 12, 193), [-10.0, 10.0, -10.000001, 10.000001, 0.0, 1.0, 0.999999, 1.000001]])
+    x = np.tile(x[:, None], (1, C)).astype(np.float32)
+    x += rng.normal(0, 0.05, x.shape).astype(np.float32)
+    raw = np.stack([rng.uniform(0.05, 1.05, C), rng.uniform(0.0, 0.12, C), rng.uniform(0.05, 1.0, C),
+                    rng.uniform(0.6, 1.4, C), rng.uniform(0.05, 5.5, C), rng.uniform(0.05, 2.2, C)]).astype(np.float32)
+    out = {"x": x, "raw_params": raw}
+    for kind, cls in (("lif", ref_fn.MultiTimeConstantLIFNeuron), ("eif", ref_fd.MultiTimeConstantEIFNeuron)):
+        neu = cls(C).eval()
+        with torch.no_grad():
+            neu.membrane_decay.copy_(torch.from_numpy(raw[0])); neu.threshold_adapt.copy_(torch.from_numpy(raw[1]))
+            neu.refractory_decay.copy_(torch.from_numpy(raw[2])); neu.threshold_base.copy_(torch.from_numpy(raw[3]))
+            if kind == "eif":
+                neu.delta_T.copy_(torch.from_numpy(raw[4])); neu.theta_rh.copy_(torch.from_numpy(raw[5]))
+            for steps in (1, 4, 7):
+                v, st = torch.from_numpy(x), [None, None, None]
+                for _ in range(steps):
+                    v, *st = neu(v, *st)
+                out["%s_T%d_spikes" % (kind, steps)] = npy(v)
+                out["%s_T%d_membrane" % (kind, steps)] = npy(st[0])
+                out["%s_T%d_threshold" % (kind, steps)] = npy(st[1])
+                out["%s_T%d_refractory" % (kind, steps)] = npy(st[2])
+    save("neuron_unit.npz", **out)
+
+    # ---- 3. in-patch kNN: reference knn() on xyz patches and on soft-spike-like features
+    out = {}
+    feats = {3: test[:4].permute(0, 2, 1).contiguous()}
+    for c in (64, 128, 256):
+        feats[c] = torch.from_numpy(np.random.default_rng(c).random((4, c, 48)).astype(np.float32))
+    for c, f in feats.items():
+        out["feat_c%d" % c] = npy(f)
+        with torch.no_grad():
+            for k in (8, 12, 16, 18, 24, 32, 48):
+                out["idx_c%d_k%d" % (c, k)] = npy(ref_fn.knn(f, k)).astype(np.int8)
+                assert torch.equal(ref_fn.knn(f, k), ref_fd.knn(f, k))
+    save("patch_knn.npz", **out)
+
+    # ---- 4. fn stage taps (b = 4)
+    xin = test[:4]
+    names = ["encoder.snn_init", "encoder.trans1", "encoder.trans2", "encoder.trans3", "encoder", "decoder.fc_out"]
+    store, hooks = hook_outputs(fn, names)
+    with torch.no_grad():
+        for b in (fn.encoder.trans1, fn.encoder.trans2, fn.encoder.trans3):
+            b.knn_cache.cache.clear()
+        normals = fn(xin)
+    for h in hooks:
+        h.remove()
+    knn_tabs = [list(b.knn_cache.cache.values())[0] for b in (fn.encoder.trans1, fn.encoder.trans2, fn.encoder.trans3)]
+    save("fn_taps.npz", patch=npy(xin),
+         stem=npy(store["encoder.snn_init"][-1]).transpose(0, 2, 1),      # last of the T self-loop calls -> [b,M,64]
+         block1=npy(store["encoder.trans1"][0]), block2=npy(store["encoder.trans2"][0]), block3=npy(store["encoder.trans3"][0]),
+         enc=npy(store["encoder"][0]), logits=npy(store["decoder.fc_out"][0]), normals=npy(normals),
+         knn0=npy(knn_tabs[0]).astype(np.int8), knn1=npy(knn_tabs[1]).astype(np.int8), knn2=npy(knn_tabs[2]).astype(np.int8))
+
+    # ---- 5. the stale-cache pair: second call of the same shape reuses the first call's neighbours
+    with torch.no_grad():
+        for b in (fn.encoder.trans1, fn.encoder.trans2, fn.encoder.trans3):
+            b.knn_cache.cache.clear()
+        nA = fn(test[4:8]); fn.reset_states()
+        nB = fn(test[8:12])                      # stale: uses A's tables
+        for b in (fn.encoder.trans1, fn.encoder.trans2, fn.encoder.trans3):
+            b.knn_cache.cache.clear()
+        nB_fresh = fn(test[8:12])
+    save("fn_cache_pair.npz", patch_a=npy(test[4:8]), patch_b=npy(test[8:12]), normals_a=npy(nA), normals_b_stale=npy(nB),
+         normals_b_fresh=npy(nB_fresh))
+
+    # ---- 6. fd stage taps (b = 4): monkey-free — hooks on modules + a recording get_graph_feature
+    xin = test[:4]
+    rec = {"knn": []}
+    orig_knn = ref_fd.knn
+
+    def rec_knn(x, k):
+        idx = orig_knn(x, k)
+        rec["knn"].append((x.shape[1], k, idx))
+        return idx
+
+    ref_fd.knn = rec_knn
+    names = ["encoder.scale_fusion", "encoder.snn_blocks.0", "encoder.snn_blocks.1", "encoder.snn_blocks.2",
+             "encoder.snn_blocks.3", "encoder.multi_scale_conv", "encoder"]
+    store, hooks = hook_outputs(fd, names)
+    with torch.no_grad():
+        fd.reset_states()
+        dist = fd(xin)
+    for h in hooks:
+        h.remove()
+    ref_fd.knn = orig_knn
+    Tn = FD_KW["time_steps_enc"]
+    spikes = np.stack([np.concatenate([npy(store["encoder.snn_blocks.%d" % i][t]) for i in range(4)], axis=1).transpose(0, 2, 1)
+                       for t in range(Tn)], 0)                                    # [T,b,M,960]
+    pooled = np.stack([npy(store["encoder.multi_scale_conv"][t].max(dim=2)[0]) for t in range(Tn)], 0)
+    per_t = len(rec["knn"]) // Tn
+    knn_feat = [npy(rec["knn"][i][2]).astype(np.int8) for i in range(per_t) if rec["knn"][i][0] != 3]   # t = 0, blocks 1..3
+    save("fd_taps.npz", patch=npy(xin), fused0=npy(store["encoder.scale_fusion"][0]).transpose(0, 2, 1),
+         spikes_t0=spikes[0], spikes_tlast=spikes[-1], pooled=pooled, enc=npy(store["encoder"][0]), dist=npy(dist),
+         knn1=knn_feat[0], knn2=knn_feat[1], knn3=knn_feat[2])
+
+    # ---- 7. shape/T variants (final outputs only)
+    out = {}
+    for M in (12, 100):
+        p = sphere_patches(3, M, qseed=1)
+        with torch.no_grad():
+            for b in (fn.encoder.trans1, fn.encoder.trans2, fn.encoder.trans3):
+                b.knn_cache.cache.clear()
+            out["patch_M%d" % M] = npy(p)
+            out["normals_M%d" % M] = npy(fn(p))
+            fd.reset_states()
+            out["dist_M%d" % M] = npy(fd(p))
+    p = sphere_patches(3, 48, qseed=2)
+    out["patch_T"] = npy(p)
+    for Tv in (6, 7):
+        fkw = dict(FN_KW, time_steps_enc=Tv)
+        dkw = dict(FD_KW, time_steps_enc=Tv)
+        fnv, fdv = build_models(bn_fn, bn_fd, fkw, dkw)
+        with torch.no_grad():
+            out["normals_T%d" % Tv] = npy(fnv(p))
+            out["dist_T%d" % Tv] = npy(fdv(p))
+    save("variants.npz", **out)
+
+    # ---- 8. outer kNN through sklearn's KDTree exactly as generation.py:110,127 calls it
+    from sklearn.neighbors import KDTree
+    cloud = T.sphere_cloud(5000, 0)
+    q = T.grid_queries(4096, 0)
+    d, idx = KDTree(cloud).query(q, 48)
+    cloud2 = T.sphere_cloud(2048, 0)
+    q2 = T.grid_queries(256, 3)
+    d2, idx2 = KDTree(cloud2).query(q2, 100)
+    save("outer_knn.npz", idx_n5000_k48=idx.astype(np.int16), dist_head=d[:64], idx_n2048_k100=idx2.astype(np.int16),
+         dist2_head=d2[:16])
+
+    # ---- 9. rotation matrices from the reference function
+    rng = np.random.default_rng(11)
+    nr = rng.normal(size=(58, 3)).astype(np.float32)
+    nr /= np.linalg.norm(nr, axis=1, keepdims=True)
+    special = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, 0, -1], [0.99999994, 1e-4, 0], [-0.99999994, 0, 1e-4]], np.float32)
+    nr = np.concatenate([special, nr], 0)
+    mats = np.stack([ref_gen.rotation_matrix_from_vectors(n, [1, 0, 0]) for n in nr], 0)
+    pat = G.gather_centre(cloud, q[:64], idx[:64])
+    rot = np.stack([np.matmul(mats[j], pat[j].T).T for j in range(64)], 0)
+    save("rotation.npz", normals=nr, matrices=mats, rotated_f32=rot.astype(np.float32))
+
+    # ---- 10. end-to-end Generator3D6.upsample on sphere N=2048, dense_spacing 0.03 (~900 seeds)
+    if not args.skip_e2e:
+        dense = os.path.join(ROOT, "oracle", "_ref", "dense")
+        if not os.path.exists(dense):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+        work = tempfile.mkdtemp(prefix="sapcu_e2e_")
+        shutil.copy(dense, os.path.join(work, "dense"))
+        cwd = os.getcwd()
+        os.chdir(work)
+        try:
+            cloud = T.sphere_cloud(2048, 0)
+            np.savetxt("test.xyz", cloud, fmt="%.6f")        # dense reads test.xyz (generate.py never writes it, §8f-1)
+            captured = []
+            RealTree = ref_gen.KDTree
+
+            class RecTree(RealTree):                          # records the array each KDTree is built on
+                def __init__(self, data, *a, **k):
+                    captured.append(np.array(data, copy=True))
+                    super().__init__(data, *a, **k)
+
+            ref_gen.KDTree = RecTree
+            for b in (fn.encoder.trans1, fn.encoder.trans2, fn.encoder.trans3):
+                b.knn_cache.cache.clear()
+            gen = ref_gen.Generator3D6(fn, fd, torch.device("cpu"), k_neighbors=48, dense_spacing=0.03, batch_size=64)
+            result = gen.upsample(cloud[None])
+            ref_gen.KDTree = RealTree
+            seeds = np.loadtxt("target.xyz")[:, 0:3]
+            save("e2e_upsample.npz", seeds=seeds, unfiltered=captured[1], filtered=result)
+        finally:
+            os.chdir(cwd)
+            shutil.rmtree(work, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,152 @@
+"""CPU suite, part 2: host logic, the C-ABI library surface (no compute calls), drop-in boundary,
+and the N > 1 sharding path under gloo (world_size 2)."""
+import ctypes
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import FD_KW, FN_KW, ROOT, golden
+
+import sapcu_amd
+from sapcu_amd import _lib, packing, testing
+from sapcu_amd import generation as gen
+from sapcu_amd import dist as sdist
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "sapcu.h")).read()
+    declared = set(re.findall(r"\b(sapcu_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 15
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libsapcu_hip.so does not export %s" % name
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert _lib.load().sapcu_abi_version() == 1
+
+
+def test_argument_errors_come_back_as_codes_not_crashes():
+    lib = _lib.load()
+    rc = lib.sapcu_knn_gather_f64(None, 10, None, 1, 4, None, None, None, None)
+    assert rc == -1 and b"null" in lib.sapcu_last_error()
+    with pytest.raises(_lib.SapcuError) as ei:
+        _lib.check(lib.sapcu_workspace_bytes(None, 1, 48))
+    assert ei.value.args[0] == -1
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(_lib.SapcuLibraryError):
+        _lib.load(str(tmp_path / "nope.so"))
+
+
+def test_state_dict_layout_matches_reference_dump():
+    g = golden("state_dict_layout.npz")
+    for kind, cls, kw in (("fn", sapcu_amd.ImprovedSNNNormalEstimation, FN_KW), ("fd", sapcu_amd.EnhancedSNNDistanceEstimation, FD_KW)):
+        sd = cls(**kw).state_dict()
+        assert list(sd) == list(g[kind + "_keys"])
+        assert [str(tuple(v.shape)) for v in sd.values()] == list(g[kind + "_shapes"])
+    assert sum(v.numel() for v in sapcu_amd.ImprovedSNNNormalEstimation(**FN_KW).state_dict().values()) == 6796652
+
+
+def test_constructor_and_forward_error_conventions():
+    with pytest.raises(NotImplementedError):
+        sapcu_amd.ImprovedSNNNormalEstimation(use_snn_decoder=True)
+    with pytest.raises(NotImplementedError):
+        sapcu_amd.EnhancedSNNDistanceEstimation(use_snn_decoder=True)
+    m = sapcu_amd.ImprovedSNNNormalEstimation(**FN_KW)
+    assert not m.training
+    with pytest.raises(ValueError):
+        m(torch.zeros(4, 48))                    # bad rank
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 48, 4))                 # not xyz
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 48, 3))                 # CPU tensors: no CPU path
+    with pytest.raises(NotImplementedError):
+        m.train()
+    m.reset_states()
+    m.eval()
+
+
+def test_packer_slot_tables(weights):
+    blob, d = packing.pack_fn(weights("fn"))
+    assert d.size == packing.FN_SLOTS == 81 and blob.dtype == np.float32 and (d % 4 == 0).all()
+    blob, d = packing.pack_fd(weights("fd"), 4)
+    assert d.size == packing.FD_SLOTS == 42 and (d % 4 == 0).all() and d[-1] < blob.size
+
+
+def test_bn_fold_is_exact_in_float64():
+    rng = np.random.default_rng(0)
+    sd = {"l.weight": torch.from_numpy(rng.normal(size=(5, 7)).astype(np.float32)), "l.bias": torch.from_numpy(rng.normal(size=5).astype(np.float32)),
+          "b.weight": torch.from_numpy(rng.uniform(0.5, 1.5, 5).astype(np.float32)), "b.bias": torch.from_numpy(rng.normal(size=5).astype(np.float32)),
+          "b.running_mean": torch.from_numpy(rng.normal(size=5).astype(np.float32)), "b.running_var": torch.from_numpy(rng.uniform(0.1, 1, 5).astype(np.float32))}
+    w, b = packing.fold_bn(sd, "l", "b")
+    x = rng.normal(size=(3, 7))
+    ref = torch.nn.functional.batch_norm(torch.nn.functional.linear(torch.from_numpy(x), sd["l.weight"].double(), sd["l.bias"].double()),
+                                         sd["b.running_mean"].double(), sd["b.running_var"].double(), sd["b.weight"].double(), sd["b.bias"].double(), False, 0.0, 1e-5)
+    np.testing.assert_allclose(x @ w.T + b, ref.numpy(), rtol=1e-12, atol=1e-12)
+
+
+def test_split_batches_is_array_split():
+    for n in (1, 63, 64, 65, 901, 4096):
+        for bs in (64, 256, 400):
+            ref = np.array_split(np.arange(n), max(1, n // bs))
+            assert [(int(c[0]), int(c[-1]) + 1) for c in ref] == gen.split_batches(n, bs)
+
+
+def test_conditioned_weights_are_deterministic(weights):
+    a, b = weights("fd"), weights("fd")
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert float(a["encoder.snn_blocks.0.delta_T"].min()) >= 0.9 - 1e-6
+
+
+def test_shard_ranges_cover_and_are_contiguous():
+    for n in (0, 1, 7, 8, 4096, 385123):
+        for w in (1, 2, 4, 8):
+            r = [sdist.shard_range(n, i, w) for i in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+
+
+def _gloo_worker(rank, world, port, n, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seeds = torch.arange(n * 3, dtype=torch.float64).view(n, 3)
+
+        class FakeGen:                      # stands in for the GPU refine: the gather logic is what is under test
+            model1 = type("M", (), {"knn_cache_mode": "reference"})()
+
+            def refine(self, cloud, s):
+                assert self.model1.knn_cache_mode == "fresh"
+                return s * 2.0 + 1.0, None, None
+
+        g = FakeGen()
+        out, (s, e) = sdist.upsample_sharded(g, None, seeds)
+        assert g.model1.knn_cache_mode == "reference"
+        q.put((rank, bool(torch.equal(out, seeds * 2.0 + 1.0)), (s, e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [10, 7, 1])
+def test_sharded_upsample_all_gather_gloo_world2(n):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _ in res)
+    assert res[0][2][0] == 0 and res[1][2][1] == n and res[0][2][1] == res[1][2][0]
