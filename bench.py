@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Headline benchmark: upsampled query-points/s on the BASELINE.json config
+"Synthetic sphere 5000 pts, 4x upsample, M=48 T=4, 1xMI355X".
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A step = ONE pass of the hot path over one resident batch of B=4096 query points per GPU:
+outer kNN + gather/centre -> fn forward -> normalise -> gather/rotate -> fd forward -> displace
+(+ for N > 1 the all-gather of the refined points).  Inputs (cloud, queries, weights) are in HBM
+before the timed region.  Weak scaling: every rank refines its own 4096 queries per step.
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel (the attention-weight GEMM gemm_kernel<EPI_LIF,PRO_ATTN_IN>,
+                fn/snn_coder.py:367-376), its three per-block shapes launched back to back on the
+                current stream between two events: achieved = mean algorithmic FLOP per launch
+                (2*r*d*d) / mean launch time, against the 157.3 TFLOP/s f32-MFMA peak.
+  cpu_baseline  the oracle (our CPU restatement, torch-CPU, all host threads) timed on a bounded
+                sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU = 4096
+M_PTS = 48
+T_STEPS = 4
+N_CLOUD = 5000
+FN_KW = dict(k_values=[24, 18, 12], emb_dims=640, time_steps_enc=T_STEPS, num_heads=8)
+FD_KW = dict(k=32, emb_dims=768, time_steps_enc=T_STEPS, num_heads=8, k_scales=[8, 16, 32, 48])
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, Chip-level parameters
+
+
+def build_models(dev):
+    import sapcu_amd
+    from sapcu_amd import testing as T
+    gold = os.path.join(ROOT, "tests", "golden")
+    bn = {}
+    for kind in ("fn", "fd"):
+        p = os.path.join(gold, "bn_calib_%s.npz" % kind)
+        bn[kind] = dict(np.load(p)) if os.path.exists(p) else None
+    fn = sapcu_amd.ImprovedSNNNormalEstimation(**FN_KW)
+    fd = sapcu_amd.EnhancedSNNDistanceEstimation(**FD_KW)
+    sdn = T.conditioned_state_dict(fn.state_dict(), 0, bn_stats=bn["fn"])
+    sdd = T.conditioned_state_dict(fd.state_dict(), 0, bn_stats=bn["fd"])
+    fn.load_state_dict(sdn)
+    fd.load_state_dict(sdd)
+    fn, fd = fn.to(dev), fd.to(dev)
+    fn.knn_cache_mode = "fresh"       # every batch computes its own in-patch neighbours (no replay shortcut)
+    return fn, fd, sdn, sdd
+
+
+def roofline_leg(dev, reps=5):
+    """Time the dominant kernel alone: its three per-block launches for one 512-patch chunk."""
+    from sapcu_amd import _lib
+    lib = _lib.load()
+    chunk = int(os.environ.get("SAPCU_CHUNK", "512"))
+    chunk = min(chunk, B_PER_GPU)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    shapes = []
+    for l, kk in enumerate(FN_KW["k_values"]):
+        d = 128 << l
+        pts = chunk * M_PTS
+        r = pts * kk
+        pe = torch.rand((r, d), generator=g).to(dev)
+        qkv = torch.rand((pts, 3 * d), generator=g).to(dev)
+        idx = torch.randint(0, M_PTS, (r,), generator=g, dtype=torch.int32).to(dev)
+        w = ((torch.rand((d, d), generator=g) - 0.5) * (2.0 / d ** 0.5)).to(dev)
+        bias = (torch.rand((d,), generator=g) + 0.3).to(dev)
+        lif = torch.stack([torch.full((d,), 0.9), torch.full((d,), 0.01), torch.full((d,), 0.5), torch.ones(d)]).to(dev)
+        out = torch.empty((r, d), device=dev)
+        shapes.append((pe, r, d, w, bias, lif, qkv, idx, kk, out))
+
+    def launch_all():
+        for pe, r, d, w, bias, lif, qkv, idx, kk, out in shapes:
+            _lib.check(lib.sapcu_attn_gemm_f32(_lib.ptr(pe), r, d, _lib.ptr(w), _lib.ptr(bias), _lib.ptr(lif), 4, _lib.ptr(qkv),
+                                               _lib.ptr(idx), kk, M_PTS, _lib.ptr(out), _lib.current_stream()))
+
+    launch_all()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()                       # torch's current stream IS the stream the kernels are launched on
+    for _ in range(reps):
+        launch_all()
+    e1.record()
+    torch.cuda.synchronize()
+    n_launch = reps * len(shapes)
+    avg_s = e0.elapsed_time(e1) * 1e-3 / n_launch
+    flop = float(np.mean([2.0 * s[1] * s[2] * s[2] for s in shapes]))
+    ach = flop / avg_s / 1e12
+    return {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": "gemm_kernel<EPI_LIF,PRO_ATTN_IN>", "avg_launch_ms": round(avg_s * 1e3, 4),
+            "flop_per_launch": flop, "launches_timed": n_launch, "chunk_patches": chunk}
+
+
+def cpu_baseline(sdn, sdd, sample=64):
+    """Oracle on `sample` of the same queries (kNN + fn + rotate + fd + displace), all host threads."""
+    from sapcu_amd import testing as T
+    from oracle import geom_path as G, snn_path as O
+    fn_hp = dict(FN_KW)
+    fd_hp = dict(FD_KW)
+    cloud, q = T.sphere_cloud(N_CLOUD, 0), T.grid_queries(sample, 0)
+
+    def fn_fwd(patch, pre):
+        with torch.no_grad():
+            return O.fn_forward(sdn, patch, fn_hp, knn_idx=pre), None
+
+    def fd_fwd(patch):
+        with torch.no_grad():
+            return O.fd_forward(sdd, patch, fd_hp)
+
+    # the GPU box gives one GPU's share of the host (16 cores); never oversubscribe a cgroup-limited box
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    G.upsample_core(cloud, q, fn_fwd, fd_fwd, M_PTS, sample, "fresh")
+    dt = time.perf_counter() - t0
+    return {"value": round(sample / dt, 3), "unit": "query-points/s", "cores": cores, "kind": "port",
+            "sample": "%d of the %d queries, one chunk, oracle (torch-CPU restatement), %.1f s" % (sample, B_PER_GPU, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import sapcu_amd
+    from sapcu_amd import testing as T
+    from sapcu_amd import dist as sdist
+    fn, fd, sdn, sdd = build_models(dev)
+    gen = sapcu_amd.Generator3D6(fn, fd, dev, k_neighbors=M_PTS, batch_size=B_PER_GPU)
+    cloud = torch.as_tensor(T.sphere_cloud(N_CLOUD, 0), device=dev)
+    seeds = torch.as_tensor(T.grid_queries(B_PER_GPU * world, 0)[rank * B_PER_GPU:(rank + 1) * B_PER_GPU], device=dev)
+
+    def step():
+        with torch.no_grad():
+            refined, _, _ = gen.refine(cloud, seeds)
+            if world > 1:
+                refined = sdist.gather_refined(refined, B_PER_GPU * world)
+        return refined
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def log(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    log("models and inputs resident; warmup x%d" % args.warmup)
+    for i in range(args.warmup):
+        tw = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        log("warmup step %d: %.1f ms" % (i, (time.perf_counter() - tw) * 1e3))
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    line = None
+    if rank == 0:
+        total = B_PER_GPU * world * args.steps
+        line = {
+            "metric": "upsampled query-points/sec (kNN + fn fwd + rotate + fd fwd + displace), 4x scale, M=48 T=4",
+            "value": round(total / dt, 2), "unit": "query-points/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic sphere N=%d (seed 0), B=%d grid queries per GPU per step, M=%d, T=%d, "
+                                   "fn k=[24,18,12] emb 640, fd k=32 scales [8,16,32,48] emb 768, conditioned-random "
+                                   "weights seed 0, in-patch kNN recomputed every batch" % (N_CLOUD, B_PER_GPU, M_PTS, T_STEPS),
+                       "queries_per_gpu_per_step": B_PER_GPU, "cloud_points": N_CLOUD, "neighbours": M_PTS,
+                       "time_steps": T_STEPS, "outer_knn": "f64 brute force", "parallelism": "query shards x%d" % world},
+            "per_gpu": round(total / dt / world, 2),
+        }
+        log("timed %d steps: %.1f ms/step" % (args.steps, dt / args.steps * 1e3))
+        if not args.no_roofline:
+            line["roofline"] = roofline_leg(dev)
+            log("roofline leg done: %s" % line["roofline"])
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sdn, sdd)
+            log("cpu baseline done: %s" % line["cpu_baseline"])
+    barrier()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,7 +42,10 @@ _SIGNATURES = {
                                  POINTER(c_void_p), c_void_p]),
     "sapcu_fd_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64,
                                  POINTER(c_void_p), c_void_p]),
-    "sapcu_gemm_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "sapcu_gemm_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                               c_int, c_void_p]),
+    "sapcu_attn_gemm_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                    c_int, c_int, c_void_p, c_void_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -102,6 +102,15 @@ __device__ __forceinline__ float lif_selfloop(float x, const NeuronP& p, int T) 
     return x;
 }
 
+// IEEE-correct f64 square root: the hardware/OCML result refined by one Markstein step
+// (s + (d - s*s) / (2 s) with the residual from an FMA), so that distances equal libm's sqrt.
+__device__ __forceinline__ double sqrt_cr(double d) {
+    if (!(d > 0.0)) return d == 0.0 ? 0.0 : sqrt(d);
+    const double s = sqrt(d);
+    const double r = __fma_rn(-s, s, d);
+    return __fma_rn(r, __ddiv_rn(0.5, s), s);
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {   // nn.GELU() default (exact erf form)
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }

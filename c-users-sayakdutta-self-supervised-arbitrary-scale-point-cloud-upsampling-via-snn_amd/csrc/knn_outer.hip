@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void knn_outer_kernel(const double* __restrict
         if (p >= k) continue;
         const TopSlot s = slot == 0 ? s0 : s1;
         idx_out[qi * k + p] = s.i;
-        if (dist_out) dist_out[qi * k + p] = __dsqrt_rn(s.d);
+        if (dist_out) dist_out[qi * k + p] = sqrt_cr(s.d);
         if (patch_out) {
             const double* pp = cloud + (int64_t)s.i * 3;
             float* o = patch_out + (qi * k + p) * 3;

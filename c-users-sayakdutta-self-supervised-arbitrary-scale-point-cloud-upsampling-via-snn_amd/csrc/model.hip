@@ -456,10 +456,23 @@ int sapcu_l2_normalize3(const float* in, float* out, int64_t b, void* stream) {
     return launch_l2_normalize3(in, out, b, (hipStream_t)stream);
 }
 
-int sapcu_gemm_f32(const float* a, int64_t r, int k, int lda, const float* w, int n, const float* bias, float* c,
-                   int ldc, void* stream) {
+int sapcu_gemm_f32(const float* a, int64_t r, int k, int lda, const float* w, int n, const float* bias,
+                   const float* lif4, int lif_steps, float* c, int ldc, void* stream) {
     SAPCU_CHECK_ARG(a && w && c && r >= 0 && n >= 1, "gemm: bad argument");
-    return gemm(a, r, k, lda, w, n, bias, c, ldc, EPI_BIAS, (hipStream_t)stream);
+    SAPCU_CHECK_ARG(!lif4 || lif_steps >= 1, "gemm: lif_steps must be >= 1");
+    return gemm(a, r, k, lda, w, n, bias, c, ldc, lif4 ? EPI_LIF : EPI_BIAS, (hipStream_t)stream, lif4, lif_steps);
+}
+
+int sapcu_attn_gemm_f32(const float* pe, int64_t r, int d, const float* w, const float* bias, const float* lif4,
+                        int lif_steps, const float* qkv, const int32_t* idx, int kk, int m_pts, float* gout,
+                        void* stream) {
+    SAPCU_CHECK_ARG(pe && w && lif4 && qkv && idx && gout && r >= 0 && d >= 32 && lif_steps >= 1, "attn_gemm: bad argument");
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a = pe; g.r = r; g.k = d; g.lda = d; g.w = w; g.n = d; g.bias = bias; g.c = gout; g.ldc = d;
+    g.epi = EPI_LIF; g.pro = PRO_ATTN_IN; g.lif = lif4; g.lif_T = lif_steps;
+    g.q = qkv; g.kf = qkv + d; g.ldq = 3 * d; g.idx = idx; g.kk = kk; g.mpts = m_pts;
+    return launch_gemm(g, (hipStream_t)stream);
 }
 
 int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob, int64_t blob_floats,

@@ -148,10 +148,19 @@ int sapcu_model_gate_violations(sapcu_model_t m, int* count_host);
 /* out = in / max(||in||_2, 1e-12) row-wise for [b,3] — the extra F.normalize of generation.py:139. */
 int sapcu_l2_normalize3(const float* in, float* out, int64_t b, void* stream);
 
-/* Plain fp32 GEMM with the library's MFMA kernel, exposed for tests and roofline runs:
- * C[r,n] = A[r,k] * W[n,k]^T + bias[n].  k % 32 == 0. */
-int sapcu_gemm_f32(const float* a, int64_t r, int k, int lda, const float* w, int n,
-                   const float* bias, float* c, int ldc, void* stream);
+/* The library's MFMA GEMM, exposed for tests and roofline runs:
+ *   C[r,n] = epi( A[r,k] * W[n,k]^T + bias[n] ),  k % 32 == 0, A/W 16-byte aligned, lda % 4 == 0.
+ * lif4 == NULL: epi = identity.  Otherwise lif4 = raw neuron parameters [4][n] and the epilogue is
+ * the lif_steps-step self-feeding LIF loop (the fused form of conv+BN -> snn loop, fn:317-320). */
+int sapcu_gemm_f32(const float* a, int64_t r, int k, int lda, const float* w, int n, const float* bias,
+                   const float* lif4, int lif_steps, float* c, int ldc, void* stream);
+
+/* The attention-weight GEMM of one fn block, the most expensive launch of the path:
+ *   g[row,:] = LIF_x4( W . (q[pt(row)] - k[nbr(row)] + pe[row]) + bias )      (fn/snn_coder.py:367-376)
+ * pe [r,d]; qkv [b*m, 3d] (q | k | v); idx [r] = flattened [b,m,kk] in-patch neighbours; w [d,d]. */
+int sapcu_attn_gemm_f32(const float* pe, int64_t r, int d, const float* w, const float* bias,
+                        const float* lif4, int lif_steps, const float* qkv, const int32_t* idx, int kk,
+                        int m_pts, float* g, void* stream);
 
 #ifdef __cplusplus
 }
