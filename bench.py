@@ -10,10 +10,11 @@ outer kNN + gather/centre -> fn forward -> normalise -> gather/rotate -> fd forw
 before the timed region.  Weak scaling: every rank refines its own 4096 queries per step.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel (the attention-weight GEMM gemm_kernel<EPI_LIF,PRO_ATTN_IN>,
-                fn/snn_coder.py:367-376), its three per-block shapes launched back to back on the
-                current stream between two events: achieved = mean algorithmic FLOP per launch
-                (2*r*d*d) / mean launch time, against the 157.3 TFLOP/s f32-MFMA peak.
+  roofline      the dominant kernel symbol (the positional-encoding GEMM gemm_kernel<EPI_LIF_ATTN>,
+                fn/snn_coder.py:360-368: d x d contraction + 4-step neuron loop + q-k+pe gather), its
+                three per-block shapes launched back to back on the current stream between two
+                events: achieved = mean algorithmic FLOP per launch (2*r*d*d) / mean launch time,
+                against the 157.3 TFLOP/s f32-MFMA peak.
   cpu_baseline  the oracle (our CPU restatement, torch-CPU, all host threads) timed on a bounded
                 sample of the same workload (rank 0, N=1 only).
 """
@@ -76,12 +77,15 @@ def roofline_leg(dev, reps=5):
         bias = (torch.rand((d,), generator=g) + 0.3).to(dev)
         lif = torch.stack([torch.full((d,), 0.9), torch.full((d,), 0.01), torch.full((d,), 0.5), torch.ones(d)]).to(dev)
         out = torch.empty((r, d), device=dev)
-        shapes.append((pe, r, d, w, bias, lif, qkv, idx, kk, out))
+        out2 = torch.empty((r, d), device=dev)
+        tab = torch.empty((r, 2), dtype=torch.int32, device=dev)
+        shapes.append((pe, r, d, w, bias, lif, qkv, idx, kk, out, out2, tab))
 
     def launch_all():
-        for pe, r, d, w, bias, lif, qkv, idx, kk, out in shapes:
-            _lib.check(lib.sapcu_attn_gemm_f32(_lib.ptr(pe), r, d, _lib.ptr(w), _lib.ptr(bias), _lib.ptr(lif), 4, _lib.ptr(qkv),
-                                               _lib.ptr(idx), kk, M_PTS, _lib.ptr(out), _lib.current_stream()))
+        for pe, r, d, w, bias, lif, qkv, idx, kk, out, out2, tab in shapes:
+            _lib.check(lib.sapcu_posenc_gemm_f32(_lib.ptr(pe), r, d, _lib.ptr(w), _lib.ptr(bias), _lib.ptr(lif), 4, _lib.ptr(qkv),
+                                                 _lib.ptr(idx), kk, M_PTS, _lib.ptr(out), _lib.ptr(out2), _lib.ptr(tab),
+                                                 _lib.current_stream()))
 
     launch_all()
     torch.cuda.synchronize()
@@ -97,7 +101,7 @@ def roofline_leg(dev, reps=5):
     ach = flop / avg_s / 1e12
     return {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-            "kernel": "gemm_kernel<EPI_LIF,PRO_ATTN_IN>", "avg_launch_ms": round(avg_s * 1e3, 4),
+            "kernel": "gemm_kernel<EPI_LIF_ATTN>", "avg_launch_ms": round(avg_s * 1e3, 4),
             "flop_per_launch": flop, "launches_timed": n_launch, "chunk_patches": chunk}
 
 

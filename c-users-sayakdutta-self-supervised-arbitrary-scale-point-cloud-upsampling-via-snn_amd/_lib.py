@@ -44,8 +44,8 @@ _SIGNATURES = {
                                  POINTER(c_void_p), c_void_p]),
     "sapcu_gemm_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                c_int, c_void_p]),
-    "sapcu_attn_gemm_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                                    c_int, c_int, c_void_p, c_void_p]),
+    "sapcu_posenc_gemm_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                      c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -61,13 +61,20 @@ __device__ __forceinline__ NeuronP load_eif(const float* __restrict__ p6, int st
     return p;
 }
 
-// eval-mode spike surrogate: 0.5*N(x) + 0.5*sigmoid(10 x), x clamped to +-10 (fn:135-146)
+// eval-mode spike surrogate: 0.5*N(x) + 0.5*sigmoid(10 x), x clamped to +-10 (fn:135-146).
+// Same operation order as the reference; the transcendentals are the hardware v_exp_f32 / v_rcp_f32
+// (1 ulp each) instead of libm calls: |error| <= 2e-7 absolute on a value in (0,1), measured against the
+// reference vectors in tests/golden/neuron_unit.npz (bar 1e-6).
 __device__ __forceinline__ float soft_spike(float d) {
     const float x = clampf(d, -10.0f, 10.0f);
-    const float g = __fdiv_rn(expf(__fdiv_rn(-__fmul_rn(x, x), 2.0f)), 2.5066282746310002f);
-    const float s = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-__fmul_rn(10.0f, x))));
+    const float g = __fmul_rn(__builtin_amdgcn_exp2f(__fmul_rn(__fmul_rn(x, x), -0.72134752044448170368f)),
+                              0.39894228040143267794f);                     // exp(-x^2/2) / sqrt(2 pi)
+    const float e = __builtin_amdgcn_exp2f(__fmul_rn(x, -14.426950408889634074f));   // exp(-10 x)
+    const float s = __builtin_amdgcn_rcpf(__fadd_rn(1.0f, e));
     return __fadd_rn(__fmul_rn(0.5f, g), __fmul_rn(0.5f, s));
 }
+
+__device__ __forceinline__ float fast_exp(float a) { return __builtin_amdgcn_exp2f(__fmul_rn(a, 1.4426950408889634074f)); }
 
 struct NeuronS {
     float m, th, r;
@@ -81,7 +88,7 @@ __device__ __forceinline__ float neuron_step(float x, NeuronS& s, const NeuronP&
     float extra = 0.f;
     if (EIF) {
         const float a = clampf(__fdiv_rn(__fsub_rn(s.m, p.rh), __fadd_rn(p.dT, 1e-6f)), -5.0f, 5.0f);
-        extra = __fmul_rn(p.dT, expf(a));
+        extra = __fmul_rn(p.dT, fast_exp(a));
     }
     const float xin = (s.r <= 0.f) ? x : __fmul_rn(x, 0.f);
     float m = __fadd_rn(__fmul_rn(__fmul_rn(s.m, p.decay), __fsub_rn(1.0f, s.r)), xin);
@@ -119,8 +126,7 @@ __device__ __forceinline__ float lrelu02(float x) { return x >= 0.f ? x : 0.2f *
 // ---------------------------------------------------------------------------------------------
 // GEMM (gemm_f32.hip):  C[r,n] = epi( pro(A)[r,k] * W[n,k]^T + bias[n] )
 // ---------------------------------------------------------------------------------------------
-enum GemmEpi { EPI_BIAS = 0, EPI_LIF = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_LRELU = 4, EPI_RESID_GELU = 5 };
-enum GemmPro { PRO_PLAIN = 0, PRO_ATTN_IN = 1 };
+enum GemmEpi { EPI_BIAS = 0, EPI_LIF = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_LRELU = 4, EPI_RESID_GELU = 5, EPI_LIF_ATTN = 6 };
 
 struct GemmArgs {
     const float* a;      // [r, lda]
@@ -131,19 +137,19 @@ struct GemmArgs {
     const float* bias;   // [n] or null
     float* c;            // [r, ldc]
     int ldc;
-    int epi, pro;
-    // EPI_LIF: raw neuron params [4][n], T self-loop steps
+    int epi;
+    // EPI_LIF / EPI_LIF_ATTN: raw neuron params [4][n], T self-loop steps
     const float* lif;
     int lif_T;
-    // EPI_RESID: c = acc + bias + resid[r, ldr]
+    // EPI_RESID / EPI_RESID_GELU: c = f(acc + bias + resid[r, ldr])
     const float* resid;
     int ldr;
-    // PRO_ATTN_IN: a = pe; A[row,:] = pe[row,:] + q[row / kk,:] - kf[(row / (m*kk))*m + idx[row],:]
-    const float* q;      // q rows at qkv + 0, kf at qkv + k (the GEMM K == d), ld = ldq
+    // EPI_LIF_ATTN: additionally c2[row,:] = q[tab[row].x,:] - kf[tab[row].y,:] + c[row,:]
+    float* c2;
+    const float* q;      // q rows at qkv + 0, kf rows at qkv + d, row stride ldq
     const float* kf;
     int ldq;
-    const int32_t* idx;  // [r] flattened [b,m,kk]
-    int kk, mpts;
+    const int2* tab;     // [r] (query-point row, neighbour row) of each edge row (launch_edge_table)
 };
 int launch_gemm(const GemmArgs& g, hipStream_t st);
 

@@ -111,7 +111,7 @@ static int gemm(const float* a, int64_t r, int k, int lda, const float* w, int n
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.a = a; g.r = r; g.k = k; g.lda = lda; g.w = w; g.n = n; g.bias = bias; g.c = c; g.ldc = ldc;
-    g.epi = epi; g.pro = PRO_PLAIN; g.lif = lif; g.lif_T = lifT; g.resid = resid; g.ldr = ldr;
+    g.epi = epi; g.lif = lif; g.lif_T = lifT; g.resid = resid; g.ldr = ldr;
     return launch_gemm(g, st);
 }
 
@@ -154,6 +154,7 @@ static int64_t fn_ws_bytes(const sapcu_model* m, int64_t b, int mp) {
     int64_t fl = 0;
     auto add = [&](int64_t n, int64_t esz) { fl += ((n * esz) + 255) & ~(int64_t)255; };
     for (int l = 0; l < 3; ++l) add(P * pl.kk[l], 4);          // idx
+    { int kmx = 1; for (int l = 0; l < 3; ++l) kmx = kmx > pl.kk[l] ? kmx : pl.kk[l]; add(P * kmx, 8); }   // edge table
     add(P * 64, 4); add(P * 192, 4); add(P * 512, 4); add(P * 1536, 4); add(P * 512, 4);
     add(pl.edge_floats, 4); add(pl.edge_floats, 4); add(pl.edge_floats, 4);
     add(pl.cb * m->emb, 4); add(pl.cb * 2048, 4); add(pl.cb * 1024, 4); add(pl.cb * 512, 4); add(pl.cb * 256, 4);
@@ -181,6 +182,9 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
         Arena A{(char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), ws_bytes, 0};
         int32_t* idx[3];
         for (int l = 0; l < 3; ++l) idx[l] = A.take<int32_t>(pl.cb * mp * pl.kk[l]);
+        int kmx = 1;
+        for (int l = 0; l < 3; ++l) kmx = kmx > pl.kk[l] ? kmx : pl.kk[l];
+        int2* tab = A.take<int2>(pl.cb * mp * kmx);
         float* feat0 = A.take<float>(pl.cb * mp * 64);
         float* cat = A.take<float>(pl.cb * mp * 192);
         float* X = A.take<float>(pl.cb * mp * 512);
@@ -229,24 +233,25 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
             // pe1 = LIF(fc_delta(x_i - x_j))                                        fn:310,355-358
             SAPCU_TRY(launch_fn_pe1(pc, idx[l], R, mp, kk, d, m->p(sb + B_DELTA_W), m->p(sb + B_DELTA_B),
                                     m->p(sb + B_DELTA_LIF), 4, B1, st));
-            // pe = LIF(fc_delta2(pe1))                                              fn:360-363
-            SAPCU_TRY(gemm(B1, R, d, d, m->p(sb + B_DELTA2_W), d, m->p(sb + B_DELTA2_B), B2, d, EPI_LIF, st,
-                           m->p(sb + B_DELTA2_LIF), 4));
-            // g = LIF(fc_gamma(q_i - k_j + pe))                                     fn:367-376
+            // pe = LIF(fc_delta2(pe1)) -> B2, and in the same epilogue attn_in = q_i - k_j + pe -> B3   fn:360-368
             {
                 GemmArgs g;
                 memset(&g, 0, sizeof(g));
-                g.a = B2; g.r = R; g.k = d; g.lda = d; g.w = m->p(sb + B_GAMMA_W); g.n = d;
-                g.bias = m->p(sb + B_GAMMA_B); g.c = B3; g.ldc = d; g.epi = EPI_LIF; g.pro = PRO_ATTN_IN;
-                g.lif = m->p(sb + B_GAMMA_LIF); g.lif_T = 4;
-                g.q = QKV; g.kf = QKV + d; g.ldq = 3 * d; g.idx = idx[l]; g.kk = kk; g.mpts = mp;
+                g.a = B1; g.r = R; g.k = d; g.lda = d; g.w = m->p(sb + B_DELTA2_W); g.n = d;
+                g.bias = m->p(sb + B_DELTA2_B); g.c = B2; g.ldc = d; g.epi = EPI_LIF_ATTN;
+                g.lif = m->p(sb + B_DELTA2_LIF); g.lif_T = 4; g.c2 = B3;
+                g.q = QKV; g.kf = QKV + d; g.ldq = 3 * d; g.tab = tab;
+                SAPCU_TRY(launch_edge_table(idx[l], R, mp, kk, tab, st));
                 SAPCU_TRY(launch_gemm(g, st));
             }
-            // a = fc_gamma2(g)                                                      fn:378
-            SAPCU_TRY(gemm(B3, R, d, d, m->p(sb + B_GAMMA2_W), d, m->p(sb + B_GAMMA2_B), B1, d, EPI_BIAS, st));
+            // g = LIF(fc_gamma(attn_in)) -> B1                                      fn:373-376
+            SAPCU_TRY(gemm(B3, R, d, d, m->p(sb + B_GAMMA_W), d, m->p(sb + B_GAMMA_B), B1, d, EPI_LIF, st,
+                           m->p(sb + B_GAMMA_LIF), 4));
+            // a = fc_gamma2(g) -> B3                                                fn:378
+            SAPCU_TRY(gemm(B1, R, d, d, m->p(sb + B_GAMMA2_W), d, m->p(sb + B_GAMMA2_B), B3, d, EPI_BIAS, st));
             // res = sum_j softmax_j(a / sqrt(hd)) * (v_j + pe)                      fn:379-389
             const float sqrt_hd = (float)sqrt((double)(d / m->heads));
-            SAPCU_TRY(launch_fn_softmax_agg(B1, B2, QKV + 2 * d, 3 * d, idx[l], P, mp, kk, d, sqrt_hd, RES, st));
+            SAPCU_TRY(launch_fn_softmax_agg(B3, B2, QKV + 2 * d, 3 * d, idx[l], P, mp, kk, d, sqrt_hd, RES, st));
             // out_proj, fc2 + residual                                              fn:393-394
             SAPCU_TRY(gemm(RES, P, d, d, m->p(sb + B_OUT_W), d, m->p(sb + B_OUT_B), X, d, EPI_BIAS, st));
             SAPCU_TRY(gemm(X, P, d, d, m->p(sb + B_FC2_W), 64, m->p(sb + B_FC2_B), cat + 64 * l, 192, EPI_RESID, st,
@@ -463,15 +468,18 @@ int sapcu_gemm_f32(const float* a, int64_t r, int k, int lda, const float* w, in
     return gemm(a, r, k, lda, w, n, bias, c, ldc, lif4 ? EPI_LIF : EPI_BIAS, (hipStream_t)stream, lif4, lif_steps);
 }
 
-int sapcu_attn_gemm_f32(const float* pe, int64_t r, int d, const float* w, const float* bias, const float* lif4,
-                        int lif_steps, const float* qkv, const int32_t* idx, int kk, int m_pts, float* gout,
-                        void* stream) {
-    SAPCU_CHECK_ARG(pe && w && lif4 && qkv && idx && gout && r >= 0 && d >= 32 && lif_steps >= 1, "attn_gemm: bad argument");
+int sapcu_posenc_gemm_f32(const float* pe1, int64_t r, int d, const float* w, const float* bias, const float* lif4,
+                          int lif_steps, const float* qkv, const int32_t* idx, int kk, int m_pts, float* pe_out,
+                          float* attn_in_out, void* edge_table_ws, void* stream) {
+    SAPCU_CHECK_ARG(pe1 && w && lif4 && qkv && idx && pe_out && attn_in_out && edge_table_ws && r >= 0 && d >= 32 &&
+                        lif_steps >= 1 && kk >= 1 && m_pts >= 1,
+                    "posenc_gemm: bad argument");
     GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.a = pe; g.r = r; g.k = d; g.lda = d; g.w = w; g.n = d; g.bias = bias; g.c = gout; g.ldc = d;
-    g.epi = EPI_LIF; g.pro = PRO_ATTN_IN; g.lif = lif4; g.lif_T = lif_steps;
-    g.q = qkv; g.kf = qkv + d; g.ldq = 3 * d; g.idx = idx; g.kk = kk; g.mpts = m_pts;
+    g.a = pe1; g.r = r; g.k = d; g.lda = d; g.w = w; g.n = d; g.bias = bias; g.c = pe_out; g.ldc = d;
+    g.epi = EPI_LIF_ATTN; g.lif = lif4; g.lif_T = lif_steps; g.c2 = attn_in_out;
+    g.q = qkv; g.kf = qkv + d; g.ldq = 3 * d; g.tab = (const int2*)edge_table_ws;
+    SAPCU_TRY(launch_edge_table(idx, r, m_pts, kk, (int2*)edge_table_ws, (hipStream_t)stream));
     return launch_gemm(g, (hipStream_t)stream);
 }
 

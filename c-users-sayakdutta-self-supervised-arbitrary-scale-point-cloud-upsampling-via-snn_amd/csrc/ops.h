@@ -14,6 +14,7 @@ int launch_fn_stem(const float* patch, int64_t rows, const float* w, const float
                    float* out, hipStream_t st);
 int launch_fn_pe1(const float* patch, const int32_t* idx, int64_t rows, int m, int kk, int d, const float* w,
                   const float* bias, const float* lif, int T, float* out, hipStream_t st);
+int launch_edge_table(const int32_t* idx, int64_t rows, int m, int kk, int2* tab, hipStream_t st);
 int launch_fn_softmax_agg(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx, int64_t pts,
                           int m, int kk, int d, float sqrt_hd, float* res, hipStream_t st);
 int launch_rowgroup_max(const float* in, int64_t groups, int m, int c, float* out, hipStream_t st);

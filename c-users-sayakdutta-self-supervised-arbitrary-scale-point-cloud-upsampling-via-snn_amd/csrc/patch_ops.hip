@@ -219,6 +219,27 @@ int launch_fn_pe1(const float* patch, const int32_t* idx, int64_t rows, int m, i
 }
 
 // =============================================================================================
+// fn: edge-row table: row (patch, point i, neighbour slot j) -> (row of point i, row of its j-th neighbour)
+//     in the [b*m, .] per-point tensors.  Lets the GEMM epilogue gather q_i / k_j without divisions.
+// =============================================================================================
+__global__ __launch_bounds__(256) void edge_table_kernel(const int32_t* __restrict__ idx, int64_t rows, int m, int kk,
+                                                         int2* __restrict__ tab) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const int64_t pt = r / kk;
+    const int64_t patch_i = pt / m;
+    tab[r] = make_int2((int)pt, (int)(patch_i * m + idx[r]));
+}
+
+int launch_edge_table(const int32_t* idx, int64_t rows, int m, int kk, int2* tab, hipStream_t st) {
+    if (rows == 0) return SAPCU_OK;
+    SAPCU_CHECK_ARG(rows < 0x7fffffffLL, "edge_table: too many rows");
+    hipLaunchKernelGGL(edge_table_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, idx, rows, m, kk, tab);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+// =============================================================================================
 // fn: per-channel softmax over the kk neighbours and aggregation (fn:379-389)
 //     attn = softmax(a / sqrt(hd));  res[pt,c] = sum_j attn_j * (v[nbr_j, c] + pe[edge_j, c])
 //     thread per (point, channel)

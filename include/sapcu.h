@@ -155,12 +155,14 @@ int sapcu_l2_normalize3(const float* in, float* out, int64_t b, void* stream);
 int sapcu_gemm_f32(const float* a, int64_t r, int k, int lda, const float* w, int n, const float* bias,
                    const float* lif4, int lif_steps, float* c, int ldc, void* stream);
 
-/* The attention-weight GEMM of one fn block, the most expensive launch of the path:
- *   g[row,:] = LIF_x4( W . (q[pt(row)] - k[nbr(row)] + pe[row]) + bias )      (fn/snn_coder.py:367-376)
- * pe [r,d]; qkv [b*m, 3d] (q | k | v); idx [r] = flattened [b,m,kk] in-patch neighbours; w [d,d]. */
-int sapcu_attn_gemm_f32(const float* pe, int64_t r, int d, const float* w, const float* bias,
-                        const float* lif4, int lif_steps, const float* qkv, const int32_t* idx, int kk,
-                        int m_pts, float* g, void* stream);
+/* The positional-encoding GEMM of one fn block — the heaviest single launch shape of the path:
+ *   pe[row,:]      = LIF_x4( W . pe1[row,:] + bias )                         (fn/snn_coder.py:360-363)
+ *   attn_in[row,:] = q[pt(row),:] - k[nbr(row),:] + pe[row,:]                (fn/snn_coder.py:367-368)
+ * pe1 [r,d]; qkv [b*m, 3d] (q | k | v); idx [r] = flattened [b,m,kk] in-patch neighbours; w [d,d];
+ * edge_table_ws: 8*r bytes of scratch (row -> (q row, k row) table, rebuilt by every call). */
+int sapcu_posenc_gemm_f32(const float* pe1, int64_t r, int d, const float* w, const float* bias,
+                          const float* lif4, int lif_steps, const float* qkv, const int32_t* idx, int kk,
+                          int m_pts, float* pe_out, float* attn_in_out, void* edge_table_ws, void* stream);
 
 #ifdef __cplusplus
 }
