@@ -150,8 +150,14 @@ struct GemmArgs {
     const float* kf;
     int ldq;
     const int2* tab;     // [r] (query-point row, neighbour row) of each edge row (launch_edge_table)
+    // split-f16 path (gemm_sf16.hip): W pre-split into hi / lo halves, same [n, k] indexing as w
+    const _Float16* w16_hi;
+    const _Float16* w16_lo;
+    int* ovf;            // device counter raised when an activation tile exceeds the f16 range (may be null)
 };
-int launch_gemm(const GemmArgs& g, hipStream_t st);
+int launch_gemm(const GemmArgs& g, hipStream_t st);        // f32 MFMA (exact f32 products)
+int launch_gemm_sf16(const GemmArgs& g, hipStream_t st);   // 3 x f16 MFMA, f32-quality (needs w16_hi/lo)
+int launch_split_weights(const float* w, int64_t count, void* hi, void* lo, int* ovf, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // knn / geometry (knn_outer.hip, geom.hip)

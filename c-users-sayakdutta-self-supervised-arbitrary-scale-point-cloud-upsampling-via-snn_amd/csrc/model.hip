@@ -79,6 +79,11 @@ struct sapcu_model {
     int ks[8];
     int32_t* ks_dev;
     int* gate_dev;
+    // split-f16 GEMM path: the whole blob pre-split (same indexing), activation-range overflow counter
+    bool sf16;
+    void* w16_hi;
+    void* w16_lo;
+    int* ovf_dev;
     // common
     int emb, T, heads;
     int64_t chunk;
@@ -105,14 +110,26 @@ struct Arena {
 static inline int64_t imax(int64_t a, int64_t b) { return a > b ? a : b; }
 static inline int imin(int a, int b) { return a < b ? a : b; }
 
-static int gemm(const float* a, int64_t r, int k, int lda, const float* w, int n, const float* bias, float* c, int ldc,
-                int epi, hipStream_t st, const float* lif = nullptr, int lifT = 0, const float* resid = nullptr,
-                int ldr = 0) {
+// Route a GEMM to the split-f16 kernel when the model carries pre-split weights, else to the f32 MFMA kernel.
+static int run_gemm(const sapcu_model* m, GemmArgs& g, hipStream_t st) {
+    if (m && m->sf16 && g.w >= m->blob && g.w < m->blob + m->blob_floats) {
+        const int64_t off = g.w - m->blob;
+        g.w16_hi = (const _Float16*)m->w16_hi + off;
+        g.w16_lo = (const _Float16*)m->w16_lo + off;
+        g.ovf = m->ovf_dev;
+        return launch_gemm_sf16(g, st);
+    }
+    return launch_gemm(g, st);
+}
+
+static int gemm(const sapcu_model* m, const float* a, int64_t r, int k, int lda, const float* w, int n,
+                const float* bias, float* c, int ldc, int epi, hipStream_t st, const float* lif = nullptr,
+                int lifT = 0, const float* resid = nullptr, int ldr = 0) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.a = a; g.r = r; g.k = k; g.lda = lda; g.w = w; g.n = n; g.bias = bias; g.c = c; g.ldc = ldc;
     g.epi = epi; g.lif = lif; g.lif_T = lifT; g.resid = resid; g.ldr = ldr;
-    return launch_gemm(g, st);
+    return run_gemm(m, g, st);
 }
 
 #define SAPCU_TRY(expr)                 \
@@ -225,10 +242,10 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
             const int64_t R = P * kk;
             const int sb = FN_BLK0 + l * B_SLOTS;
             // x = LIF(fc1(feat))                                                    fn:317-320
-            SAPCU_TRY(gemm(fin, P, 64, ldin, m->p(sb + B_FC1_W), d, m->p(sb + B_FC1_B), X, d, EPI_LIF, st,
+            SAPCU_TRY(gemm(m, fin, P, 64, ldin, m->p(sb + B_FC1_W), d, m->p(sb + B_FC1_B), X, d, EPI_LIF, st,
                            m->p(sb + B_SNN1), 4));
             // q|k|v = LIF(w_qs|w_ks|w_vs (x))                                       fn:322-335
-            SAPCU_TRY(gemm(X, P, d, d, m->p(sb + B_QKV_W), 3 * d, m->p(sb + B_QKV_B), QKV, 3 * d, EPI_LIF, st,
+            SAPCU_TRY(gemm(m, X, P, d, d, m->p(sb + B_QKV_W), 3 * d, m->p(sb + B_QKV_B), QKV, 3 * d, EPI_LIF, st,
                            m->p(sb + B_QKV_LIF), 4));
             // pe1 = LIF(fc_delta(x_i - x_j))                                        fn:310,355-358
             SAPCU_TRY(launch_fn_pe1(pc, idx[l], R, mp, kk, d, m->p(sb + B_DELTA_W), m->p(sb + B_DELTA_B),
@@ -242,19 +259,19 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
                 g.lif = m->p(sb + B_DELTA2_LIF); g.lif_T = 4; g.c2 = B3;
                 g.q = QKV; g.kf = QKV + d; g.ldq = 3 * d; g.tab = tab;
                 SAPCU_TRY(launch_edge_table(idx[l], R, mp, kk, tab, st));
-                SAPCU_TRY(launch_gemm(g, st));
+                SAPCU_TRY(run_gemm(m, g, st));
             }
             // g = LIF(fc_gamma(attn_in)) -> B1                                      fn:373-376
-            SAPCU_TRY(gemm(B3, R, d, d, m->p(sb + B_GAMMA_W), d, m->p(sb + B_GAMMA_B), B1, d, EPI_LIF, st,
+            SAPCU_TRY(gemm(m, B3, R, d, d, m->p(sb + B_GAMMA_W), d, m->p(sb + B_GAMMA_B), B1, d, EPI_LIF, st,
                            m->p(sb + B_GAMMA_LIF), 4));
             // a = fc_gamma2(g) -> B3                                                fn:378
-            SAPCU_TRY(gemm(B1, R, d, d, m->p(sb + B_GAMMA2_W), d, m->p(sb + B_GAMMA2_B), B3, d, EPI_BIAS, st));
+            SAPCU_TRY(gemm(m, B1, R, d, d, m->p(sb + B_GAMMA2_W), d, m->p(sb + B_GAMMA2_B), B3, d, EPI_BIAS, st));
             // res = sum_j softmax_j(a / sqrt(hd)) * (v_j + pe)                      fn:379-389
             const float sqrt_hd = (float)sqrt((double)(d / m->heads));
             SAPCU_TRY(launch_fn_softmax_agg(B3, B2, QKV + 2 * d, 3 * d, idx[l], P, mp, kk, d, sqrt_hd, RES, st));
             // out_proj, fc2 + residual                                              fn:393-394
-            SAPCU_TRY(gemm(RES, P, d, d, m->p(sb + B_OUT_W), d, m->p(sb + B_OUT_B), X, d, EPI_BIAS, st));
-            SAPCU_TRY(gemm(X, P, d, d, m->p(sb + B_FC2_W), 64, m->p(sb + B_FC2_B), cat + 64 * l, 192, EPI_RESID, st,
+            SAPCU_TRY(gemm(m, RES, P, d, d, m->p(sb + B_OUT_W), d, m->p(sb + B_OUT_B), X, d, EPI_BIAS, st));
+            SAPCU_TRY(gemm(m, X, P, d, d, m->p(sb + B_FC2_W), 64, m->p(sb + B_FC2_B), cat + 64 * l, 192, EPI_RESID, st,
                            nullptr, 0, fin, ldin));
             if (taps && taps[SAPCU_FN_TAP_BLOCK1 + l]) {
                 SAPCU_CHECK_HIP(hipMemcpy2DAsync((char*)taps[SAPCU_FN_TAP_BLOCK1 + l] + s * mp * 64 * 4, 64 * 4,
@@ -264,16 +281,16 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
             ldin = 192;
         }
         // conv_final + LIF x T_enc, max over points, fc_out                          fn:465-475
-        SAPCU_TRY(gemm(cat, P, 192, 192, m->p(FN_FINAL_W), m->emb, m->p(FN_FINAL_B), B1, m->emb, EPI_LIF, st,
+        SAPCU_TRY(gemm(m, cat, P, 192, 192, m->p(FN_FINAL_W), m->emb, m->p(FN_FINAL_B), B1, m->emb, EPI_LIF, st,
                        m->p(FN_FINAL_LIF), m->T));
         SAPCU_TRY(launch_rowgroup_max(B1, cb, mp, m->emb, pooled, st));
         SAPCU_TRY(tap_copy(taps, SAPCU_FN_TAP_POOLED, s * m->emb * 4, pooled, cb * m->emb * 4, st));
-        SAPCU_TRY(gemm(pooled, cb, m->emb, m->emb, m->p(FN_FCOUT_W), 2048, m->p(FN_FCOUT_B), enc, 2048, EPI_BIAS, st));
+        SAPCU_TRY(gemm(m, pooled, cb, m->emb, m->emb, m->p(FN_FCOUT_W), 2048, m->p(FN_FCOUT_B), enc, 2048, EPI_BIAS, st));
         SAPCU_TRY(tap_copy(taps, SAPCU_FN_TAP_ENC, s * 2048 * 4, enc, cb * 2048 * 4, st));
         // decoder MLP (Linear+BN+GELU) x3, Linear(256,3), LayerNorm(3), normalize    fn:542-549
-        SAPCU_TRY(gemm(enc, cb, 2048, 2048, m->p(FN_MLP0_W), 1024, m->p(FN_MLP0_B), h1, 1024, EPI_GELU, st));
-        SAPCU_TRY(gemm(h1, cb, 1024, 1024, m->p(FN_MLP1_W), 512, m->p(FN_MLP1_B), h2, 512, EPI_GELU, st));
-        SAPCU_TRY(gemm(h2, cb, 512, 512, m->p(FN_MLP2_W), 256, m->p(FN_MLP2_B), h3, 256, EPI_GELU, st));
+        SAPCU_TRY(gemm(m, enc, cb, 2048, 2048, m->p(FN_MLP0_W), 1024, m->p(FN_MLP0_B), h1, 1024, EPI_GELU, st));
+        SAPCU_TRY(gemm(m, h1, cb, 1024, 1024, m->p(FN_MLP1_W), 512, m->p(FN_MLP1_B), h2, 512, EPI_GELU, st));
+        SAPCU_TRY(gemm(m, h2, cb, 512, 512, m->p(FN_MLP2_W), 256, m->p(FN_MLP2_B), h3, 256, EPI_GELU, st));
         SAPCU_TRY(launch_fn_tail(h3, cb, 256, m->p(FN_HEAD_W), m->p(FN_HEAD_B), m->p(FN_LN_W), m->p(FN_LN_B), logits,
                                  normals + s * 3, st));
         SAPCU_TRY(tap_copy(taps, SAPCU_FN_TAP_LOGITS, s * 3 * 4, logits, cb * 3 * 4, st));
@@ -352,7 +369,7 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
         // scale fusion, EIF over T steps                                           fd:411-444
         SAPCU_TRY(launch_patch_knn(pc, cb, mp, 3, 3, pl.kmax0, idx0, st));
         SAPCU_TRY(launch_fd_edge0(pc, idx0, pl.kmax0, P, mp, m->nscale, m->ks_dev, m->p(FD_E0_W), m->p(FD_E0_B), E0, st));
-        SAPCU_TRY(gemm(E0, P, 64 * m->nscale, 64 * m->nscale, m->p(FD_FUSE_W), 64, m->p(FD_FUSE_B), FUSED, 64,
+        SAPCU_TRY(gemm(m, E0, P, 64 * m->nscale, 64 * m->nscale, m->p(FD_FUSE_W), 64, m->p(FD_FUSE_B), FUSED, 64,
                        EPI_LRELU, st));
         SAPCU_TRY(tap_copy(taps, SAPCU_FD_TAP_FUSED0, s * mp * 64 * 4, FUSED, P * 64 * 4, st));
         SAPCU_TRY(launch_fd_neuron(true, 0, FUSED, 64, nullptr, 0, mp, nullptr, P, 64, m->p(FD_SNN0), T, SPK, 960, 0,
@@ -371,7 +388,7 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
                 SAPCU_CHECK_HIP(hipMemcpyAsync((int32_t*)taps[SAPCU_FD_TAP_KNN] + ((int64_t)(l - 1) * b + s) * mp * pl.kk,
                                                idl, P * pl.kk * 4, hipMemcpyDeviceToDevice, st));
             const int ew = FD_EDGE1_W + 3 * (l - 1);
-            SAPCU_TRY(gemm(F, P, cin[l], 960, m->p(ew), 2 * cout[l], nullptr, AB, 2 * cout[l], EPI_BIAS, st));
+            SAPCU_TRY(gemm(m, F, P, cin[l], 960, m->p(ew), 2 * cout[l], nullptr, AB, 2 * cout[l], EPI_BIAS, st));
             SAPCU_TRY(launch_fd_neuron(l == 1, 1, AB, 2 * cout[l], idl, pl.kk, mp, m->p(ew + 1), P, cout[l], m->p(ew + 2),
                                        T, SPK, 960, coff[l], nullptr, m->gate_dev, st));
         }
@@ -381,7 +398,7 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
                                                SPK + (int64_t)t * P * 960, P * 960 * 4, hipMemcpyDeviceToDevice, st));
         }
         // multi_scale_conv + BN + LeakyReLU over all T*P rows, max over points        fd:476-480
-        SAPCU_TRY(gemm(SPK, (int64_t)T * P, 960, 960, m->p(FD_MSC_W), emb, m->p(FD_MSC_B), AGG, emb, EPI_LRELU, st));
+        SAPCU_TRY(gemm(m, SPK, (int64_t)T * P, 960, 960, m->p(FD_MSC_W), emb, m->p(FD_MSC_B), AGG, emb, EPI_LRELU, st));
         SAPCU_TRY(launch_rowgroup_max(AGG, (int64_t)T * cb, mp, emb, POOLED, st));
         if (taps && taps[SAPCU_FD_TAP_POOLED]) {
             for (int t = 0; t < T; ++t)
@@ -391,16 +408,16 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
         SAPCU_TRY(launch_fd_temporal(POOLED, T, cb, emb, m->p(FD_TI_W), m->p(FD_SNNFC), ENC, st));
         SAPCU_TRY(tap_copy(taps, SAPCU_FD_TAP_ENC, s * emb * 4, ENC, cb * emb * 4, st));
         // decoder                                                                    fd:711-725
-        SAPCU_TRY(gemm(ENC, cb, emb, emb, m->p(FD_FCIN_W), 256, m->p(FD_FCIN_B), D1, 256, EPI_GELU, st));
-        SAPCU_TRY(gemm(D1, cb, 256, 256, m->p(FD_R0_FC0_W), 128, m->p(FD_R0_FC0_B), D2a, 128, EPI_GELU, st));
-        SAPCU_TRY(gemm(D1, cb, 256, 256, m->p(FD_R0_PROJ_W), 128, m->p(FD_R0_PROJ_B), D2b, 128, EPI_BIAS, st));
-        SAPCU_TRY(gemm(D2a, cb, 128, 128, m->p(FD_R0_FC4_W), 128, m->p(FD_R0_FC4_B), D2c, 128, EPI_RESID_GELU, st,
+        SAPCU_TRY(gemm(m, ENC, cb, emb, emb, m->p(FD_FCIN_W), 256, m->p(FD_FCIN_B), D1, 256, EPI_GELU, st));
+        SAPCU_TRY(gemm(m, D1, cb, 256, 256, m->p(FD_R0_FC0_W), 128, m->p(FD_R0_FC0_B), D2a, 128, EPI_GELU, st));
+        SAPCU_TRY(gemm(m, D1, cb, 256, 256, m->p(FD_R0_PROJ_W), 128, m->p(FD_R0_PROJ_B), D2b, 128, EPI_BIAS, st));
+        SAPCU_TRY(gemm(m, D2a, cb, 128, 128, m->p(FD_R0_FC4_W), 128, m->p(FD_R0_FC4_B), D2c, 128, EPI_RESID_GELU, st,
                        nullptr, 0, D2b, 128));
-        SAPCU_TRY(gemm(D2c, cb, 128, 128, m->p(FD_R1_FC0_W), 64, m->p(FD_R1_FC0_B), D3a, 64, EPI_GELU, st));
-        SAPCU_TRY(gemm(D2c, cb, 128, 128, m->p(FD_R1_PROJ_W), 64, m->p(FD_R1_PROJ_B), D3b, 64, EPI_BIAS, st));
-        SAPCU_TRY(gemm(D3a, cb, 64, 64, m->p(FD_R1_FC4_W), 64, m->p(FD_R1_FC4_B), D3c, 64, EPI_RESID_GELU, st, nullptr,
+        SAPCU_TRY(gemm(m, D2c, cb, 128, 128, m->p(FD_R1_FC0_W), 64, m->p(FD_R1_FC0_B), D3a, 64, EPI_GELU, st));
+        SAPCU_TRY(gemm(m, D2c, cb, 128, 128, m->p(FD_R1_PROJ_W), 64, m->p(FD_R1_PROJ_B), D3b, 64, EPI_BIAS, st));
+        SAPCU_TRY(gemm(m, D3a, cb, 64, 64, m->p(FD_R1_FC4_W), 64, m->p(FD_R1_FC4_B), D3c, 64, EPI_RESID_GELU, st, nullptr,
                        0, D3b, 64));
-        SAPCU_TRY(gemm(D3c, cb, 64, 64, m->p(FD_QKV_W), 192, m->p(FD_QKV_B), QKV, 192, EPI_BIAS, st));
+        SAPCU_TRY(gemm(m, D3c, cb, 64, 64, m->p(FD_QKV_W), 192, m->p(FD_QKV_B), QKV, 192, EPI_BIAS, st));
         SAPCU_TRY(launch_fd_tail(D3c, QKV, cb, m->heads, m->p(FD_WO_T), m->p(FD_BO), m->p(FD_LN_W), m->p(FD_LN_B),
                                  m->p(FD_WH_T), m->p(FD_BH), m->p(FD_WD), m->p(FD_BD), ATT, dist + s, st));
     }
@@ -461,16 +478,35 @@ int sapcu_l2_normalize3(const float* in, float* out, int64_t b, void* stream) {
     return launch_l2_normalize3(in, out, b, (hipStream_t)stream);
 }
 
+static int split_into_ws(const float* w, int64_t cnt, void* w16_ws, GemmArgs& g, hipStream_t st) {
+    char* base = (char*)w16_ws;            // hi (2*cnt B) | lo (2*cnt B) | overflow counter
+    int* ovf = (int*)(base + 4 * cnt);
+    SAPCU_CHECK_HIP(hipMemsetAsync(ovf, 0, sizeof(int), st));
+    SAPCU_TRY(launch_split_weights(w, cnt, base, base + 2 * cnt, ovf, st));
+    g.w16_hi = (const _Float16*)base;
+    g.w16_lo = (const _Float16*)(base + 2 * cnt);
+    g.ovf = ovf;
+    return SAPCU_OK;
+}
+
 int sapcu_gemm_f32(const float* a, int64_t r, int k, int lda, const float* w, int n, const float* bias,
-                   const float* lif4, int lif_steps, float* c, int ldc, void* stream) {
+                   const float* lif4, int lif_steps, float* c, int ldc, void* w16_ws, void* stream) {
     SAPCU_CHECK_ARG(a && w && c && r >= 0 && n >= 1, "gemm: bad argument");
     SAPCU_CHECK_ARG(!lif4 || lif_steps >= 1, "gemm: lif_steps must be >= 1");
-    return gemm(a, r, k, lda, w, n, bias, c, ldc, lif4 ? EPI_LIF : EPI_BIAS, (hipStream_t)stream, lif4, lif_steps);
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a = a; g.r = r; g.k = k; g.lda = lda; g.w = w; g.n = n; g.bias = bias; g.c = c; g.ldc = ldc;
+    g.epi = lif4 ? EPI_LIF : EPI_BIAS; g.lif = lif4; g.lif_T = lif_steps;
+    if (w16_ws) {
+        SAPCU_TRY(split_into_ws(w, (int64_t)n * k, w16_ws, g, (hipStream_t)stream));
+        return launch_gemm_sf16(g, (hipStream_t)stream);
+    }
+    return launch_gemm(g, (hipStream_t)stream);
 }
 
 int sapcu_posenc_gemm_f32(const float* pe1, int64_t r, int d, const float* w, const float* bias, const float* lif4,
                           int lif_steps, const float* qkv, const int32_t* idx, int kk, int m_pts, float* pe_out,
-                          float* attn_in_out, void* edge_table_ws, void* stream) {
+                          float* attn_in_out, void* edge_table_ws, void* w16_ws, void* stream) {
     SAPCU_CHECK_ARG(pe1 && w && lif4 && qkv && idx && pe_out && attn_in_out && edge_table_ws && r >= 0 && d >= 32 &&
                         lif_steps >= 1 && kk >= 1 && m_pts >= 1,
                     "posenc_gemm: bad argument");
@@ -480,6 +516,10 @@ int sapcu_posenc_gemm_f32(const float* pe1, int64_t r, int d, const float* w, co
     g.epi = EPI_LIF_ATTN; g.lif = lif4; g.lif_T = lif_steps; g.c2 = attn_in_out;
     g.q = qkv; g.kf = qkv + d; g.ldq = 3 * d; g.tab = (const int2*)edge_table_ws;
     SAPCU_TRY(launch_edge_table(idx, r, m_pts, kk, (int2*)edge_table_ws, (hipStream_t)stream));
+    if (w16_ws) {   // split-f16 path: split W into the caller's scratch (hi | lo | counter), then 3 x f16 MFMA
+        SAPCU_TRY(split_into_ws(w, (int64_t)d * d, w16_ws, g, (hipStream_t)stream));
+        return launch_gemm_sf16(g, (hipStream_t)stream);
+    }
     return launch_gemm(g, (hipStream_t)stream);
 }
 
@@ -492,6 +532,11 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
     m->ks_dev = nullptr;
     m->gate_dev = nullptr;
     m->blob = nullptr;
+    m->w16_hi = nullptr;
+    m->w16_lo = nullptr;
+    m->ovf_dev = nullptr;
+    const char* ge = getenv("SAPCU_GEMM");
+    m->sf16 = !(ge && strcmp(ge, "f32") == 0);
     const char* ce = getenv("SAPCU_CHUNK");
     m->chunk = ce ? atoll(ce) : 512;
     if (m->chunk < 1) m->chunk = 1;
@@ -544,6 +589,19 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
         m->blob_floats = blob_floats;
         hip_ok(hipMalloc((void**)&m->blob, (size_t)blob_floats * 4), "hipMalloc(blob)");
         if (rc == SAPCU_OK) hip_ok(hipMemcpy(m->blob, blob, (size_t)blob_floats * 4, hipMemcpyDeviceToDevice), "copy blob");
+        if (rc == SAPCU_OK) hip_ok(hipMalloc((void**)&m->ovf_dev, 2 * sizeof(int)), "hipMalloc(ovf)");
+        if (rc == SAPCU_OK) hip_ok(hipMemset(m->ovf_dev, 0, 2 * sizeof(int)), "memset ovf");
+        if (rc == SAPCU_OK && m->sf16) {
+            hip_ok(hipMalloc(&m->w16_hi, (size_t)blob_floats * 2), "hipMalloc(w16_hi)");
+            if (rc == SAPCU_OK) hip_ok(hipMalloc(&m->w16_lo, (size_t)blob_floats * 2), "hipMalloc(w16_lo)");
+            if (rc == SAPCU_OK) {
+                int wovf = 0;
+                if (launch_split_weights(m->blob, blob_floats, m->w16_hi, m->w16_lo, m->ovf_dev + 1, nullptr) != SAPCU_OK)
+                    rc = SAPCU_ERR_HIP;
+                if (rc == SAPCU_OK) hip_ok(hipMemcpy(&wovf, m->ovf_dev + 1, sizeof(int), hipMemcpyDeviceToHost), "read ovf");
+                if (rc == SAPCU_OK && wovf != 0) m->sf16 = false;   // a parameter exceeds the f16 range: exact-f32 kernels
+            }
+        }
         if (rc == SAPCU_OK && kind == SAPCU_KIND_FD) {
             hip_ok(hipMalloc((void**)&m->ks_dev, 8 * sizeof(int32_t)), "hipMalloc(ks)");
             if (rc == SAPCU_OK) hip_ok(hipMemcpy(m->ks_dev, m->ks, 8 * sizeof(int32_t), hipMemcpyHostToDevice), "copy ks");
@@ -552,6 +610,9 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
         }
     }
     if (rc != SAPCU_OK) {
+        if (m->w16_hi) (void)hipFree(m->w16_hi);
+        if (m->w16_lo) (void)hipFree(m->w16_lo);
+        if (m->ovf_dev) (void)hipFree(m->ovf_dev);
         if (m->blob) (void)hipFree(m->blob);
         if (m->ks_dev) (void)hipFree(m->ks_dev);
         if (m->gate_dev) (void)hipFree(m->gate_dev);
@@ -564,6 +625,9 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
 
 int sapcu_model_destroy(sapcu_model_t m) {
     if (!m) return SAPCU_OK;
+    if (m->w16_hi) (void)hipFree(m->w16_hi);
+    if (m->w16_lo) (void)hipFree(m->w16_lo);
+    if (m->ovf_dev) (void)hipFree(m->ovf_dev);
     if (m->blob) (void)hipFree(m->blob);
     if (m->ks_dev) (void)hipFree(m->ks_dev);
     if (m->gate_dev) (void)hipFree(m->gate_dev);
@@ -583,6 +647,14 @@ int sapcu_model_gate_violations(sapcu_model_t m, int* count_host) {
     SAPCU_CHECK_ARG(m && count_host, "gate_violations: null pointer");
     *count_host = 0;
     if (m->gate_dev) SAPCU_CHECK_HIP(hipMemcpy(count_host, m->gate_dev, sizeof(int), hipMemcpyDeviceToHost));
+    return SAPCU_OK;
+}
+
+int sapcu_model_gemm_mode(sapcu_model_t m, int* split_f16_host, int* range_overflows_host) {
+    SAPCU_CHECK_ARG(m && split_f16_host && range_overflows_host, "gemm_mode: null pointer");
+    *split_f16_host = m->sf16 ? 1 : 0;
+    *range_overflows_host = 0;
+    if (m->ovf_dev) SAPCU_CHECK_HIP(hipMemcpy(range_overflows_host, m->ovf_dev, sizeof(int), hipMemcpyDeviceToHost));
     return SAPCU_OK;
 }
 

@@ -111,6 +111,13 @@ class _HipModel(nn.Module):
             self._ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
         return self._ws
 
+    def gemm_mode(self):
+        """(split_f16, range_overflows): which GEMM kernels the handle uses and how many activation tiles left
+        the f16 range so far (must be 0; sapcu.h sapcu_model_gemm_mode)."""
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(_lib.load().sapcu_model_gemm_mode(self._engine(), ctypes.byref(a), ctypes.byref(b)))
+        return bool(a.value), b.value
+
     @staticmethod
     def _taps_array(names, taps):
         if not taps:

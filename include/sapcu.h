@@ -145,24 +145,35 @@ int sapcu_fd_forward(sapcu_model_t m, const float* patch, int64_t b, int m_pts,
  * dead EdgeConv stages; a non-zero count means an output may deviate.  Synchronises the device. */
 int sapcu_model_gate_violations(sapcu_model_t m, int* count_host);
 
+/* Which GEMM kernels the handle uses (1 = split-f16: every f32 operand as hi + lo*2^-11 halves, three f16
+ * MFMAs per product, f32-quality results at 5.3x the f32-MFMA rate; 0 = exact-f32 MFMA, selected by the
+ * environment variable SAPCU_GEMM=f32 or automatically when a parameter exceeds the f16 range), and how
+ * many activation tiles exceeded the f16 range in forwards so far (must be 0).  Synchronises the device. */
+int sapcu_model_gemm_mode(sapcu_model_t m, int* split_f16_host, int* range_overflows_host);
+
 /* out = in / max(||in||_2, 1e-12) row-wise for [b,3] — the extra F.normalize of generation.py:139. */
 int sapcu_l2_normalize3(const float* in, float* out, int64_t b, void* stream);
 
-/* The library's MFMA GEMM, exposed for tests and roofline runs:
+/* The library's MFMA GEMMs, exposed for tests and roofline runs:
  *   C[r,n] = epi( A[r,k] * W[n,k]^T + bias[n] ),  k % 32 == 0, A/W 16-byte aligned, lda % 4 == 0.
  * lif4 == NULL: epi = identity.  Otherwise lif4 = raw neuron parameters [4][n] and the epilogue is
- * the lif_steps-step self-feeding LIF loop (the fused form of conv+BN -> snn loop, fn:317-320). */
+ * the lif_steps-step self-feeding LIF loop (the fused form of conv+BN -> snn loop, fn:317-320).
+ * w16_ws == NULL: exact-f32 MFMA kernel.  Otherwise 4*n*k + 16 bytes of scratch: W is split into f16
+ * hi/lo halves there and the split-f16 kernel runs (3 x f16 MFMA per product; last 4 bytes of the
+ * scratch = count of activation tiles beyond the f16 range). */
 int sapcu_gemm_f32(const float* a, int64_t r, int k, int lda, const float* w, int n, const float* bias,
-                   const float* lif4, int lif_steps, float* c, int ldc, void* stream);
+                   const float* lif4, int lif_steps, float* c, int ldc, void* w16_ws, void* stream);
 
 /* The positional-encoding GEMM of one fn block — the heaviest single launch shape of the path:
  *   pe[row,:]      = LIF_x4( W . pe1[row,:] + bias )                         (fn/snn_coder.py:360-363)
  *   attn_in[row,:] = q[pt(row),:] - k[nbr(row),:] + pe[row,:]                (fn/snn_coder.py:367-368)
  * pe1 [r,d]; qkv [b*m, 3d] (q | k | v); idx [r] = flattened [b,m,kk] in-patch neighbours; w [d,d];
- * edge_table_ws: 8*r bytes of scratch (row -> (q row, k row) table, rebuilt by every call). */
+ * edge_table_ws: 8*r bytes of scratch (row -> (q row, k row) table, rebuilt by every call).
+ * w16_ws: NULL -> exact-f32 MFMA kernel; else 4*d*d + 16 bytes of scratch -> split-f16 (3 x f16 MFMA) kernel. */
 int sapcu_posenc_gemm_f32(const float* pe1, int64_t r, int d, const float* w, const float* bias,
                           const float* lif4, int lif_steps, const float* qkv, const int32_t* idx, int kk,
-                          int m_pts, float* pe_out, float* attn_in_out, void* edge_table_ws, void* stream);
+                          int m_pts, float* pe_out, float* attn_in_out, void* edge_table_ws, void* w16_ws,
+                          void* stream);
 
 #ifdef __cplusplus
 }

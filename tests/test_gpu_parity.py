@@ -153,17 +153,55 @@ def test_patch_knn_xyz_exact_and_feature_space_flips():
 
 
 # ------------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("r,k,n", [(1, 32, 1), (130, 64, 3), (257, 192, 640), (1000, 960, 768), (4096, 512, 512)])
-def test_gemm_f32_against_float64(r, k, n):
+def _run_gemm(a, w, bias, split):
     from sapcu_amd import _lib
-    rng = np.random.default_rng(r + k + n)
-    a, w, bias = rng.normal(size=(r, k)).astype(np.float32), rng.normal(size=(n, k)).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    r, k = a.shape
+    n = w.shape[0]
     A, W, Bv = _dev(a), _dev(w), _dev(bias)
     C = torch.full((r, n), float("nan"), device=U.dev())
-    _lib.check(_lib.load().sapcu_gemm_f32(_lib.ptr(A), r, k, k, _lib.ptr(W), n, _lib.ptr(Bv), None, 0, _lib.ptr(C), n, _lib.current_stream()))
+    ws = torch.zeros(4 * n * k + 16, dtype=torch.uint8, device=U.dev()) if split else None
+    _lib.check(_lib.load().sapcu_gemm_f32(_lib.ptr(A), r, k, k, _lib.ptr(W), n, _lib.ptr(Bv), None, 0, _lib.ptr(C), n,
+                                          _lib.ptr(ws), _lib.current_stream()))
+    torch.cuda.synchronize()
+    ovf = int(ws[-16:].view(torch.int32)[0].item()) if split else 0
+    return C.cpu().numpy(), ovf
+
+
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("r,k,n", [(1, 32, 1), (130, 64, 3), (257, 192, 640), (1000, 960, 768), (4096, 512, 512)])
+def test_gemm_against_float64(r, k, n, split):
+    rng = np.random.default_rng(r + k + n)
+    a, w, bias = rng.normal(size=(r, k)).astype(np.float32), rng.normal(size=(n, k)).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    c, ovf = _run_gemm(a, w, bias, split)
     ref = a.astype(np.float64) @ w.astype(np.float64).T + bias
-    err = np.abs(C.cpu().numpy() - ref).max()
-    assert err <= 2e-6 * np.sqrt(k) * 4, err
+    err = np.abs(c - ref).max()
+    assert ovf == 0 and err <= 2e-6 * np.sqrt(k) * 4, err
+
+
+def test_split_f16_gemm_error_bound_on_mixed_magnitudes():
+    """Spikes down to 1e-6, weights spanning 1e-4..10, activations up to 2e4.  Bound: f32-level relative error
+    on sum|a||w| plus the f16 subnormal quantum (2^-25 per activation below 0.25, 2^-29 per weight below
+    2^-6) — an ABSOLUTE term that is negligible against O(1) pre-activations."""
+    rng = np.random.default_rng(5)
+    k, n, r = 512, 256, 1024
+    a = (rng.random((r, k)) * np.power(10.0, rng.uniform(-6, 0, (r, 1)))).astype(np.float32)
+    a[:8] *= 2e4
+    w = (rng.normal(size=(n, k)) * np.power(10.0, rng.uniform(-4, 1, (n, 1)))).astype(np.float32)
+    bias = np.zeros(n, np.float32)
+    A64, W64 = np.abs(a).astype(np.float64), np.abs(w).astype(np.float64)
+    ref = a.astype(np.float64) @ w.astype(np.float64).T
+    bound = 4e-7 * (A64 @ W64.T) + 2.0 ** -25 * W64.sum(1)[None, :] + 2.0 ** -29 * A64.sum(1)[:, None]
+    c32, _ = _run_gemm(a, w, bias, False)
+    c16, ovf = _run_gemm(a, w, bias, True)
+    r32, r16 = np.abs(c32 - ref) / bound, np.abs(c16 - ref) / bound
+    print("error / bound: f32 MFMA max %.2f, split-f16 max %.2f" % (r32.max(), r16.max()))
+    assert ovf == 0 and r16.max() <= 1.0
+    big = np.abs(a).max(1) > 0.25                                              # rows without subnormal low halves
+    rel = (np.abs(c16 - ref) / (A64 @ W64.T))[big]
+    assert rel.max() <= 4e-7
+    a[0, 0] = 7e4                                                             # beyond f16: must be reported
+    _, ovf = _run_gemm(a, w, bias, True)
+    assert ovf >= 1
 
 
 # ------------------------------------------------------------------------------- fn
@@ -268,6 +306,24 @@ def test_fd_forward_256_patches_forced_neighbour_protocol(models):
     assert (d_gpu - d_free).abs()[~flip_patches].max() <= TOL
     assert int(flip_patches.sum()) <= 256 // 10
     assert d_free.std() > 1e-2
+
+
+def test_gemm_modes_agree_and_stay_in_range(weights, monkeypatch):
+    """The default split-f16 GEMMs against the exact-f32 MFMA kernels (SAPCU_GEMM=f32) on the same patches."""
+    fn16, fd16, sdn, sdd = U.build_gpu_models(weights)
+    fn16._engine(), fd16._engine()                      # handles are built lazily: build them before the switch
+    monkeypatch.setenv("SAPCU_GEMM", "f32")
+    fn32, fd32, _, _ = U.build_gpu_models(weights)
+    fn16.knn_cache_mode = fn32.knn_cache_mode = "fresh"
+    patch = U.sphere_patches(32, 48, skip=700).to(U.dev())
+    n16, n32 = fn16(patch), fn32(patch)
+    assert fn32.gemm_mode() == (False, 0) and fn16.gemm_mode() == (True, 0)
+    assert (n16 - n32).abs().max() <= TOL
+    knn = torch.empty((3, 32, 48, 32), dtype=torch.int32, device=U.dev())
+    d32 = fd32(patch, taps={"knn": knn})
+    d16 = fd16(patch, knn_force=knn)
+    assert fd16.gemm_mode() == (True, 0)
+    assert (d16 - d32).abs().max() <= TOL
 
 
 def test_fd_forced_tables_are_honoured(models):
