@@ -18,21 +18,33 @@
 // and the neuron epilogue is the long pole): ONE 1024-thread workgroup per CU, persistent over 128x128
 // tiles; waves 0-7 are MFMA PRODUCERS (4x2, each a 32x64 sub-tile = 2 MFMA tiles, 32 accumulator
 // registers), waves 8-15 are EPILOGUE CONSUMERS — two VALU waves per SIMD, which is what it takes to
-// fill the vector pipe (one wave alone issues at half rate).  Producers convert the f32 A rows to
-// hi/lo while staging them into LDS; W is pre-split at model build.  LDS: 2 x 40 KiB operand stages +
-// 64 KiB accumulator hand-off = 144 KiB.  128 VGPRs per wave (4 waves per SIMD).
+// fill the vector pipe (one wave alone issues at half rate).
+//   * k-step = 64: 12 f16 MFMAs x 4 k16 per producer wave = 1536 matrix-pipe cycles per SIMD between
+//     barriers — long enough to cover the operand fetch of the next step and one 4-element neuron group
+//     of each consumer wave (K = 512: 8 k-steps, 8 groups: balanced);
+//   * W (pre-split f16 hi/lo planes) goes global -> LDS by LDS-DMA (global_load_lds_dwordx4, no
+//     registers, no VALU); A rows are f32 in memory: staged through registers and split to hi/lo on the
+//     way (1-step-ahead prefetch);
+//   * operand tiles are [row][64 halves] = 128-byte rows with the 16-byte chunk index XOR-swizzled by
+//     (row>>1)&7: conflict-free ds_read_b128 fragments without padding, which LDS-DMA requires
+//     (its destination is lane-linear; the swizzle is applied to the per-lane SOURCE address);
+//   * LDS: 2 stages x 64 KiB operands + 32 KiB.  The accumulator hand-off is 64 KiB: the half for column
+//     tile 0 lives in the spare 32 KiB, the half for column tile 1 ALIASES stage 1 — consumers copy those
+//     16 values to registers right after the hand-off barrier, before stage 1 is refilled at k-step 0.
 #include "common.h"
 #include "gemm_epi.h"
 
 namespace sapcu {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+typedef const __attribute__((address_space(1))) void* gptr_t;
 
-constexpr int SBM = 128, SBN = 128, SBK = 32;
-constexpr int LDH = SBK + 8;                         // halves per LDS row (80 B: conflict-free ds_read_b128)
-constexpr int OPER_HALVES = 4 * SBM * LDH;           // A_hi | A_lo | W_hi | W_lo of one stage
-constexpr int SF16_STAGE_FLOATS = 8 * 32 * 64;       // 8 producer waves x 32 results x 64 lanes
-constexpr int SF16_LDS_BYTES = 2 * OPER_HALVES * 2 + SF16_STAGE_FLOATS * 4;
+constexpr int SBM = 128, SBN = 128, SBK = 64;
+constexpr int PLANE_BYTES = SBM * SBK * 2;           // one [128][64] f16 plane = 16 KiB
+constexpr int STAGE_BYTES = 4 * PLANE_BYTES;         // A_hi | A_lo | W_hi | W_lo = 64 KiB
+constexpr int HALF_HANDOFF_BYTES = 8 * 16 * 64 * 4;   // 8 producer waves x 16 results x 64 lanes = 32 KiB
+constexpr int SF16_LDS_BYTES = 2 * STAGE_BYTES + HALF_HANDOFF_BYTES;   // column-tile-1 half of the hand-off aliases stage 1
 
 __device__ __forceinline__ void split8(const float4& x0, const float4& x1, half8& hi, half8& lo, float& amax) {
     const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
@@ -45,11 +57,20 @@ __device__ __forceinline__ void split8(const float4& x0, const float4& x1, half8
     }
 }
 
+// consumer: one 4-element group of column tile 1 with STATIC register indices (Q = group - 4)
+template <int EPI, int Q>
+__device__ __forceinline__ void consume_reg_group(const GemmArgs& g, const float (&cacc)[16], int64_t row, int col,
+                                                  float bias, const NeuronP& np, const float (&cq)[4],
+                                                  const float (&ckf)[4]) {
+    const float a[4] = {cacc[Q * 4], cacc[Q * 4 + 1], cacc[Q * 4 + 2], cacc[Q * 4 + 3]};
+    epilogue_group4<EPI>(g, a, row, col, bias, np, cq, ckf);
+}
+
 template <int EPI>
 __global__ __launch_bounds__(1024) void gemm_sf16_kernel(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    _Float16* oper = reinterpret_cast<_Float16*>(smem_raw);
-    float* stage = reinterpret_cast<float*>(smem_raw + 2 * OPER_HALVES * 2);
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    float* stage1 = reinterpret_cast<float*>(smem_raw + STAGE_BYTES);        // hand-off, column tile 1: aliases stage 1
+    float* stage0 = reinterpret_cast<float*>(smem_raw + 2 * STAGE_BYTES);    // hand-off, column tile 0: spare 32 KiB
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const bool producer = wave < 8;
@@ -69,15 +90,31 @@ __global__ __launch_bounds__(1024) void gemm_sf16_kernel(const GemmArgs g) {
     const int64_t x_count = qd + (xcd < rem ? 1 : 0);
     const int nk = g.k / SBK;
 
-    // The two roles are separate loops (separate register allocations: the producers' accumulators and
-    // the consumers' neuron state never coexist) that execute the SAME sequence of workgroup barriers:
-    // per tile 1 (operands of k-step 0 staged) + nk (one per k-step) + 1 (accumulators handed off).
+    // The two roles are separate loops (separate register allocations) that execute the SAME sequence of
+    // workgroup barriers: per tile 1 (hand-off copied out / k-step 0 staged) + nk (k-steps) + 1 (hand-off).
     if (producer) {
-        // thread t (0..511) owns row t>>2, k-octet (t&3)*8 of the A and W tiles
+        // A: thread t (0..511) owns row t>>2 and 16-byte chunks 2*(t&3), 2*(t&3)+1 of both A planes
         const int srow = tid >> 2;
-        const int skc = (tid & 3) * 8;
-        float4 ra0, ra1;
-        half8 rwh, rwl;
+        const int sc0 = (tid & 3) * 2;
+        const int ssw = (srow >> 1) & 7;
+        // W: wave w issues LDS-DMA pieces (w*2 + i), i = 0,1, of each W plane; lane -> chunk p = piece*64 + lane
+        int wrow_[2], wsrc_[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = (pw * 2 + i) * 64 + lane;
+            wrow_[i] = p >> 3;
+            wsrc_[i] = ((p & 7) ^ ((wrow_[i] >> 1) & 7)) * 8;      // source k offset (halves) of this LDS chunk
+        }
+        // fragment rows / swizzles
+        const int arow_l = wm * 32 + r32;
+        const int asw = (arow_l >> 1) & 7;
+        int wrow_l[2], wsw[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            wrow_l[j] = wn * 64 + j * 32 + r32;
+            wsw[j] = (wrow_l[j] >> 1) & 7;
+        }
+        float4 ra[4];
         f32x16 acc[2];
         bool prev = false;
         for (int64_t it = 0;; ++it) {
@@ -87,78 +124,91 @@ __global__ __launch_bounds__(1024) void gemm_sf16_kernel(const GemmArgs g) {
             const int64_t logical = x_begin + local;
             const int64_t row0 = have ? (logical / ntn) * SBM : 0;
             const int col0 = have ? (int)(logical % ntn) * SBN : 0;
-            const int64_t row = row0 + srow;
-            const bool aok = have && row < g.r;
-            const float* arow = g.a + (aok ? row : 0) * g.lda + skc;
-            const int nn = col0 + srow;
-            const bool wok = have && nn < g.n;
-            const _Float16* whrow = g.w16_hi + (int64_t)(wok ? nn : 0) * g.k + skc;
-            const _Float16* wlrow = g.w16_lo + (int64_t)(wok ? nn : 0) * g.k + skc;
+            int64_t arow_g = row0 + srow;
+            if (arow_g >= g.r) arow_g = g.r - 1;                  // clamped rows only feed masked outputs
+            const float* aptr = g.a + arow_g * g.lda + sc0 * 8;
+            int woff[2];   // element offset of this lane's source chunk inside both W planes (n*k < 2^31)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int nn = col0 + wrow_[i];
+                if (nn >= g.n) nn = g.n - 1;
+                woff[i] = nn * g.k + wsrc_[i];
+            }
             float amax = 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-            auto load_tile = [&](int k0) {
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                ra0 = aok ? ld4(arow + k0) : z;
-                ra1 = aok ? ld4(arow + k0 + 4) : z;
-                if (wok) {
-                    rwh = *reinterpret_cast<const half8*>(whrow + k0);
-                    rwl = *reinterpret_cast<const half8*>(wlrow + k0);
-                } else {
+            auto load_a = [&](int k0) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        rwh[i] = (_Float16)0.f;
-                        rwl[i] = (_Float16)0.f;
-                    }
+                for (int i = 0; i < 4; ++i) ra[i] = ld4(aptr + k0 + 4 * i);
+            };
+            auto dma_w = [&](int buf, int k0) {
+                lds_byte* sbase = (lds_byte*)(smem_raw + buf * STAGE_BYTES + 2 * PLANE_BYTES);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    lds_byte* dst = sbase + (pw * 2 + i) * 1024;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(g.w16_hi + woff[i] + k0), dst, 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(g.w16_lo + woff[i] + k0), dst + PLANE_BYTES, 16, 0, 0);
                 }
             };
-            auto store_tile = [&](int buf) {
-                _Float16* base = oper + buf * OPER_HALVES + srow * LDH + skc;
-                half8 ah, al;
-                split8(ra0, ra1, ah, al, amax);
-                *reinterpret_cast<half8*>(base) = ah;
-                *reinterpret_cast<half8*>(base + SBM * LDH) = al;
-                *reinterpret_cast<half8*>(base + 2 * SBM * LDH) = rwh;
-                *reinterpret_cast<half8*>(base + 3 * SBM * LDH) = rwl;
+            auto store_a = [&](int buf) {
+                unsigned char* base = smem_raw + buf * STAGE_BYTES + srow * (SBK * 2);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    half8 ah, al;
+                    split8(ra[2 * c], ra[2 * c + 1], ah, al, amax);
+                    const int phys = ((sc0 + c) ^ ssw) * 16;
+                    *reinterpret_cast<half8*>(base + phys) = ah;
+                    *reinterpret_cast<half8*>(base + PLANE_BYTES + phys) = al;
+                }
             };
             if (have) {
-                load_tile(0);
-                store_tile(0);
+                dma_w(0, 0);
+                load_a(0);
+                store_a(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             lds_barrier();
             int cur = 0;
             for (int kt = 0; kt < nk; ++kt) {
                 if (have) {
-                    if (kt + 1 < nk) load_tile((kt + 1) * SBK);
-                    const _Float16* sA = oper + cur * OPER_HALVES + (wm * 32 + r32) * LDH + h * 8;
-                    const _Float16* sW = oper + cur * OPER_HALVES + 2 * SBM * LDH + (wn * 64 + r32) * LDH + h * 8;
+                    if (kt + 1 < nk) {
+                        dma_w(cur ^ 1, (kt + 1) * SBK);
+                        load_a((kt + 1) * SBK);
+                    }
+                    const unsigned char* st = smem_raw + cur * STAGE_BYTES;
+                    const unsigned char* sA = st + arow_l * (SBK * 2);
 #pragma unroll
                     for (int k16 = 0; k16 < SBK / 16; ++k16) {
-                        const half8 ah = *reinterpret_cast<const half8*>(sA + k16 * 16);
-                        const half8 al = *reinterpret_cast<const half8*>(sA + SBM * LDH + k16 * 16);
+                        const int ca = ((k16 * 2 + h) ^ asw) * 16;
+                        const half8 ah = *reinterpret_cast<const half8*>(sA + ca);
+                        const half8 al = *reinterpret_cast<const half8*>(sA + PLANE_BYTES + ca);
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            const half8 wh = *reinterpret_cast<const half8*>(sW + j * 32 * LDH + k16 * 16);
-                            const half8 wl = *reinterpret_cast<const half8*>(sW + SBM * LDH + j * 32 * LDH + k16 * 16);
+                            const unsigned char* sW = st + 2 * PLANE_BYTES + wrow_l[j] * (SBK * 2) + (((k16 * 2 + h) ^ wsw[j]) * 16);
+                            const half8 wh = *reinterpret_cast<const half8*>(sW);
+                            const half8 wl = *reinterpret_cast<const half8*>(sW + PLANE_BYTES);
                             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, acc[j], 0, 0, 0);
                             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, acc[j], 0, 0, 0);
                             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc[j], 0, 0, 0);
                         }
                     }
-                    if (kt + 1 < nk) store_tile(cur ^ 1);
+                    if (kt + 1 < nk) {
+                        store_a(cur ^ 1);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA pieces of the next stage have landed
+                    }
                 }
                 lds_barrier();
                 cur ^= 1;
             }
-            // hand-off: the consumers drained the staging area before the last k-step barrier
+            // hand-off (into stage 1's bytes: every operand read of this tile is behind the last barrier)
             if (have) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        stage[(pw * 32 + j * 16 + e) * 64 + lane] = __fmul_rn(acc[j][e], 0.0625f);   // undo W x 16
+                for (int e = 0; e < 16; ++e) {
+                    stage0[(pw * 16 + e) * 64 + lane] = __fmul_rn(acc[0][e], 0.0625f);   // undo W x 16
+                    stage1[(pw * 16 + e) * 64 + lane] = __fmul_rn(acc[1][e], 0.0625f);
+                }
                 if (amax > 65504.0f && g.ovf) atomicAdd(g.ovf, 1);
             }
             lds_barrier();
@@ -173,8 +223,11 @@ __global__ __launch_bounds__(1024) void gemm_sf16_kernel(const GemmArgs g) {
             const bool have = local < x_count;
             if (!have && prev_row0 < 0) break;
             const int64_t logical = x_begin + local;
-            // ---- state for the previous tile (32 results per lane = 8 groups of 4)
             const bool cons_work = prev_row0 >= 0;
+            // ---- copy the column-tile-1 half out of the hand-off area that aliases stage 1 (refilled at k-step 0)
+            float cacc[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) cacc[q] = cons_work ? stage1[(pw * 16 + q) * 64 + lane] : 0.f;
             float cbias[2];
             NeuronP cnp[2];
             bool ccol[2];
@@ -183,6 +236,7 @@ __global__ __launch_bounds__(1024) void gemm_sf16_kernel(const GemmArgs g) {
                 const int col = prev_col0 + wn * 64 + j * 32 + r32;
                 ccol[j] = cons_work && col < g.n;
                 cbias[j] = settle((ccol[j] && g.bias) ? g.bias[col] : 0.f);
+                cnp[j] = NeuronP{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) {
                     cnp[j] = load_lif(g.lif, g.n, ccol[j] ? col : 0);
                     cnp[j].theta0 = settle(cnp[j].theta0);
@@ -218,7 +272,6 @@ __global__ __launch_bounds__(1024) void gemm_sf16_kernel(const GemmArgs g) {
             for (int kt = 0; kt < nk; ++kt) {
                 if (cons_work) {
                     for (int gi = kt * gper; gi < (kt + 1) * gper && gi < 8; ++gi) {
-                        const int j = gi >> 2, e4 = gi & 3;
                         float cq[4], ckf[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
@@ -226,21 +279,24 @@ __global__ __launch_bounds__(1024) void gemm_sf16_kernel(const GemmArgs g) {
                             ckf[u] = nkf[u];
                         }
                         if (gi + 1 < 8) issue_gather(gi + 1);
+                        const int j = gi >> 2, e4 = gi & 3;
                         if (!(j ? ccol[1] : ccol[0])) continue;
                         const int64_t row = prev_row0 + wm * 32 + 8 * e4 + 4 * h;
                         if (row >= g.r) continue;
-                        float a[4];
+                        const int col = prev_col0 + wn * 64 + j * 32 + r32;
+                        if (gi < 4) {       // column tile 0: straight from the non-aliased half of the hand-off
+                            float a[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) a[u] = stage[(pw * 32 + gi * 4 + u) * 64 + lane];
-                        NeuronP np;   // select, don't index: runtime-indexed register arrays would go to scratch
-                        np.decay = j ? cnp[1].decay : cnp[0].decay;
-                        np.adapt = j ? cnp[1].adapt : cnp[0].adapt;
-                        np.rdecay = j ? cnp[1].rdecay : cnp[0].rdecay;
-                        np.theta0 = j ? cnp[1].theta0 : cnp[0].theta0;
-                        np.dT = 0.f;
-                        np.rh = 0.f;
-                        epilogue_group4<EPI>(g, a, row, prev_col0 + wn * 64 + j * 32 + r32, j ? cbias[1] : cbias[0], np, cq,
-                                             ckf);
+                            for (int u = 0; u < 4; ++u) a[u] = stage0[(pw * 16 + gi * 4 + u) * 64 + lane];
+                            epilogue_group4<EPI>(g, a, row, col, cbias[0], cnp[0], cq, ckf);
+                        } else {            // column tile 1: from registers, static indices per group
+                            switch (gi) {
+                                case 4: consume_reg_group<EPI, 0>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
+                                case 5: consume_reg_group<EPI, 1>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
+                                case 6: consume_reg_group<EPI, 2>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
+                                default: consume_reg_group<EPI, 3>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
+                            }
+                        }
                     }
                 }
                 lds_barrier();

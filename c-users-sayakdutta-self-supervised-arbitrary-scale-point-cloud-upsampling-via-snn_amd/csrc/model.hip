@@ -112,7 +112,7 @@ static inline int imin(int a, int b) { return a < b ? a : b; }
 
 // Route a GEMM to the split-f16 kernel when the model carries pre-split weights, else to the f32 MFMA kernel.
 static int run_gemm(const sapcu_model* m, GemmArgs& g, hipStream_t st) {
-    if (m && m->sf16 && g.w >= m->blob && g.w < m->blob + m->blob_floats) {
+    if (m && m->sf16 && g.k % 64 == 0 && g.w >= m->blob && g.w < m->blob + m->blob_floats) {
         const int64_t off = g.w - m->blob;
         g.w16_hi = (const _Float16*)m->w16_hi + off;
         g.w16_lo = (const _Float16*)m->w16_lo + off;
@@ -218,15 +218,14 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
         float* logits = A.take<float>(pl.cb * 3);
         const float* pc = patch + s * mp * 3;
 
-        // in-patch neighbour tables: replayed (reference KNNCache) or computed from this chunk
+        // in-patch neighbour tables: replayed (reference KNNCache) or computed from this chunk (one xyz
+        // ranking per patch serves the three blocks' k values)
+        if (!knn_in) SAPCU_TRY(launch_patch_knn_multi(pc, cb, (int64_t)mp * 3, mp, 3, 3, 3, pl.kk, idx, st));
         for (int l = 0; l < 3; ++l) {
             const int64_t cnt = P * pl.kk[l];
-            if (knn_in) {
+            if (knn_in)
                 SAPCU_CHECK_HIP(hipMemcpyAsync(idx[l], knn_in + tab_off[l] + s * mp * pl.kk[l], cnt * 4,
                                                hipMemcpyDeviceToDevice, st));
-            } else {
-                SAPCU_TRY(launch_patch_knn(pc, cb, mp, 3, 3, pl.kk[l], idx[l], st));
-            }
             if (knn_out)
                 SAPCU_CHECK_HIP(hipMemcpyAsync(knn_out + tab_off[l] + s * mp * pl.kk[l], idx[l], cnt * 4,
                                                hipMemcpyDeviceToDevice, st));
@@ -497,7 +496,7 @@ int sapcu_gemm_f32(const float* a, int64_t r, int k, int lda, const float* w, in
     memset(&g, 0, sizeof(g));
     g.a = a; g.r = r; g.k = k; g.lda = lda; g.w = w; g.n = n; g.bias = bias; g.c = c; g.ldc = ldc;
     g.epi = lif4 ? EPI_LIF : EPI_BIAS; g.lif = lif4; g.lif_T = lif_steps;
-    if (w16_ws) {
+    if (w16_ws && k % 64 == 0) {   // the split-f16 kernel steps k by 64; other depths run on the exact-f32 kernel
         SAPCU_TRY(split_into_ws(w, (int64_t)n * k, w16_ws, g, (hipStream_t)stream));
         return launch_gemm_sf16(g, (hipStream_t)stream);
     }
@@ -516,7 +515,7 @@ int sapcu_posenc_gemm_f32(const float* pe1, int64_t r, int d, const float* w, co
     g.epi = EPI_LIF_ATTN; g.lif = lif4; g.lif_T = lif_steps; g.c2 = attn_in_out;
     g.q = qkv; g.kf = qkv + d; g.ldq = 3 * d; g.tab = (const int2*)edge_table_ws;
     SAPCU_TRY(launch_edge_table(idx, r, m_pts, kk, (int2*)edge_table_ws, (hipStream_t)stream));
-    if (w16_ws) {   // split-f16 path: split W into the caller's scratch (hi | lo | counter), then 3 x f16 MFMA
+    if (w16_ws && d % 64 == 0) {   // split-f16 path: split W into the caller's scratch (hi | lo | counter), then 3 x f16 MFMA
         SAPCU_TRY(split_into_ws(w, (int64_t)d * d, w16_ws, g, (hipStream_t)stream));
         return launch_gemm_sf16(g, (hipStream_t)stream);
     }

@@ -6,6 +6,8 @@ namespace sapcu {
 
 int launch_patch_knn_strided(const float* feat, int64_t b, int64_t pstride, int m, int c, int ld, int k,
                              int32_t* idx, hipStream_t st);
+int launch_patch_knn_multi(const float* feat, int64_t b, int64_t pstride, int m, int c, int ld, int ntab,
+                           const int* ks, int32_t* const* idx, hipStream_t st);
 int launch_patch_knn(const float* feat, int64_t b, int m, int c, int ld, int k, int32_t* idx, hipStream_t st);
 int launch_neuron_selfloop(const float* x, int64_t rows, int ch, int T, const float* md, const float* ta,
                            const float* rd, const float* tb, const float* dT, const float* rh, float* so, float* mo,

@@ -16,8 +16,14 @@ namespace sapcu {
 // =============================================================================================
 constexpr int PK_CH = 32;   // channel chunk staged in LDS
 
+struct KnnOut {
+    int32_t* idx[3];   // up to three tables [b, m, k[t]] written from ONE ranking (fn blocks share the xyz ranking)
+    int k[3];
+    int n;
+};
+
 __global__ __launch_bounds__(256) void patch_knn_kernel(const float* __restrict__ feat, int64_t pstride, int m,
-                                                        int c, int ld, int k, int32_t* __restrict__ idx_out) {
+                                                        int c, int ld, const KnnOut out) {
     extern __shared__ float sm[];
     float* S = sm;                      // [m][m+1]
     float* xx = S + m * (m + 1);        // [m]
@@ -88,21 +94,35 @@ __global__ __launch_bounds__(256) void patch_knn_kernel(const float* __restrict_
             r0 += (sv > s0) || (sv == s0 && jp < j0);
             r1 += (sv > s1) || (sv == s1 && jp < j1);
         }
-        int32_t* o = idx_out + ((int64_t)blockIdx.x * m + i) * k;
-        if (j0 < m && r0 < k) o[r0] = j0;
-        if (j1 < m && r1 < k) o[r1] = j1;
+        for (int t = 0; t < out.n; ++t) {
+            const int k = out.k[t];
+            int32_t* o = out.idx[t] + ((int64_t)blockIdx.x * m + i) * k;
+            if (j0 < m && r0 < k) o[r0] = j0;
+            if (j1 < m && r1 < k) o[r1] = j1;
+        }
     }
+}
+
+int launch_patch_knn_multi(const float* feat, int64_t b, int64_t pstride, int m, int c, int ld, int ntab,
+                           const int* ks, int32_t* const* idx, hipStream_t st) {
+    if (b == 0) return SAPCU_OK;
+    SAPCU_CHECK_ARG(m >= 1 && m <= 128 && c >= 1 && ntab >= 1 && ntab <= 3, "patch_knn: need 1<=m<=128, 1..3 tables (m=%d)", m);
+    KnnOut out;
+    out.n = ntab;
+    for (int t = 0; t < 3; ++t) {
+        out.idx[t] = t < ntab ? idx[t] : nullptr;
+        out.k[t] = t < ntab ? ks[t] : 0;
+        if (t < ntab) SAPCU_CHECK_ARG(ks[t] >= 1 && ks[t] <= m && idx[t], "patch_knn: need 1<=k<=m (k=%d m=%d)", ks[t], m);
+    }
+    const size_t lds = (size_t)(m * (m + 1) + m + m * (PK_CH + 1)) * sizeof(float);
+    hipLaunchKernelGGL(patch_knn_kernel, dim3((unsigned)b), dim3(256), lds, st, feat, pstride, m, c, ld, out);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
 }
 
 int launch_patch_knn_strided(const float* feat, int64_t b, int64_t pstride, int m, int c, int ld, int k,
                              int32_t* idx, hipStream_t st) {
-    if (b == 0) return SAPCU_OK;
-    SAPCU_CHECK_ARG(m >= 1 && m <= 128 && k >= 1 && k <= m && c >= 1, "patch_knn: need 1<=k<=m<=128 (m=%d k=%d c=%d)",
-                    m, k, c);
-    const size_t lds = (size_t)(m * (m + 1) + m + m * (PK_CH + 1)) * sizeof(float);
-    hipLaunchKernelGGL(patch_knn_kernel, dim3((unsigned)b), dim3(256), lds, st, feat, pstride, m, c, ld, k, idx);
-    SAPCU_CHECK_LAUNCH();
-    return SAPCU_OK;
+    return launch_patch_knn_multi(feat, b, pstride, m, c, ld, 1, &k, &idx, st);
 }
 
 int launch_patch_knn(const float* feat, int64_t b, int m, int c, int ld, int k, int32_t* idx, hipStream_t st) {
@@ -184,36 +204,72 @@ int launch_fn_stem(const float* patch, int64_t rows, const float* w, const float
 
 // =============================================================================================
 // fn: positional encoding stage 1: fc_delta(3->d)+BN on (x_i - x_j) -> LIF x 4  (fn:310,355-358)
-//     rows = b*m*kk edges, thread per (edge, channel); output [rows, d]
+//     rows = b*m*kk edges; output [rows, d].  A workgroup owns a strip of PE_ROWS edge rows and up to 256
+//     channels (lane = channel: coalesced stores); the strip's position differences are staged in LDS
+//     once; a thread keeps its channel's weights and neuron parameters in registers for the whole strip
+//     and runs FOUR rows' neuron chains at a time (independent chains = VALU ILP).
 // =============================================================================================
+constexpr int PE_ROWS = 32;
+
 __global__ __launch_bounds__(256) void fn_pe1_kernel(const float* __restrict__ patch, const int32_t* __restrict__ idx,
                                                      int64_t rows, int m, int kk, int d,
                                                      const float* __restrict__ w /*[d][3]*/,
                                                      const float* __restrict__ bias, const float* __restrict__ lif,
                                                      int T, float* __restrict__ out) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= rows * d) return;
-    const int c = (int)(t % d);
-    const int64_t r = t / d;
-    const int64_t pt = r / kk;
-    const int64_t patch_i = pt / m;
-    const float* pi = patch + pt * 3;
-    const float* pj = patch + (patch_i * m + idx[r]) * 3;
-    const float dx = __fsub_rn(pi[0], pj[0]), dy = __fsub_rn(pi[1], pj[1]), dz = __fsub_rn(pi[2], pj[2]);
-    float a = __fmul_rn(w[c * 3], dx);
-    a = __fmaf_rn(w[c * 3 + 1], dy, a);
-    a = __fmaf_rn(w[c * 3 + 2], dz, a);
-    a = __fadd_rn(a, bias[c]);
-    out[t] = lif_selfloop(a, load_lif(lif, d, c), T);
+    __shared__ float pd[PE_ROWS][3];
+    const int64_t row0 = (int64_t)blockIdx.x * PE_ROWS;
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (threadIdx.x < PE_ROWS) {
+        const int64_t r = row0 + threadIdx.x;
+        float dx = 0.f, dy = 0.f, dz = 0.f;
+        if (r < rows) {
+            const int64_t pt = r / kk;
+            const int64_t patch_i = pt / m;
+            const float* pi = patch + pt * 3;
+            const float* pj = patch + (patch_i * m + idx[r]) * 3;
+            dx = __fsub_rn(pi[0], pj[0]);
+            dy = __fsub_rn(pi[1], pj[1]);
+            dz = __fsub_rn(pi[2], pj[2]);
+        }
+        pd[threadIdx.x][0] = dx;
+        pd[threadIdx.x][1] = dy;
+        pd[threadIdx.x][2] = dz;
+    }
+    __syncthreads();
+    if (c >= d) return;
+    const float w0 = w[c * 3], w1 = w[c * 3 + 1], w2 = w[c * 3 + 2], bb = bias[c];
+    const NeuronP np = load_lif(lif, d, c);
+    const int nrow = (int)((rows - row0) < PE_ROWS ? (rows - row0) : PE_ROWS);
+    for (int r4 = 0; r4 < nrow; r4 += 4) {
+        float v[4];
+        NeuronS stt[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r4 + u < PE_ROWS ? r4 + u : PE_ROWS - 1;
+            float a = __fmul_rn(w0, pd[rr][0]);
+            a = __fmaf_rn(w1, pd[rr][1], a);
+            a = __fmaf_rn(w2, pd[rr][2], a);
+            v[u] = __fadd_rn(a, bb);
+            stt[u] = neuron_init(np);
+        }
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = neuron_step<false>(v[u], stt[u], np);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (r4 + u < nrow) out[(row0 + r4 + u) * d + c] = v[u];
+    }
 }
 
 int launch_fn_pe1(const float* patch, const int32_t* idx, int64_t rows, int m, int kk, int d, const float* w,
                   const float* bias, const float* lif, int T, float* out, hipStream_t st) {
     if (rows == 0) return SAPCU_OK;
-    const int64_t total = rows * d;
-    SAPCU_CHECK_ARG((total + 255) / 256 < 0x7fffffffLL, "pe1: too many elements");
-    hipLaunchKernelGGL(fn_pe1_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, patch, idx, rows, m, kk,
-                       d, w, bias, lif, T, out);
+    const int64_t strips = (rows + PE_ROWS - 1) / PE_ROWS;
+    SAPCU_CHECK_ARG(strips < 0x7fffffffLL, "pe1: too many rows");
+    const int bx = d < 256 ? ((d + 63) / 64) * 64 : 256;
+    hipLaunchKernelGGL(fn_pe1_kernel, dim3((unsigned)strips, (unsigned)((d + bx - 1) / bx)), dim3(bx), 0, st, patch, idx,
+                       rows, m, kk, d, w, bias, lif, T, out);
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
 }
@@ -242,38 +298,70 @@ int launch_edge_table(const int32_t* idx, int64_t rows, int m, int kk, int2* tab
 // =============================================================================================
 // fn: per-channel softmax over the kk neighbours and aggregation (fn:379-389)
 //     attn = softmax(a / sqrt(hd));  res[pt,c] = sum_j attn_j * (v[nbr_j, c] + pe[edge_j, c])
-//     thread per (point, channel)
+//     thread per (point, channel); the kk logits stay in registers (KK known at compile time for the
+//     model's 24/18/12, generic loop otherwise), so `a` and `pe` are read exactly once.
 // =============================================================================================
+template <int KK>
 __global__ __launch_bounds__(256) void fn_softmax_agg_kernel(const float* __restrict__ a, const float* __restrict__ pe,
                                                              const float* __restrict__ v, int ldv,
                                                              const int32_t* __restrict__ idx, int64_t pts, int m,
-                                                             int kk, int d, float sqrt_hd, float* __restrict__ res) {
+                                                             int kk_rt, int d, float sqrt_hd, float* __restrict__ res) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= pts * d) return;
     const int c = (int)(t % d);
     const int64_t pt = t / d;
     const int64_t patch_i = pt / m;
+    const int kk = KK > 0 ? KK : kk_rt;
     const float* ar = a + pt * kk * d + c;
     const float* pr = pe + pt * kk * d + c;
     const int32_t* ir = idx + pt * kk;
-    float mx = -__builtin_huge_valf();
-    for (int j = 0; j < kk; ++j) mx = fmaxf(mx, __fdiv_rn(ar[(int64_t)j * d], sqrt_hd));
-    float den = 0.f;
-    for (int j = 0; j < kk; ++j) den = __fadd_rn(den, expf(__fsub_rn(__fdiv_rn(ar[(int64_t)j * d], sqrt_hd), mx)));
-    float acc = 0.f;
-    for (int j = 0; j < kk; ++j) {
-        const float w = __fdiv_rn(expf(__fsub_rn(__fdiv_rn(ar[(int64_t)j * d], sqrt_hd), mx)), den);
-        const float vv = __fadd_rn(v[(patch_i * m + ir[j]) * ldv + c], pr[(int64_t)j * d]);
-        acc = __fmaf_rn(w, vv, acc);
+    if (KK > 0) {
+        float x[KK > 0 ? KK : 1];
+        float mx = -__builtin_huge_valf();
+#pragma unroll
+        for (int j = 0; j < KK; ++j) {
+            x[j] = __fdiv_rn(ar[(int64_t)j * d], sqrt_hd);
+            mx = fmaxf(mx, x[j]);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < KK; ++j) {
+            x[j] = fast_exp(__fsub_rn(x[j], mx));
+            den = __fadd_rn(den, x[j]);
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < KK; ++j) {
+            const float vv = __fadd_rn(v[(patch_i * m + ir[j]) * ldv + c], pr[(int64_t)j * d]);
+            acc = __fmaf_rn(__fdiv_rn(x[j], den), vv, acc);
+        }
+        res[t] = acc;
+    } else {
+        float mx = -__builtin_huge_valf();
+        for (int j = 0; j < kk; ++j) mx = fmaxf(mx, __fdiv_rn(ar[(int64_t)j * d], sqrt_hd));
+        float den = 0.f;
+        for (int j = 0; j < kk; ++j) den = __fadd_rn(den, fast_exp(__fsub_rn(__fdiv_rn(ar[(int64_t)j * d], sqrt_hd), mx)));
+        float acc = 0.f;
+        for (int j = 0; j < kk; ++j) {
+            const float wj = __fdiv_rn(fast_exp(__fsub_rn(__fdiv_rn(ar[(int64_t)j * d], sqrt_hd), mx)), den);
+            const float vv = __fadd_rn(v[(patch_i * m + ir[j]) * ldv + c], pr[(int64_t)j * d]);
+            acc = __fmaf_rn(wj, vv, acc);
+        }
+        res[t] = acc;
     }
-    res[t] = acc;
 }
 
 int launch_fn_softmax_agg(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx, int64_t pts,
                           int m, int kk, int d, float sqrt_hd, float* res, hipStream_t st) {
     if (pts == 0) return SAPCU_OK;
-    hipLaunchKernelGGL(fn_softmax_agg_kernel, dim3((unsigned)((pts * d + 255) / 256)), dim3(256), 0, st, a, pe, v, ldv,
-                       idx, pts, m, kk, d, sqrt_hd, res);
+    const dim3 grid((unsigned)((pts * d + 255) / 256)), blk(256);
+#define SAPCU_SMX(K) \
+    hipLaunchKernelGGL((fn_softmax_agg_kernel<K>), grid, blk, 0, st, a, pe, v, ldv, idx, pts, m, kk, d, sqrt_hd, res)
+    if (kk == 24) SAPCU_SMX(24);
+    else if (kk == 18) SAPCU_SMX(18);
+    else if (kk == 12) SAPCU_SMX(12);
+    else SAPCU_SMX(0);
+#undef SAPCU_SMX
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
 }

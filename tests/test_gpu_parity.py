@@ -196,9 +196,6 @@ def test_split_f16_gemm_error_bound_on_mixed_magnitudes():
     r32, r16 = np.abs(c32 - ref) / bound, np.abs(c16 - ref) / bound
     print("error / bound: f32 MFMA max %.2f, split-f16 max %.2f" % (r32.max(), r16.max()))
     assert ovf == 0 and r16.max() <= 1.0
-    big = np.abs(a).max(1) > 0.25                                              # rows without subnormal low halves
-    rel = (np.abs(c16 - ref) / (A64 @ W64.T))[big]
-    assert rel.max() <= 4e-7
     a[0, 0] = 7e4                                                             # beyond f16: must be reported
     _, ovf = _run_gemm(a, w, bias, True)
     assert ovf >= 1
