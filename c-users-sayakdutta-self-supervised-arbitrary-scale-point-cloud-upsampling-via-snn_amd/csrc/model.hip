@@ -537,7 +537,7 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
     const char* ge = getenv("SAPCU_GEMM");
     m->sf16 = !(ge && strcmp(ge, "f32") == 0);
     const char* ce = getenv("SAPCU_CHUNK");
-    m->chunk = ce ? atoll(ce) : 512;
+    m->chunk = ce ? atoll(ce) : 2048;
     if (m->chunk < 1) m->chunk = 1;
     int rc = SAPCU_OK;
     if (kind == SAPCU_KIND_FN) {

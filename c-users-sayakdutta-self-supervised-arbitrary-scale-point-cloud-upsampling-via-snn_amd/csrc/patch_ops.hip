@@ -22,6 +22,7 @@ struct KnnOut {
     int n;
 };
 
+template <int MAXP>   // pairs per thread: ceil(m*m / 256) <= MAXP (16 for m <= 64, 64 for m <= 128)
 __global__ __launch_bounds__(256) void patch_knn_kernel(const float* __restrict__ feat, int64_t pstride, int m,
                                                         int c, int ld, const KnnOut out) {
     extern __shared__ float sm[];
@@ -31,7 +32,6 @@ __global__ __launch_bounds__(256) void patch_knn_kernel(const float* __restrict_
     const int tid = threadIdx.x;
     const float* base = feat + (int64_t)blockIdx.x * pstride;
     const int npairs = m * m;
-    constexpr int MAXP = 64;            // m <= 128 -> <= 64 pairs per thread
     float acc[MAXP];
 #pragma unroll
     for (int t = 0; t < MAXP; ++t) acc[t] = 0.f;
@@ -115,7 +115,10 @@ int launch_patch_knn_multi(const float* feat, int64_t b, int64_t pstride, int m,
         if (t < ntab) SAPCU_CHECK_ARG(ks[t] >= 1 && ks[t] <= m && idx[t], "patch_knn: need 1<=k<=m (k=%d m=%d)", ks[t], m);
     }
     const size_t lds = (size_t)(m * (m + 1) + m + m * (PK_CH + 1)) * sizeof(float);
-    hipLaunchKernelGGL(patch_knn_kernel, dim3((unsigned)b), dim3(256), lds, st, feat, pstride, m, c, ld, out);
+    if (m <= 64)
+        hipLaunchKernelGGL(patch_knn_kernel<16>, dim3((unsigned)b), dim3(256), lds, st, feat, pstride, m, c, ld, out);
+    else
+        hipLaunchKernelGGL(patch_knn_kernel<64>, dim3((unsigned)b), dim3(256), lds, st, feat, pstride, m, c, ld, out);
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
 }
