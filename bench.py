@@ -109,8 +109,19 @@ def roofline_leg(dev, reps=3):
     byts = float(np.mean([3.0 * s[1] * s[2] * 4 for s in shapes]))      # read pe1, write pe, write attn_in (f32)
     steps = float(np.mean([4.0 * s[1] * s[2] for s in shapes]))         # neuron element-steps
     gbs = byts / avg_s / 1e9
+    # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
+    # command, corrected as MI355X_MICROARCH.md prescribes) — condensed by profiles/pmc_to_json.py
+    traffic, src = None, None
+    for cand in sorted([f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json")], reverse=True):
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", cand))).get("gemm_sf16_kernel<6>")
+            if rec:
+                traffic, src = float(rec["hbm_bytes_per_launch"]), "profiles/" + cand
+                break
+        except (OSError, ValueError, KeyError):
+            pass
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": src,
             "kernel": "gemm_sf16_kernel<EPI_LIF_ATTN>", "avg_launch_ms": round(avg_s * 1e3, 4),
             "bytes_per_launch": byts, "launches_timed": n_launch, "chunk_patches": chunk,
             "mfma": {"algorithmic_tflops": round(flop / avg_s / 1e12, 2), "issued_f16_tflops": round(3 * flop / avg_s / 1e12, 2),

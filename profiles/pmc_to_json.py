@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) into per-kernel averages (JSON).
+
+Units and corrections follow MI355X_MICROARCH.md §HBM: the counters are in KiB; on gfx950 FETCH_SIZE reports
+half of the bytes of a wide (16 B/lane) coalesced stream, so `fetch_bytes_corrected = 2 * fetch_bytes_raw`;
+WRITE_SIZE is exact for 4-16 B/lane streaming stores."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_kernel(d, counter):
+    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].split("(")[0].replace("void sapcu::", "").replace("sapcu::", "")
+        agg[name].append(float(r["Counter_Value"]) * 1024.0)
+    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+
+
+def main(fetch_dir, write_dir, out):
+    fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    res = {}
+    for k in sorted(set(fe) | set(wr)):
+        if not k.startswith(("gemm", "fn_", "fd_", "patch_", "knn_", "rowgroup", "edge_", "gather", "displace")):
+            continue
+        f, nf = fe.get(k, (0.0, 0))
+        w, nw = wr.get(k, (0.0, 0))
+        res[k] = {"launches": max(nf, nw), "fetch_bytes_raw": round(f), "fetch_bytes_corrected": round(2 * f),
+                  "write_bytes": round(w), "hbm_bytes_per_launch": round(2 * f + w)}
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    print(json.dumps(res.get("gemm_sf16_kernel<6>"), indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
