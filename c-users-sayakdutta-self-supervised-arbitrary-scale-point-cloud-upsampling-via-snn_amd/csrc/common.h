@@ -64,14 +64,15 @@ __device__ __forceinline__ NeuronP load_eif(const float* __restrict__ p6, int st
 // eval-mode spike surrogate: 0.5*N(x) + 0.5*sigmoid(10 x), x clamped to +-10 (fn:135-146).
 // Same operation order as the reference; the transcendentals are the hardware v_exp_f32 / v_rcp_f32
 // (1 ulp each) instead of libm calls: |error| <= 2e-7 absolute on a value in (0,1), measured against the
-// reference vectors in tests/golden/neuron_unit.npz (bar 1e-6).
+// reference vectors in tests/golden/neuron_unit.npz (bar 1e-6).  The two halvings are exact (powers of
+// two), so 0.5/sqrt(2 pi) is one constant and 0.5*s + g one FMA — bit-identical to mul, mul, add.
 __device__ __forceinline__ float soft_spike(float d) {
     const float x = clampf(d, -10.0f, 10.0f);
     const float g = __fmul_rn(__builtin_amdgcn_exp2f(__fmul_rn(__fmul_rn(x, x), -0.72134752044448170368f)),
-                              0.39894228040143267794f);                     // exp(-x^2/2) / sqrt(2 pi)
+                              0.19947114020071633897f);                     // 0.5 * exp(-x^2/2) / sqrt(2 pi)
     const float e = __builtin_amdgcn_exp2f(__fmul_rn(x, -14.426950408889634074f));   // exp(-10 x)
     const float s = __builtin_amdgcn_rcpf(__fadd_rn(1.0f, e));
-    return __fadd_rn(__fmul_rn(0.5f, g), __fmul_rn(0.5f, s));
+    return __fmaf_rn(0.5f, s, g);
 }
 
 __device__ __forceinline__ float fast_exp(float a) { return __builtin_amdgcn_exp2f(__fmul_rn(a, 1.4426950408889634074f)); }
@@ -101,12 +102,51 @@ __device__ __forceinline__ float neuron_step(float x, NeuronS& s, const NeuronP&
     return sp;
 }
 
-// `for t in range(T): x, *st = snn(x, *st)` — spikes fed back as the next input (fn:319-320).
-// State lives in registers for all T steps.
+// `for t in range(T): x, *st = snn(x, *st)` — spikes fed back as the next input (fn:319-320), LIF.
+// State lives in registers for all T steps.  Two exact simplifications of neuron_step<false>:
+//   * step 0 starts from m = 0, r = 0:  m = x,  r = s0  (0*decay*(1-0) + x and 0*rdecay + s0, exactly);
+//   * for t >= 1 the gate `x * (r <= 0)` is closed — soft_spike() >= 0.199 * 2^-72 > 0, so r > 0 — and the
+//     fed-back input contributes exactly +0;  the state updates after the last spike are dead.
+// W chains are advanced together (independent chains = VALU ILP for the GEMM consumers / pos-enc kernel).
+template <int W>
+__device__ __forceinline__ void lif_selfloop_n(float (&v)[W], const NeuronP& p, int T) {
+    float m[W], r[W], th[W];
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        m[u] = v[u];
+        v[u] = soft_spike(__fsub_rn(m[u], p.theta0));
+    }
+    if (T <= 1) return;
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        m[u] = __fmul_rn(m[u], __fsub_rn(1.0f, v[u]));
+        r[u] = v[u];
+        const float t0 = __fadd_rn(p.theta0, __fmul_rn(p.adapt, v[u]));
+        th[u] = __fadd_rn(p.theta0, __fmul_rn(__fsub_rn(t0, p.theta0), 0.95f));
+    }
+    for (int t = 1; t < T - 1; ++t) {
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            const float mm = __fmul_rn(__fmul_rn(m[u], p.decay), __fsub_rn(1.0f, r[u]));
+            const float sp = soft_spike(__fsub_rn(mm, th[u]));
+            m[u] = __fmul_rn(mm, __fsub_rn(1.0f, sp));
+            r[u] = __fadd_rn(__fmul_rn(r[u], p.rdecay), sp);
+            const float t0 = __fadd_rn(th[u], __fmul_rn(p.adapt, sp));
+            th[u] = __fadd_rn(p.theta0, __fmul_rn(__fsub_rn(t0, p.theta0), 0.95f));
+            v[u] = sp;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        const float mm = __fmul_rn(__fmul_rn(m[u], p.decay), __fsub_rn(1.0f, r[u]));
+        v[u] = soft_spike(__fsub_rn(mm, th[u]));
+    }
+}
+
 __device__ __forceinline__ float lif_selfloop(float x, const NeuronP& p, int T) {
-    NeuronS s = neuron_init(p);
-    for (int t = 0; t < T; ++t) x = neuron_step<false>(x, s, p);
-    return x;
+    float v[1] = {x};
+    lif_selfloop_n<1>(v, p, T);
+    return v[0];
 }
 
 // IEEE-correct f64 square root: the hardware/OCML result refined by one Markstein step

@@ -38,15 +38,7 @@ __device__ __forceinline__ void epilogue_group4(const GemmArgs& g, const float (
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) v[u] = __fadd_rn(acc[u], bias);
-    if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) {
-        NeuronS st[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) st[u] = neuron_init(np);
-        for (int t = 0; t < g.lif_T; ++t) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = neuron_step<false>(v[u], st[u], np);
-        }
-    }
+    if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) lif_selfloop_n<4>(v, np, g.lif_T);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         if (EPI == EPI_GELU) v[u] = gelu_erf(v[u]);

@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256) void neuron_selfloop_kernel(const float* __res
     NeuronS s = neuron_init(p);
     float v = x[t];
     for (int i = 0; i < T; ++i) v = neuron_step<EIF>(v, s, p);
+    if (!EIF) v = lif_selfloop(x[t], p, T);   // LIF spikes come from the production (peeled) loop; states from the step form
     if (so) so[t] = v;
     if (mo) mo[t] = s.m;
     if (to) to[t] = s.th;
@@ -245,7 +246,6 @@ __global__ __launch_bounds__(256) void fn_pe1_kernel(const float* __restrict__ p
     const int nrow = (int)((rows - row0) < PE_ROWS ? (rows - row0) : PE_ROWS);
     for (int r4 = 0; r4 < nrow; r4 += 4) {
         float v[4];
-        NeuronS stt[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int rr = r4 + u < PE_ROWS ? r4 + u : PE_ROWS - 1;
@@ -253,12 +253,8 @@ __global__ __launch_bounds__(256) void fn_pe1_kernel(const float* __restrict__ p
             a = __fmaf_rn(w1, pd[rr][1], a);
             a = __fmaf_rn(w2, pd[rr][2], a);
             v[u] = __fadd_rn(a, bb);
-            stt[u] = neuron_init(np);
         }
-        for (int t = 0; t < T; ++t) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = neuron_step<false>(v[u], stt[u], np);
-        }
+        lif_selfloop_n<4>(v, np, T);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (r4 + u < nrow) out[(row0 + r4 + u) * d + c] = v[u];
