@@ -10,7 +10,7 @@ outer kNN + gather/centre -> fn forward -> normalise -> gather/rotate -> fd forw
 before the timed region.  Weak scaling: every rank refines its own 4096 queries per step.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel symbol (the positional-encoding GEMM gemm_sf16_kernel<EPI_LIF_ATTN>,
+  roofline      the dominant kernel symbol (the positional-encoding GEMM gemm_ring_kernel<EPI_LIF_ATTN>,
                 fn/snn_coder.py:360-368: d x d contraction + 4-step neuron loop + q-k+pe gather), its
                 three per-block shapes launched back to back on the current stream between two
                 events: achieved = mean algorithmic HBM bytes per launch (3*r*d*4: read pe1, write pe,
@@ -60,7 +60,7 @@ def build_models(dev):
 
 
 def roofline_leg(dev, reps=3):
-    """Time the dominant kernel symbol alone: gemm_sf16_kernel<EPI_LIF_ATTN> (pos-enc GEMM, fn/snn_coder.py:360-368),
+    """Time the dominant kernel symbol alone: gemm_ring_kernel<EPI_LIF_ATTN> (pos-enc GEMM, fn/snn_coder.py:360-368),
     its three per-block launches for one chunk of patches, back to back on the current stream.
 
     The kernel reads pe1 [r,d] and writes pe [r,d] and attn_in [r,d] (f32) and runs the 4-step neuron loop on
@@ -76,6 +76,9 @@ def roofline_leg(dev, reps=3):
         pts = chunk * M_PTS
         r = pts * kk
         pe = torch.rand((r, d), device=dev)
+        pes = torch.empty_like(pe)
+        _lib.check(lib.sapcu_to_split_rows(_lib.ptr(pe), r, d, d, _lib.ptr(pes), d, _lib.current_stream()))
+        pe = pes                       # the models hand pe1 over as split rows (written by fn_pe1_kernel)
         qkv = torch.rand((pts, 3 * d), device=dev)
         idx = torch.randint(0, M_PTS, (r,), dtype=torch.int32, device=dev)
         w = (torch.rand((d, d), device=dev) - 0.5) * (2.0 / d ** 0.5)
@@ -91,7 +94,7 @@ def roofline_leg(dev, reps=3):
         for pe, r, d, w, bias, lif, qkv, idx, kk, out, out2, tab, w16 in shapes:
             _lib.check(lib.sapcu_posenc_gemm_f32(_lib.ptr(pe), r, d, _lib.ptr(w), _lib.ptr(bias), _lib.ptr(lif), 4, _lib.ptr(qkv),
                                                  _lib.ptr(idx), kk, M_PTS, _lib.ptr(out), _lib.ptr(out2), _lib.ptr(tab),
-                                                 _lib.ptr(w16), _lib.current_stream()))
+                                                 _lib.ptr(w16), 1, _lib.current_stream()))
 
     launch_all()
     torch.cuda.synchronize()
@@ -114,7 +117,7 @@ def roofline_leg(dev, reps=3):
     traffic, src = None, None
     for cand in sorted([f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json")], reverse=True):
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", cand))).get("gemm_sf16_kernel<6>")
+            rec = json.load(open(os.path.join(ROOT, "profiles", cand))).get("gemm_ring_kernel<6>")
             if rec:
                 traffic, src = float(rec["hbm_bytes_per_launch"]), "profiles/" + cand
                 break
@@ -122,7 +125,7 @@ def roofline_leg(dev, reps=3):
             pass
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": src,
-            "kernel": "gemm_sf16_kernel<EPI_LIF_ATTN>", "avg_launch_ms": round(avg_s * 1e3, 4),
+            "kernel": "gemm_ring_kernel<EPI_LIF_ATTN>", "avg_launch_ms": round(avg_s * 1e3, 4),
             "bytes_per_launch": byts, "launches_timed": n_launch, "chunk_patches": chunk,
             "mfma": {"algorithmic_tflops": round(flop / avg_s / 1e12, 2), "issued_f16_tflops": round(3 * flop / avg_s / 1e12, 2),
                      "peak_f16_dense_tflops": PEAK_F16_MFMA_TFLOPS, "issued_frac": round(3 * flop / avg_s / 1e12 / PEAK_F16_MFMA_TFLOPS, 4)},

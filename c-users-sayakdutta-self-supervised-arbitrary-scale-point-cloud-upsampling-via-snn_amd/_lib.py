@@ -43,9 +43,10 @@ _SIGNATURES = {
     "sapcu_fd_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64,
                                  POINTER(c_void_p), c_void_p]),
     "sapcu_gemm_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
-                               c_int, c_void_p, c_void_p]),
+                               c_int, c_void_p, c_int, c_int, c_void_p]),
+    "sapcu_to_split_rows": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
     "sapcu_posenc_gemm_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                                      c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                      c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "sapcu_model_gemm_mode": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
 }
 

@@ -194,9 +194,12 @@ struct GemmArgs {
     const _Float16* w16_hi;
     const _Float16* w16_lo;
     int* ovf;            // device counter raised when an activation tile exceeds the f16 range (may be null)
+    // "split rows" (gemm_epi.h): A already split by its producer -> all-DMA ring kernel; outputs to be split
+    int a_split, c_split, c2_split;
 };
 int launch_gemm(const GemmArgs& g, hipStream_t st);        // f32 MFMA (exact f32 products)
-int launch_gemm_sf16(const GemmArgs& g, hipStream_t st);   // 3 x f16 MFMA, f32-quality (needs w16_hi/lo)
+int launch_gemm_sf16(const GemmArgs& g, hipStream_t st);   // 3 x f16 MFMA, f32-quality (needs w16_hi/lo); f32 A
+int launch_gemm_sf16_ring(const GemmArgs& g, hipStream_t st);   // same arithmetic, A in split rows, 4-slot LDS-DMA ring
 int launch_split_weights(const float* w, int64_t count, void* hi, void* lo, int* ovf, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------

@@ -21,39 +21,64 @@ __device__ __forceinline__ float settle(float x) {
     return x;
 }
 
-// Epilogue of FOUR accumulator elements of one lane: same column, rows row..row+3.  The four neuron
-// chains are independent, so unrolling them gives the VALU 4-way ILP; gathers are issued for all four
-// before the first is used, stores after the last is computed.
-template <int EPI>
-__device__ __forceinline__ void epilogue_group4(const GemmArgs& g, const float (&acc)[4], int64_t row, int col,
-                                                float bias, const NeuronP& np, const float (&q)[4],
-                                                const float (&kf)[4]) {
-    float v[4], res[4];
-    bool ok[4];
+// "Split rows": a [rows, K] activation tensor whose producer already split every value for the split-f16
+// GEMM (gemm_sf16_ring.hip).  A row keeps the f32 row's footprint (pitch = ld floats = 4*ld bytes): the first
+// K halves are hi = f16_rn(x), the halves starting at half-index ld (byte 2*ld) are lo = f16_rn(x - hi).
+__device__ __forceinline__ void store_split(float* base, int64_t row, int ld, int col, float v) {
+    _Float16* rp = reinterpret_cast<_Float16*>(base + row * ld);
+    const _Float16 hi = (_Float16)v;
+    rp[col] = hi;
+    rp[ld + col] = (_Float16)(v - (float)hi);
+}
+
+// Epilogue of W accumulator elements of one lane: same column, rows row..row+W-1.  The W neuron chains
+// are independent, so unrolling them gives the VALU W-way ILP; loads are issued for all before the first
+// is used, stores after the last is computed.
+template <int EPI, int W>
+__device__ __forceinline__ void epilogue_group(const GemmArgs& g, const float (&acc)[W], int64_t row, int col,
+                                               float bias, const NeuronP& np, const float (&q)[W],
+                                               const float (&kf)[W]) {
+    float v[W], res[W];
+    bool ok[W];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) ok[u] = (row + u) < g.r;
+    for (int u = 0; u < W; ++u) ok[u] = (row + u) < g.r;
     if (EPI == EPI_RESID || EPI == EPI_RESID_GELU) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) res[u] = ok[u] ? g.resid[(row + u) * g.ldr + col] : 0.f;
+        for (int u = 0; u < W; ++u) res[u] = ok[u] ? g.resid[(row + u) * g.ldr + col] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = __fadd_rn(acc[u], bias);
-    if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) lif_selfloop_n<4>(v, np, g.lif_T);
+    for (int u = 0; u < W; ++u) v[u] = __fadd_rn(acc[u], bias);
+    if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) lif_selfloop_n<W>(v, np, g.lif_T);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < W; ++u) {
         if (EPI == EPI_GELU) v[u] = gelu_erf(v[u]);
         if (EPI == EPI_LRELU) v[u] = lrelu02(v[u]);
         if (EPI == EPI_RESID) v[u] = __fadd_rn(v[u], res[u]);
         if (EPI == EPI_RESID_GELU) v[u] = gelu_erf(__fadd_rn(v[u], res[u]));
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < W; ++u) {
         if (!ok[u]) continue;
-        g.c[(row + u) * g.ldc + col] = v[u];
+        if (g.c_split) {
+            store_split(g.c, row + u, g.ldc, col, v[u]);
+            if (EPI != EPI_LIF && EPI != EPI_LIF_ATTN && !(fabsf(v[u]) < 65504.0f) && g.ovf) atomicAdd(g.ovf, 1);
+        } else {
+            g.c[(row + u) * g.ldc + col] = v[u];
+        }
         // attn_in = q_i - k_j + pos_enc (fn/snn_coder.py:368), operand of the next GEMM
-        if (EPI == EPI_LIF_ATTN) g.c2[(row + u) * g.ldc + col] = __fadd_rn(__fsub_rn(q[u], kf[u]), v[u]);
+        if (EPI == EPI_LIF_ATTN) {
+            const float ai = __fadd_rn(__fsub_rn(q[u], kf[u]), v[u]);
+            if (g.c2_split) store_split(g.c2, row + u, g.ldc, col, ai);
+            else g.c2[(row + u) * g.ldc + col] = ai;
+        }
     }
 }
 
+template <int EPI>
+__device__ __forceinline__ void epilogue_group4(const GemmArgs& g, const float (&acc)[4], int64_t row, int col,
+                                                float bias, const NeuronP& np, const float (&q)[4],
+                                                const float (&kf)[4]) {
+    epilogue_group<EPI, 4>(g, acc, row, col, bias, np, q, kf);
+}
 
 }  // namespace sapcu

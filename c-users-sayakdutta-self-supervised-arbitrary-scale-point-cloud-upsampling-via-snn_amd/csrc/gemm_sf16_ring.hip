@@ -1,0 +1,318 @@
+// Split-f16 MFMA GEMM, all-DMA ring version: the hot kernel of the edge GEMMs (gfx950).
+//
+//   C[r, n] = epi( A[r, k] . W[n, k]^T + bias[n] )
+//
+// Same arithmetic as gemm_sf16.hip (x = hi + lo halves, three v_mfma_f32_32x32x16_f16 per product into one
+// f32 accumulator, weights pre-scaled by 16), but A arrives ALREADY SPLIT ("split rows", gemm_epi.h: the
+// producing epilogue / element-wise kernel wrote hi and lo halves instead of an f32), so BOTH operands are
+// plain f16 planes that stream global -> LDS by LDS-DMA with no registers and no VALU in between.
+//
+// Why: with one k-step of prefetch the f32-A kernel was bound by operand latency (bias-only GEMM at
+// r=294912, k=n=512: 690 us against ~200 us of matrix-pipe time; removing the A loads, the W loads or the
+// MFMAs each saved only 15-25 %).  Here a 4-slot ring keeps THREE k-steps (96 KiB per CU) in flight across
+// tile boundaries, and the producer waves execute nothing but ds_read + MFMA + 4 DMA issues per k-step.
+//
+// Structure: ONE 1024-thread workgroup per CU, persistent over 128x128 tiles.
+//   waves 0-7   PRODUCERS, 4x2 sub-tiles of 32x64 (2 MFMA tiles, 32 accumulator registers each).
+//               k-step = 32: per step  s_waitcnt vmcnt(keep 2 steps in flight) -> barrier -> issue the DMAs of
+//               step g+3 into the slot read at step g-1 -> 12 MFMAs from slot g%4.
+//   waves 8-15  CONSUMERS (two VALU waves per SIMD): epilogue of the PREVIOUS tile from registers, in
+//               2-element pieces between the k-step barriers (K = 512: 16 steps, 16 pieces: balanced).
+//   hand-off    through a 32 KiB LDS area in two halves: first the column-tile-1 half (consumers copy its 16
+//               values to registers), then the column-tile-0 half, which STAYS there and is read piece by piece
+//               during the next tile — the ring keeps streaming underneath.
+//   LDS         4 slots x (A_hi | A_lo | W_hi | W_lo) x [128 rows][32 halves] = 128 KiB + 32 KiB hand-off = 160 KiB.
+//               64-byte rows, 16-byte chunk index XOR-swizzled by (row>>2)&3: conflict-free ds_read_b128; the DMA
+//               destination is lane-linear, so the swizzle is applied to each lane's SOURCE address.
+#include "common.h"
+#include "gemm_epi.h"
+
+namespace sapcu {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+
+constexpr int RBM = 128, RBN = 128, RBK = 32;
+constexpr int RPLANE = RBM * RBK * 2;            // 8 KiB
+constexpr int RSLOT = 4 * RPLANE;                // 32 KiB
+constexpr int RSLOTS = 4;
+constexpr int RHAND = 8 * 16 * 64 * 4;           // 32 KiB: one column-tile half of the accumulators
+constexpr int RING_LDS_BYTES = RSLOTS * RSLOT + RHAND;
+
+// wait until at most N of this wave's vector-memory operations (the ring's DMAs) are outstanding
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    if (N >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// one 2-element consumer piece of column tile 1 with STATIC register indices (Q = 0..7: registers 2Q, 2Q+1)
+template <int EPI, int Q>
+__device__ __forceinline__ void ring_reg_piece(const GemmArgs& g, const float (&cacc)[16], int64_t row, int col, float bias,
+                                               const NeuronP& np, const float (&cq)[2], const float (&ckf)[2]) {
+    const float a[2] = {cacc[2 * Q], cacc[2 * Q + 1]};
+    epilogue_group<EPI, 2>(g, a, row, col, bias, np, cq, ckf);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    float* hand = reinterpret_cast<float*>(smem_raw + RSLOTS * RSLOT);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave < 8;
+    const int pw = wave & 7;
+    const int wm = pw >> 1, wn = pw & 1;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    const int ntn = (g.n + RBN - 1) / RBN;
+    const int64_t ntm = (g.r + RBM - 1) / RBM;
+    const int64_t ntiles = ntm * ntn;
+    const int nx = gridDim.x < 8 ? 1 : 8;
+    const int xcd = nx == 1 ? 0 : (int)(blockIdx.x & 7);
+    const int wg_in_x = nx == 1 ? (int)blockIdx.x : (int)(blockIdx.x >> 3);
+    const int wgs_per_x = nx == 1 ? (int)gridDim.x : (int)((gridDim.x - xcd + 7) >> 3);
+    const int64_t qd = ntiles / nx, rem = ntiles % nx;
+    const int64_t x_begin = xcd * qd + (xcd < rem ? xcd : rem);
+    const int64_t x_count = qd + (xcd < rem ? 1 : 0);
+    const int nk = g.k / RBK;
+    // this workgroup's tiles: local indices wg_in_x, wg_in_x + wgs_per_x, ... < x_count
+    const int64_t my_tiles = x_count > wg_in_x ? (x_count - wg_in_x + wgs_per_x - 1) / wgs_per_x : 0;
+    if (my_tiles == 0) return;
+
+    if (producer) {
+        // DMA role: wave w moves piece w (rows 16w..16w+15) of each of the 4 planes; lane -> 16-byte chunk
+        const int drow = pw * 16 + (lane >> 2);
+        const int dsrc = ((lane & 3) ^ ((drow >> 2) & 3)) * 8;     // source k offset (halves) of this lane's LDS chunk
+        // fragment rows / swizzles
+        const int arow_l = wm * 32 + r32;
+        const int asw = (arow_l >> 2) & 3;
+        int wrow_l[2], wsw[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            wrow_l[j] = wn * 64 + j * 32 + r32;
+            wsw[j] = (wrow_l[j] >> 2) & 3;
+        }
+        const _Float16* a16 = reinterpret_cast<const _Float16*>(g.a);
+        const int64_t a_pitch = 2 * (int64_t)g.lda;               // halves per A row
+        const int64_t total_steps = my_tiles * nk;
+
+        // prefetch cursor: global step index -> (tile, k-step)
+        int64_t pf_tile = 0;
+        int pf_kt = 0;
+        const _Float16* pf_a = nullptr;
+        int pf_woff = 0;
+        auto pf_setup = [&]() {
+            const int64_t logical = x_begin + pf_tile * wgs_per_x + wg_in_x;
+            const int64_t row0 = (logical / ntn) * RBM;
+            const int col0 = (int)(logical % ntn) * RBN;
+            int64_t ar = row0 + drow;
+            if (ar >= g.r) ar = g.r - 1;                           // clamped rows only feed masked outputs
+            pf_a = a16 + ar * a_pitch + dsrc;
+            int nn = col0 + drow;
+            if (nn >= g.n) nn = g.n - 1;
+            pf_woff = nn * g.k + dsrc;
+        };
+        auto issue = [&](int64_t gstep) {                          // DMAs of global step gstep (cursor must be on it)
+            lds_byte* sbase = (lds_byte*)(smem_raw + (int)(gstep & (RSLOTS - 1)) * RSLOT + pw * 1024);
+            const int k0 = pf_kt * RBK;
+            __builtin_amdgcn_global_load_lds((gptr_t)(pf_a + k0), sbase, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(pf_a + g.lda + k0), sbase + RPLANE, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(g.w16_hi + pf_woff + k0), sbase + 2 * RPLANE, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(g.w16_lo + pf_woff + k0), sbase + 3 * RPLANE, 16, 0, 0);
+            if (++pf_kt == nk) {
+                pf_kt = 0;
+                ++pf_tile;
+                if (pf_tile < my_tiles) pf_setup();
+            }
+        };
+        pf_setup();
+        int64_t issued = 0;
+        for (; issued < 3 && issued < total_steps; ++issued) issue(issued);
+
+        f32x16 acc[2];
+        int64_t gstep = 0;
+        for (int64_t ti = 0; ti < my_tiles; ++ti) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+            for (int kt = 0; kt < nk; ++kt, ++gstep) {
+                // this wave's DMAs of step gstep have landed when at most (steps issued beyond gstep) x 4 are pending
+                const int64_t ahead = issued - gstep - 1;
+                if (ahead >= 2) wait_vm<8>();
+                else if (ahead == 1) wait_vm<4>();
+                else wait_vm<0>();
+                lds_barrier();                                      // everyone's pieces of step gstep are in; slot (gstep-1)%4 is free
+                if (issued < total_steps) {
+                    issue(issued);
+                    ++issued;
+                }
+                const unsigned char* st = smem_raw + (int)(gstep & (RSLOTS - 1)) * RSLOT;
+                const unsigned char* sA = st + arow_l * (RBK * 2);
+#pragma unroll
+                for (int k16 = 0; k16 < RBK / 16; ++k16) {
+                    const int ca = ((k16 * 2 + h) ^ asw) * 16;
+                    const half8 ah = *reinterpret_cast<const half8*>(sA + ca);
+                    const half8 al = *reinterpret_cast<const half8*>(sA + RPLANE + ca);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const unsigned char* sW = st + 2 * RPLANE + wrow_l[j] * (RBK * 2) + (((k16 * 2 + h) ^ wsw[j]) * 16);
+                        const half8 wh = *reinterpret_cast<const half8*>(sW);
+                        const half8 wl = *reinterpret_cast<const half8*>(sW + RPLANE);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc[j], 0, 0, 0);
+                    }
+                }
+            }
+            // hand-off in two halves through the 32 KiB area (the ring keeps streaming underneath)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 1 - jj;                               // column tile 1 first (goes to registers), then 0 (stays)
+                lds_barrier();                                      // consumers are done with what the area held
+#pragma unroll
+                for (int e = 0; e < 16; ++e) hand[(pw * 16 + e) * 64 + lane] = __fmul_rn(acc[j][e], 0.0625f);   // undo W x 16
+                lds_barrier();                                      // half j is ready
+            }
+        }
+    } else {
+        float cacc[16];                // column tile 1 of the previous tile; column tile 0 stays in the hand-off area
+        int64_t prev_row0 = -1;
+        int prev_col0 = 0;
+        // pieces (2 elements) per k-step so that the 16 pieces are done within the next tile's nk steps
+        const int pper = (16 + nk - 1) / nk;
+        for (int64_t ti = 0; ti <= my_tiles; ++ti) {               // last round = drain (no barriers on either side)
+            const bool have = ti < my_tiles;
+            const bool cons_work = prev_row0 >= 0;
+            float cbias[2];
+            NeuronP cnp[2];
+            bool ccol[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = prev_col0 + wn * 64 + j * 32 + r32;
+                ccol[j] = cons_work && col < g.n;
+                cbias[j] = settle((ccol[j] && g.bias) ? g.bias[col] : 0.f);
+                cnp[j] = NeuronP{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) {
+                    cnp[j] = load_lif(g.lif, g.n, ccol[j] ? col : 0);
+                    cnp[j].theta0 = settle(cnp[j].theta0);
+                }
+            }
+            // EPI_LIF_ATTN: lane l holds the (q row, k row) pair of tile row wm*32 + (l & 31); a piece fetches its
+            // two pairs with ds_bpermute and its q/k gathers are issued one piece AHEAD.
+            int2 tabrow = make_int2(0, 0);
+            float nq[2] = {0.f, 0.f}, nkf[2] = {0.f, 0.f};
+            auto issue_gather = [&](int pi) {      // piece pi: column tile j = pi>>3, accumulator registers e0 = 2*(pi&7), +1
+                if (EPI != EPI_LIF_ATTN) return;
+                const int j = pi >> 3, e0 = 2 * (pi & 7);
+                const int col = prev_col0 + wn * 64 + j * 32 + r32;
+                const int lrow = (e0 & 3) + 8 * (e0 >> 2) + 4 * h;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int qr = __shfl(tabrow.x, lrow + u);
+                    const int kr = __shfl(tabrow.y, lrow + u);
+                    const bool ok = col < g.n && (prev_row0 + wm * 32 + lrow + u) < g.r;
+                    nq[u] = ok ? g.q[(int64_t)qr * g.ldq + col] : 0.f;
+                    nkf[u] = ok ? g.kf[(int64_t)kr * g.ldq + col] : 0.f;
+                }
+            };
+            if (cons_work && EPI == EPI_LIF_ATTN) {
+                const int64_t trow = prev_row0 + wm * 32 + (lane & 31);
+                if (trow < g.r) tabrow = g.tab[trow];
+                tabrow.x = __builtin_bit_cast(int, settle(__builtin_bit_cast(float, tabrow.x)));
+                tabrow.y = __builtin_bit_cast(int, settle(__builtin_bit_cast(float, tabrow.y)));
+                issue_gather(0);
+            }
+            for (int kt = 0; kt < nk; ++kt) {
+                if (have) lds_barrier();
+                if (!cons_work) continue;
+                for (int pi = kt * pper; pi < (kt + 1) * pper && pi < 16; ++pi) {
+                    float cq[2] = {nq[0], nq[1]}, ckf[2] = {nkf[0], nkf[1]};
+                    if (pi + 1 < 16) issue_gather(pi + 1);
+                    const int j = pi >> 3, e0 = 2 * (pi & 7);
+                    if (!(j ? ccol[1] : ccol[0])) continue;
+                    const int64_t row = prev_row0 + wm * 32 + (e0 & 3) + 8 * (e0 >> 2) + 4 * h;
+                    if (row >= g.r) continue;
+                    const int col = prev_col0 + wn * 64 + j * 32 + r32;
+                    if (pi < 8) {        // column tile 0: straight from the hand-off area
+                        const float a[2] = {hand[(pw * 16 + e0) * 64 + lane], hand[(pw * 16 + e0 + 1) * 64 + lane]};
+                        epilogue_group<EPI, 2>(g, a, row, col, cbias[0], cnp[0], cq, ckf);
+                    } else {             // column tile 1: from registers, static indices per piece
+                        switch (pi) {
+                            case 8: ring_reg_piece<EPI, 0>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
+                            case 9: ring_reg_piece<EPI, 1>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
+                            case 10: ring_reg_piece<EPI, 2>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
+                            case 11: ring_reg_piece<EPI, 3>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
+                            case 12: ring_reg_piece<EPI, 4>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
+                            case 13: ring_reg_piece<EPI, 5>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
+                            case 14: ring_reg_piece<EPI, 6>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
+                            default: ring_reg_piece<EPI, 7>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
+                        }
+                    }
+                }
+            }
+            if (!have) break;
+            // take this tile's accumulators: column tile 1 to registers, then column tile 0 stays in the area
+            lds_barrier();                                          // (we are done with the area: producers may overwrite)
+            lds_barrier();                                          // column tile 1 is in
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cacc[e] = hand[(pw * 16 + e) * 64 + lane];
+            lds_barrier();                                          // copied out
+            lds_barrier();                                          // column tile 0 is in (and stays)
+            const int64_t logical = x_begin + ti * wgs_per_x + wg_in_x;
+            prev_row0 = (logical / ntn) * RBM;
+            prev_col0 = (int)(logical % ntn) * RBN;
+        }
+    }
+}
+
+static int g_num_cus_ring = 0;
+
+template <int EPI>
+static int launch_ring_t(const GemmArgs& g, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        SAPCU_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<EPI>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
+        attr_set = true;
+    }
+    if (g_num_cus_ring == 0) {
+        int dev = 0;
+        SAPCU_CHECK_HIP(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        SAPCU_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        g_num_cus_ring = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int64_t tiles = ((g.r + RBM - 1) / RBM) * ((g.n + RBN - 1) / RBN);
+    const int64_t grid = tiles < g_num_cus_ring ? tiles : g_num_cus_ring;
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI>), dim3((unsigned)grid), dim3(1024), RING_LDS_BYTES, st, g);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+int launch_gemm_sf16_ring(const GemmArgs& g, hipStream_t st) {
+    if (g.r == 0 || g.n == 0) return SAPCU_OK;
+    SAPCU_CHECK_ARG(g.a_split, "gemm_ring: A must be in split rows");
+    SAPCU_CHECK_ARG(g.k > 0 && g.k % RBK == 0 && g.k <= g.lda, "gemm_ring: k=%d must be a multiple of %d and <= lda", g.k, RBK);
+    SAPCU_CHECK_ARG(g.lda % 8 == 0 && ((uintptr_t)g.a & 15) == 0 && g.w16_hi && g.w16_lo &&
+                        ((uintptr_t)g.w16_hi & 15) == 0 && ((uintptr_t)g.w16_lo & 15) == 0,
+                    "gemm_ring: operands must be 16-byte aligned with lda %% 8 == 0 (lda=%d)", g.lda);
+    switch (g.epi) {
+        case EPI_BIAS: return launch_ring_t<EPI_BIAS>(g, st);
+        case EPI_LIF: return launch_ring_t<EPI_LIF>(g, st);
+        case EPI_GELU: return launch_ring_t<EPI_GELU>(g, st);
+        case EPI_RESID: return launch_ring_t<EPI_RESID>(g, st);
+        case EPI_LRELU: return launch_ring_t<EPI_LRELU>(g, st);
+        case EPI_RESID_GELU: return launch_ring_t<EPI_RESID_GELU>(g, st);
+        case EPI_LIF_ATTN:
+            SAPCU_CHECK_ARG(g.ldq > 0 && g.tab && g.q && g.kf && g.c2, "gemm_ring: bad attn operands");
+            return launch_ring_t<EPI_LIF_ATTN>(g, st);
+        default: set_error("gemm_ring: unknown epilogue %d", g.epi); return SAPCU_ERR_ARG;
+    }
+}
+
+}  // namespace sapcu

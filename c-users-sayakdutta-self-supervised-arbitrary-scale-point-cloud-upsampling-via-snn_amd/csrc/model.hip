@@ -112,23 +112,31 @@ static inline int imin(int a, int b) { return a < b ? a : b; }
 
 // Route a GEMM to the split-f16 kernel when the model carries pre-split weights, else to the f32 MFMA kernel.
 static int run_gemm(const sapcu_model* m, GemmArgs& g, hipStream_t st) {
-    if (m && m->sf16 && g.k % 64 == 0 && g.w >= m->blob && g.w < m->blob + m->blob_floats) {
+    const bool have16 = m && m->sf16 && g.w >= m->blob && g.w < m->blob + m->blob_floats;
+    if (have16) {
         const int64_t off = g.w - m->blob;
         g.w16_hi = (const _Float16*)m->w16_hi + off;
         g.w16_lo = (const _Float16*)m->w16_lo + off;
         g.ovf = m->ovf_dev;
-        return launch_gemm_sf16(g, st);
+        if (g.a_split) return launch_gemm_sf16_ring(g, st);          // A already split by its producer: all-DMA ring
+        if (g.k % 64 == 0) return launch_gemm_sf16(g, st);
+    }
+    if (g.a_split || g.c_split || g.c2_split) {
+        set_error("run_gemm: split-row operands need the split-f16 kernels");
+        return SAPCU_ERR_ARG;
     }
     return launch_gemm(g, st);
 }
 
+// fmt bit 0: A is in split rows; bit 1: write C in split rows (both only in split-f16 mode)
 static int gemm(const sapcu_model* m, const float* a, int64_t r, int k, int lda, const float* w, int n,
                 const float* bias, float* c, int ldc, int epi, hipStream_t st, const float* lif = nullptr,
-                int lifT = 0, const float* resid = nullptr, int ldr = 0) {
+                int lifT = 0, const float* resid = nullptr, int ldr = 0, int fmt = 0) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.a = a; g.r = r; g.k = k; g.lda = lda; g.w = w; g.n = n; g.bias = bias; g.c = c; g.ldc = ldc;
     g.epi = epi; g.lif = lif; g.lif_T = lifT; g.resid = resid; g.ldr = ldr;
+    g.a_split = fmt & 1; g.c_split = (fmt >> 1) & 1;
     return run_gemm(m, g, st);
 }
 
@@ -240,15 +248,18 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
             const int kk = pl.kk[l];
             const int64_t R = P * kk;
             const int sb = FN_BLK0 + l * B_SLOTS;
+            // Tensors that only feed another GEMM travel as split rows (SP) in split-f16 mode: their producer
+            // writes f16 hi/lo halves and the consuming GEMM streams them by LDS-DMA (gemm_sf16_ring.hip).
+            const int SP = m->sf16 ? 1 : 0;
             // x = LIF(fc1(feat))                                                    fn:317-320
             SAPCU_TRY(gemm(m, fin, P, 64, ldin, m->p(sb + B_FC1_W), d, m->p(sb + B_FC1_B), X, d, EPI_LIF, st,
-                           m->p(sb + B_SNN1), 4));
+                           m->p(sb + B_SNN1), 4, nullptr, 0, SP << 1));
             // q|k|v = LIF(w_qs|w_ks|w_vs (x))                                       fn:322-335
             SAPCU_TRY(gemm(m, X, P, d, d, m->p(sb + B_QKV_W), 3 * d, m->p(sb + B_QKV_B), QKV, 3 * d, EPI_LIF, st,
-                           m->p(sb + B_QKV_LIF), 4));
+                           m->p(sb + B_QKV_LIF), 4, nullptr, 0, SP));
             // pe1 = LIF(fc_delta(x_i - x_j))                                        fn:310,355-358
             SAPCU_TRY(launch_fn_pe1(pc, idx[l], R, mp, kk, d, m->p(sb + B_DELTA_W), m->p(sb + B_DELTA_B),
-                                    m->p(sb + B_DELTA_LIF), 4, B1, st));
+                                    m->p(sb + B_DELTA_LIF), 4, B1, SP, st));
             // pe = LIF(fc_delta2(pe1)) -> B2, and in the same epilogue attn_in = q_i - k_j + pe -> B3   fn:360-368
             {
                 GemmArgs g;
@@ -257,21 +268,24 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
                 g.bias = m->p(sb + B_DELTA2_B); g.c = B2; g.ldc = d; g.epi = EPI_LIF_ATTN;
                 g.lif = m->p(sb + B_DELTA2_LIF); g.lif_T = 4; g.c2 = B3;
                 g.q = QKV; g.kf = QKV + d; g.ldq = 3 * d; g.tab = tab;
+                g.a_split = SP; g.c2_split = SP;
                 SAPCU_TRY(launch_edge_table(idx[l], R, mp, kk, tab, st));
                 SAPCU_TRY(run_gemm(m, g, st));
             }
             // g = LIF(fc_gamma(attn_in)) -> B1                                      fn:373-376
             SAPCU_TRY(gemm(m, B3, R, d, d, m->p(sb + B_GAMMA_W), d, m->p(sb + B_GAMMA_B), B1, d, EPI_LIF, st,
-                           m->p(sb + B_GAMMA_LIF), 4));
+                           m->p(sb + B_GAMMA_LIF), 4, nullptr, 0, SP | (SP << 1)));
             // a = fc_gamma2(g) -> B3                                                fn:378
-            SAPCU_TRY(gemm(m, B1, R, d, d, m->p(sb + B_GAMMA2_W), d, m->p(sb + B_GAMMA2_B), B3, d, EPI_BIAS, st));
+            SAPCU_TRY(gemm(m, B1, R, d, d, m->p(sb + B_GAMMA2_W), d, m->p(sb + B_GAMMA2_B), B3, d, EPI_BIAS, st, nullptr, 0,
+                           nullptr, 0, SP));
             // res = sum_j softmax_j(a / sqrt(hd)) * (v_j + pe)                      fn:379-389
             const float sqrt_hd = (float)sqrt((double)(d / m->heads));
-            SAPCU_TRY(launch_fn_softmax_agg(B3, B2, QKV + 2 * d, 3 * d, idx[l], P, mp, kk, d, sqrt_hd, RES, st));
+            SAPCU_TRY(launch_fn_softmax_agg(B3, B2, QKV + 2 * d, 3 * d, idx[l], P, mp, kk, d, sqrt_hd, RES, SP, st));
             // out_proj, fc2 + residual                                              fn:393-394
-            SAPCU_TRY(gemm(m, RES, P, d, d, m->p(sb + B_OUT_W), d, m->p(sb + B_OUT_B), X, d, EPI_BIAS, st));
+            SAPCU_TRY(gemm(m, RES, P, d, d, m->p(sb + B_OUT_W), d, m->p(sb + B_OUT_B), X, d, EPI_BIAS, st, nullptr, 0, nullptr,
+                           0, SP | (SP << 1)));
             SAPCU_TRY(gemm(m, X, P, d, d, m->p(sb + B_FC2_W), 64, m->p(sb + B_FC2_B), cat + 64 * l, 192, EPI_RESID, st,
-                           nullptr, 0, fin, ldin));
+                           nullptr, 0, fin, ldin, SP));
             if (taps && taps[SAPCU_FN_TAP_BLOCK1 + l]) {
                 SAPCU_CHECK_HIP(hipMemcpy2DAsync((char*)taps[SAPCU_FN_TAP_BLOCK1 + l] + s * mp * 64 * 4, 64 * 4,
                                                  cat + 64 * l, 192 * 4, 64 * 4, (size_t)P, hipMemcpyDeviceToDevice, st));
@@ -489,23 +503,32 @@ static int split_into_ws(const float* w, int64_t cnt, void* w16_ws, GemmArgs& g,
 }
 
 int sapcu_gemm_f32(const float* a, int64_t r, int k, int lda, const float* w, int n, const float* bias,
-                   const float* lif4, int lif_steps, float* c, int ldc, void* w16_ws, void* stream) {
+                   const float* lif4, int lif_steps, float* c, int ldc, void* w16_ws, int a_split_rows, int c_split_rows,
+                   void* stream) {
     SAPCU_CHECK_ARG(a && w && c && r >= 0 && n >= 1, "gemm: bad argument");
     SAPCU_CHECK_ARG(!lif4 || lif_steps >= 1, "gemm: lif_steps must be >= 1");
+    SAPCU_CHECK_ARG(!(a_split_rows || c_split_rows) || w16_ws, "gemm: split rows need the split-f16 kernels (w16_ws)");
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.a = a; g.r = r; g.k = k; g.lda = lda; g.w = w; g.n = n; g.bias = bias; g.c = c; g.ldc = ldc;
     g.epi = lif4 ? EPI_LIF : EPI_BIAS; g.lif = lif4; g.lif_T = lif_steps;
-    if (w16_ws && k % 64 == 0) {   // the split-f16 kernel steps k by 64; other depths run on the exact-f32 kernel
+    g.a_split = a_split_rows ? 1 : 0; g.c_split = c_split_rows ? 1 : 0;
+    if (w16_ws && (g.a_split || k % 64 == 0)) {   // f32-A split-f16 kernel steps k by 64; other depths run on exact f32
         SAPCU_TRY(split_into_ws(w, (int64_t)n * k, w16_ws, g, (hipStream_t)stream));
-        return launch_gemm_sf16(g, (hipStream_t)stream);
+        return g.a_split ? launch_gemm_sf16_ring(g, (hipStream_t)stream) : launch_gemm_sf16(g, (hipStream_t)stream);
     }
+    SAPCU_CHECK_ARG(!g.c_split, "gemm: split-row output needs k %% 64 == 0 on the f32-A path");
     return launch_gemm(g, (hipStream_t)stream);
+}
+
+int sapcu_to_split_rows(const float* in, int64_t rows, int k, int ld_in, float* out, int ld_out, void* stream) {
+    SAPCU_CHECK_ARG(in && out && rows >= 0 && k >= 1 && ld_in >= k && ld_out >= k, "to_split_rows: bad argument");
+    return launch_to_split_rows(in, rows, k, ld_in, out, ld_out, (hipStream_t)stream);
 }
 
 int sapcu_posenc_gemm_f32(const float* pe1, int64_t r, int d, const float* w, const float* bias, const float* lif4,
                           int lif_steps, const float* qkv, const int32_t* idx, int kk, int m_pts, float* pe_out,
-                          float* attn_in_out, void* edge_table_ws, void* w16_ws, void* stream) {
+                          float* attn_in_out, void* edge_table_ws, void* w16_ws, int split_rows, void* stream) {
     SAPCU_CHECK_ARG(pe1 && w && lif4 && qkv && idx && pe_out && attn_in_out && edge_table_ws && r >= 0 && d >= 32 &&
                         lif_steps >= 1 && kk >= 1 && m_pts >= 1,
                     "posenc_gemm: bad argument");
@@ -515,8 +538,14 @@ int sapcu_posenc_gemm_f32(const float* pe1, int64_t r, int d, const float* w, co
     g.epi = EPI_LIF_ATTN; g.lif = lif4; g.lif_T = lif_steps; g.c2 = attn_in_out;
     g.q = qkv; g.kf = qkv + d; g.ldq = 3 * d; g.tab = (const int2*)edge_table_ws;
     SAPCU_TRY(launch_edge_table(idx, r, m_pts, kk, (int2*)edge_table_ws, (hipStream_t)stream));
-    if (w16_ws && d % 64 == 0) {   // split-f16 path: split W into the caller's scratch (hi | lo | counter), then 3 x f16 MFMA
+    SAPCU_CHECK_ARG(!split_rows || w16_ws, "posenc_gemm: split rows need the split-f16 kernels (w16_ws)");
+    if (w16_ws && (split_rows || d % 64 == 0)) {   // split W into the caller's scratch (hi | lo | counter), then 3 x f16 MFMA
         SAPCU_TRY(split_into_ws(w, (int64_t)d * d, w16_ws, g, (hipStream_t)stream));
+        if (split_rows) {     // the production form: pe1 arrives as split rows, attn_in leaves as split rows
+            g.a_split = 1;
+            g.c2_split = 1;
+            return launch_gemm_sf16_ring(g, (hipStream_t)stream);
+        }
         return launch_gemm_sf16(g, (hipStream_t)stream);
     }
     return launch_gemm(g, (hipStream_t)stream);

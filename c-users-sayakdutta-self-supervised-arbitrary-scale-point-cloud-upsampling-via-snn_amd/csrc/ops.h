@@ -15,13 +15,14 @@ int launch_neuron_selfloop(const float* x, int64_t rows, int ch, int T, const fl
 int launch_fn_stem(const float* patch, int64_t rows, const float* w, const float* bias, const float* lif, int T,
                    float* out, hipStream_t st);
 int launch_fn_pe1(const float* patch, const int32_t* idx, int64_t rows, int m, int kk, int d, const float* w,
-                  const float* bias, const float* lif, int T, float* out, hipStream_t st);
+                  const float* bias, const float* lif, int T, float* out, int split, hipStream_t st);
 int launch_edge_table(const int32_t* idx, int64_t rows, int m, int kk, int2* tab, hipStream_t st);
 int launch_fn_softmax_agg(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx, int64_t pts,
-                          int m, int kk, int d, float sqrt_hd, float* res, hipStream_t st);
+                          int m, int kk, int d, float sqrt_hd, float* res, int split, hipStream_t st);
 int launch_rowgroup_max(const float* in, int64_t groups, int m, int c, float* out, hipStream_t st);
 int launch_fn_tail(const float* h, int64_t b, int kdim, const float* w, const float* bias, const float* lnw,
                    const float* lnb, float* logits, float* normals, hipStream_t st);
+int launch_to_split_rows(const float* in, int64_t rows, int k, int ld_in, float* out, int ld_out, hipStream_t st);
 int launch_l2_normalize3(const float* in, float* out, int64_t b, hipStream_t st);
 int launch_fd_edge0(const float* patch, const int32_t* idx, int kmax, int64_t pts, int m, int nscale,
                     const int32_t* ks_dev, const float* w, const float* bias, float* out, hipStream_t st);

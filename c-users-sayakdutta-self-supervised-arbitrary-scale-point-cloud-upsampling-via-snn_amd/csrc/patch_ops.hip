@@ -4,6 +4,7 @@
 // wavefront's 64 lanes touch 256 contiguous bytes.
 #include "common.h"
 #include "ops.h"
+#include "gemm_epi.h"
 
 namespace sapcu {
 
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void fn_pe1_kernel(const float* __restrict__ p
                                                      int64_t rows, int m, int kk, int d,
                                                      const float* __restrict__ w /*[d][3]*/,
                                                      const float* __restrict__ bias, const float* __restrict__ lif,
-                                                     int T, float* __restrict__ out) {
+                                                     int T, float* __restrict__ out, int split) {
     __shared__ float pd[PE_ROWS][3];
     const int64_t row0 = (int64_t)blockIdx.x * PE_ROWS;
     const int c = blockIdx.y * blockDim.x + threadIdx.x;
@@ -257,18 +258,21 @@ __global__ __launch_bounds__(256) void fn_pe1_kernel(const float* __restrict__ p
         lif_selfloop_n<4>(v, np, T);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (r4 + u < nrow) out[(row0 + r4 + u) * d + c] = v[u];
+            if (r4 + u < nrow) {
+                if (split) store_split(out, row0 + r4 + u, d, c, v[u]);      // operand of the pos-enc ring GEMM
+                else out[(row0 + r4 + u) * d + c] = v[u];
+            }
     }
 }
 
 int launch_fn_pe1(const float* patch, const int32_t* idx, int64_t rows, int m, int kk, int d, const float* w,
-                  const float* bias, const float* lif, int T, float* out, hipStream_t st) {
+                  const float* bias, const float* lif, int T, float* out, int split, hipStream_t st) {
     if (rows == 0) return SAPCU_OK;
     const int64_t strips = (rows + PE_ROWS - 1) / PE_ROWS;
     SAPCU_CHECK_ARG(strips < 0x7fffffffLL, "pe1: too many rows");
     const int bx = d < 256 ? ((d + 63) / 64) * 64 : 256;
     hipLaunchKernelGGL(fn_pe1_kernel, dim3((unsigned)strips, (unsigned)((d + bx - 1) / bx)), dim3(bx), 0, st, patch, idx,
-                       rows, m, kk, d, w, bias, lif, T, out);
+                       rows, m, kk, d, w, bias, lif, T, out, split);
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
 }
@@ -304,7 +308,8 @@ template <int KK>
 __global__ __launch_bounds__(256) void fn_softmax_agg_kernel(const float* __restrict__ a, const float* __restrict__ pe,
                                                              const float* __restrict__ v, int ldv,
                                                              const int32_t* __restrict__ idx, int64_t pts, int m,
-                                                             int kk_rt, int d, float sqrt_hd, float* __restrict__ res) {
+                                                             int kk_rt, int d, float sqrt_hd, float* __restrict__ res,
+                                                             int split) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= pts * d) return;
     const int c = (int)(t % d);
@@ -334,7 +339,8 @@ __global__ __launch_bounds__(256) void fn_softmax_agg_kernel(const float* __rest
             const float vv = __fadd_rn(v[(patch_i * m + ir[j]) * ldv + c], pr[(int64_t)j * d]);
             acc = __fmaf_rn(__fdiv_rn(x[j], den), vv, acc);
         }
-        res[t] = acc;
+        if (split) store_split(res, pt, d, c, acc);
+        else res[t] = acc;
     } else {
         float mx = -__builtin_huge_valf();
         for (int j = 0; j < kk; ++j) mx = fmaxf(mx, __fdiv_rn(ar[(int64_t)j * d], sqrt_hd));
@@ -346,16 +352,17 @@ __global__ __launch_bounds__(256) void fn_softmax_agg_kernel(const float* __rest
             const float vv = __fadd_rn(v[(patch_i * m + ir[j]) * ldv + c], pr[(int64_t)j * d]);
             acc = __fmaf_rn(wj, vv, acc);
         }
-        res[t] = acc;
+        if (split) store_split(res, pt, d, c, acc);
+        else res[t] = acc;
     }
 }
 
 int launch_fn_softmax_agg(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx, int64_t pts,
-                          int m, int kk, int d, float sqrt_hd, float* res, hipStream_t st) {
+                          int m, int kk, int d, float sqrt_hd, float* res, int split, hipStream_t st) {
     if (pts == 0) return SAPCU_OK;
     const dim3 grid((unsigned)((pts * d + 255) / 256)), blk(256);
 #define SAPCU_SMX(K) \
-    hipLaunchKernelGGL((fn_softmax_agg_kernel<K>), grid, blk, 0, st, a, pe, v, ldv, idx, pts, m, kk, d, sqrt_hd, res)
+    hipLaunchKernelGGL((fn_softmax_agg_kernel<K>), grid, blk, 0, st, a, pe, v, ldv, idx, pts, m, kk, d, sqrt_hd, res, split)
     if (kk == 24) SAPCU_SMX(24);
     else if (kk == 18) SAPCU_SMX(18);
     else if (kk == 12) SAPCU_SMX(12);
@@ -439,6 +446,24 @@ int launch_fn_tail(const float* h, int64_t b, int kdim, const float* w, const fl
     if (b == 0) return SAPCU_OK;
     hipLaunchKernelGGL(fn_tail_kernel, dim3((unsigned)((b + 3) / 4)), dim3(256), 0, st, h, b, kdim, w, bias, lnw, lnb,
                        logits, normals);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+// f32 [rows, k] (row pitch ld_in) -> split rows (row pitch ld_out floats; gemm_epi.h)
+__global__ __launch_bounds__(256) void to_split_rows_kernel(const float* __restrict__ in, int64_t rows, int k, int ld_in,
+                                                            float* __restrict__ out, int ld_out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * k) return;
+    const int64_t r = t / k;
+    const int c = (int)(t % k);
+    store_split(out, r, ld_out, c, in[r * ld_in + c]);
+}
+
+int launch_to_split_rows(const float* in, int64_t rows, int k, int ld_in, float* out, int ld_out, hipStream_t st) {
+    if (rows == 0) return SAPCU_OK;
+    hipLaunchKernelGGL(to_split_rows_kernel, dim3((unsigned)((rows * k + 255) / 256)), dim3(256), 0, st, in, rows, k, ld_in,
+                       out, ld_out);
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
 }

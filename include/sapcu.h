@@ -159,21 +159,31 @@ int sapcu_l2_normalize3(const float* in, float* out, int64_t b, void* stream);
  * lif4 == NULL: epi = identity.  Otherwise lif4 = raw neuron parameters [4][n] and the epilogue is
  * the lif_steps-step self-feeding LIF loop (the fused form of conv+BN -> snn loop, fn:317-320).
  * w16_ws == NULL: exact-f32 MFMA kernel.  Otherwise 4*n*k + 16 bytes of scratch: W is split into f16
- * hi/lo halves there and the split-f16 kernel runs (3 x f16 MFMA per product; last 4 bytes of the
- * scratch = count of activation tiles beyond the f16 range). */
+ * hi/lo halves there and a split-f16 kernel runs (3 x f16 MFMA per product; last 4 bytes of the
+ * scratch = count of activation values beyond the f16 range).
+ * a_split_rows: A is in "split rows" (see sapcu_to_split_rows) -> the all-DMA ring kernel (lda % 8 == 0);
+ * c_split_rows: write C as split rows (needs w16_ws). */
 int sapcu_gemm_f32(const float* a, int64_t r, int k, int lda, const float* w, int n, const float* bias,
-                   const float* lif4, int lif_steps, float* c, int ldc, void* w16_ws, void* stream);
+                   const float* lif4, int lif_steps, float* c, int ldc, void* w16_ws, int a_split_rows,
+                   int c_split_rows, void* stream);
+
+/* f32 [rows,k] (row pitch ld_in floats) -> "split rows" (row pitch ld_out floats): each value x becomes two
+ * f16 halves hi = f16_rn(x) at half-index c and lo = f16_rn(x - hi) at half-index ld_out + c of its row — the
+ * operand format of the split-f16 ring GEMM.  Inside the models the producing kernels write it directly. */
+int sapcu_to_split_rows(const float* in, int64_t rows, int k, int ld_in, float* out, int ld_out, void* stream);
 
 /* The positional-encoding GEMM of one fn block — the heaviest single launch shape of the path:
  *   pe[row,:]      = LIF_x4( W . pe1[row,:] + bias )                         (fn/snn_coder.py:360-363)
  *   attn_in[row,:] = q[pt(row),:] - k[nbr(row),:] + pe[row,:]                (fn/snn_coder.py:367-368)
  * pe1 [r,d]; qkv [b*m, 3d] (q | k | v); idx [r] = flattened [b,m,kk] in-patch neighbours; w [d,d];
  * edge_table_ws: 8*r bytes of scratch (row -> (q row, k row) table, rebuilt by every call).
- * w16_ws: NULL -> exact-f32 MFMA kernel; else 4*d*d + 16 bytes of scratch -> split-f16 (3 x f16 MFMA) kernel. */
+ * w16_ws: NULL -> exact-f32 MFMA kernel; else 4*d*d + 16 bytes of scratch -> split-f16 (3 x f16 MFMA) kernel.
+ * split_rows != 0 (needs w16_ws): pe1 is in split rows and attn_in_out is written as split rows — the form the
+ * models run (all-DMA ring kernel). */
 int sapcu_posenc_gemm_f32(const float* pe1, int64_t r, int d, const float* w, const float* bias,
                           const float* lif4, int lif_steps, const float* qkv, const int32_t* idx, int kk,
                           int m_pts, float* pe_out, float* attn_in_out, void* edge_table_ws, void* w16_ws,
-                          void* stream);
+                          int split_rows, void* stream);
 
 #ifdef __cplusplus
 }

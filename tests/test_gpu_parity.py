@@ -154,21 +154,28 @@ def test_patch_knn_xyz_exact_and_feature_space_flips():
 
 # ------------------------------------------------------------------------------- GEMM
 def _run_gemm(a, w, bias, split):
+    """split: False = exact-f32 MFMA kernel; True = split-f16 with f32 A; "ring" = split-f16 ring kernel (A as split rows)."""
     from sapcu_amd import _lib
+    lib = _lib.load()
     r, k = a.shape
     n = w.shape[0]
     A, W, Bv = _dev(a), _dev(w), _dev(bias)
     C = torch.full((r, n), float("nan"), device=U.dev())
     ws = torch.zeros(4 * n * k + 16, dtype=torch.uint8, device=U.dev()) if split else None
-    _lib.check(_lib.load().sapcu_gemm_f32(_lib.ptr(A), r, k, k, _lib.ptr(W), n, _lib.ptr(Bv), None, 0, _lib.ptr(C), n,
-                                          _lib.ptr(ws), _lib.current_stream()))
+    a_split = 0
+    if split == "ring":
+        As = torch.empty_like(A)
+        _lib.check(lib.sapcu_to_split_rows(_lib.ptr(A), r, k, k, _lib.ptr(As), k, _lib.current_stream()))
+        A, a_split = As, 1
+    _lib.check(lib.sapcu_gemm_f32(_lib.ptr(A), r, k, k, _lib.ptr(W), n, _lib.ptr(Bv), None, 0, _lib.ptr(C), n,
+                                  _lib.ptr(ws), a_split, 0, _lib.current_stream()))
     torch.cuda.synchronize()
     ovf = int(ws[-16:].view(torch.int32)[0].item()) if split else 0
     return C.cpu().numpy(), ovf
 
 
-@pytest.mark.parametrize("split", [False, True])
-@pytest.mark.parametrize("r,k,n", [(1, 32, 1), (130, 64, 3), (257, 192, 640), (1000, 960, 768), (4096, 512, 512)])
+@pytest.mark.parametrize("split", [False, True, "ring"])
+@pytest.mark.parametrize("r,k,n", [(1, 32, 1), (130, 64, 3), (257, 192, 640), (1000, 960, 768), (4096, 512, 512), (40000, 128, 128)])
 def test_gemm_against_float64(r, k, n, split):
     rng = np.random.default_rng(r + k + n)
     a, w, bias = rng.normal(size=(r, k)).astype(np.float32), rng.normal(size=(n, k)).astype(np.float32), rng.normal(size=n).astype(np.float32)
@@ -193,9 +200,10 @@ def test_split_f16_gemm_error_bound_on_mixed_magnitudes():
     bound = 4e-7 * (A64 @ W64.T) + 2.0 ** -25 * W64.sum(1)[None, :] + 2.0 ** -29 * A64.sum(1)[:, None]
     c32, _ = _run_gemm(a, w, bias, False)
     c16, ovf = _run_gemm(a, w, bias, True)
-    r32, r16 = np.abs(c32 - ref) / bound, np.abs(c16 - ref) / bound
-    print("error / bound: f32 MFMA max %.2f, split-f16 max %.2f" % (r32.max(), r16.max()))
-    assert ovf == 0 and r16.max() <= 1.0
+    cring, _ = _run_gemm(a, w, bias, "ring")
+    r32, r16, rr = np.abs(c32 - ref) / bound, np.abs(c16 - ref) / bound, np.abs(cring - ref) / bound
+    print("error / bound: f32 MFMA max %.2f, split-f16 max %.2f, ring max %.2f" % (r32.max(), r16.max(), rr.max()))
+    assert ovf == 0 and r16.max() <= 1.0 and rr.max() <= 1.0
     a[0, 0] = 7e4                                                             # beyond f16: must be reported
     _, ovf = _run_gemm(a, w, bias, True)
     assert ovf >= 1
