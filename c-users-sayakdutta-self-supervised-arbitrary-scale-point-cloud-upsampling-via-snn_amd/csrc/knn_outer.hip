@@ -25,7 +25,17 @@ struct TopSlot {
     int i;
 };
 
-__device__ __forceinline__ double shfl_up1(double v) { return __shfl_up(v, 1); }
+// Cross-lane moves without the LDS crossbar: ds_bpermute (what __shfl compiles to) has ~100 cycles of
+// latency and an insertion chains ~15 of them; a wave-uniform source lane is a v_readlane, and "take the
+// value of lane-1" is one DPP move (wave_shr:1, lane 0 keeps its own).
+__device__ __forceinline__ int shr1_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ double shr1_d(double v) {
+    return __hiloint2double(shr1_i(__double2hiint(v)), shr1_i(__double2loint(v)));
+}
+__device__ __forceinline__ double readlane_d(double v, int lane_uniform) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane_uniform),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane_uniform));
+}
 
 __global__ __launch_bounds__(256) void knn_outer_kernel(const double* __restrict__ cloud, int64_t n,
                                                         const double* __restrict__ queries, int64_t b, int k,
@@ -71,18 +81,18 @@ __global__ __launch_bounds__(256) void knn_outer_kernel(const double* __restrict
             while (mask) {
                 const int src = __builtin_ctzll(mask);
                 mask &= mask - 1;
-                const double cd = __shfl(d, src);
+                const double cd = readlane_d(d, src);
                 if (!(cd < tau)) continue;
                 const int ci = (int)(base + off + src);
                 // position = number of entries <= candidate (all have smaller point index)
                 const int pos = __popcll(__ballot(s0.d <= cd)) + __popcll(__ballot(s1.d <= cd));
                 // shift entries at positions >= pos up by one, drop the last
-                const double u0d = shfl_up1(s0.d);
-                const int u0i = __shfl_up(s0.i, 1);
-                double u1d = shfl_up1(s1.d);
-                int u1i = __shfl_up(s1.i, 1);
-                const double l63d = __shfl(s0.d, 63);
-                const int l63i = __shfl(s0.i, 63);
+                const double u0d = shr1_d(s0.d);
+                const int u0i = shr1_i(s0.i);
+                double u1d = shr1_d(s1.d);
+                int u1i = shr1_i(s1.i);
+                const double l63d = readlane_d(s0.d, 63);
+                const int l63i = __builtin_amdgcn_readlane(s0.i, 63);
                 if (lane == 0) {
                     u1d = l63d;
                     u1i = l63i;
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(256) void knn_outer_kernel(const double* __restrict
                 }
                 // new k-th distance
                 const int kl = (k - 1) & 63;
-                tau = (k - 1) < 64 ? __shfl(s0.d, kl) : __shfl(s1.d, kl);
+                tau = (k - 1) < 64 ? readlane_d(s0.d, kl) : readlane_d(s1.d, kl);
             }
         }
     }

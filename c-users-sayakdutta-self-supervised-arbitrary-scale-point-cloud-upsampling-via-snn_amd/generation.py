@@ -13,8 +13,8 @@ not in results:
   shape-keyed neighbour cache makes results depend on the batch shapes (``knn_cache_mode``).
 
 Seed generation (generation.py:112-118: the ``./dense`` subprocess and its text files) is outside
-the hot path; ``upsample`` shells out exactly like the reference, while
-``upsample_seeds`` takes the seed array directly.
+the GPU hot path; ``upsample`` generates the seeds in process (csrc/dense_seeds.cpp:
+same seeds, same order), ``upsample_seeds`` takes a seed array directly.
 """
 import os
 
@@ -34,6 +34,25 @@ def split_batches(n, batch_size):
         out.append((s, e))
         s = e
     return out
+
+
+def dense_seeds(data, spacing):
+    """Seed points of a cloud [N,3] (float64 host array) — in-process equivalent of `./dense spacing N` +
+    np.loadtxt("target.xyz") (generation.py:114-118): same seeds, same order, same 6-decimal values."""
+    import ctypes
+    lib = _lib.load()
+    cloud = np.ascontiguousarray(data, dtype=np.float64)
+    cap = max(1 << 16, 128 * cloud.shape[0])
+    while True:
+        out = np.empty((cap, 3), dtype=np.float64)
+        n = ctypes.c_int64(0)
+        rc = lib.sapcu_dense_seeds_host(cloud.ctypes.data, cloud.shape[0], float(spacing), out.ctypes.data, cap,
+                                        ctypes.byref(n))
+        if rc == -2:                       # buffer too small: n holds the required count
+            cap = int(n.value)
+            continue
+        _lib.check(rc)
+        return out[: n.value].copy()
 
 
 def knn_gather(cloud_dev, queries_dev, k, want_dist=False, want_patch=True):
@@ -104,11 +123,17 @@ class Generator3D6(object):
         seeds = self._dense_seeds(data)
         return self.upsample_seeds(data, seeds)
 
-    # -- seed generation: the reference's subprocess, verbatim behaviour (generation.py:112-118)
+    # -- seed generation (generation.py:112-118).  Default: in process (csrc/dense_seeds.cpp), identical seeds in
+    #    identical order.  seed_source = "subprocess" keeps the reference's mechanics verbatim: os.system("./dense")
+    #    in the working directory, which reads test.xyz and writes target.xyz.
+    seed_source = "inprocess"
+
     def _dense_seeds(self, data):
+        if self.seed_source == "inprocess":
+            return dense_seeds(data, self.dense_spacing)
         if not os.path.exists("./dense"):
             raise FileNotFoundError("./dense not found in the working directory: the reference shells out to it "
-                                    "(generation.py:114-116); build it or call upsample_seeds(data, seeds)")
+                                    "(generation.py:114-116)")
         os.system("./dense %s %d" % (self.dense_spacing, data.shape[0]))
         return np.loadtxt("target.xyz")[:, 0:3]
 

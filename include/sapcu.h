@@ -62,6 +62,15 @@ int sapcu_gather_rotate_f64(const double* cloud, int64_t n, const double* querie
 int sapcu_displace_f64(const double* queries, const float* normals, const float* dist, int64_t b,
                        double* out, void* stream);
 
+/* Seed generation in process (HOST pointers, CPU code) — replaces the `./dense <cell> <n>` subprocess and
+ * its test.xyz / target.xyz text files (generation.py:112-118, dense.cpp:175-252): breadth-first voxel flood
+ * from the occupied voxels, emitting (in the reference's order, rounded to 6 decimals like its "%lf" output)
+ * the voxel centres whose distance to the local triangle fan lies in [0.011, 0.015].
+ * seeds_out_host [capacity,3] f64; *count_host = number of seeds found (SAPCU_ERR_WORKSPACE if > capacity:
+ * call again with a larger buffer).  Row (f-1) of SURVEY.md §8f: not part of the GPU hot path. */
+int sapcu_dense_seeds_host(const double* cloud_host, int64_t n, double cell, double* seeds_out_host,
+                           int64_t capacity, int64_t* count_host);
+
 /* ---------------------------------------------------------------- neuron unit ----------- */
 
 /* Self-feeding T-step neuron loop `for t: x,*st = snn(x,*st)` — fn/snn_coder.py:87-153,

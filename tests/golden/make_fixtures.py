@@ -107,10 +107,50 @@ def hook_outputs(model, names):
     return store, hooks
 
 
+def run_reference_dense(cloud, cell):
+    """Run the reference's own seed generator (dense.cpp compiled by oracle/Makefile) the way generation.py:114-118
+    does — in a scratch directory, through its text files."""
+    dense = os.path.join(ROOT, "oracle", "_ref", "dense")
+    if not os.path.exists(dense):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    work = tempfile.mkdtemp(prefix="sapcu_dense_")
+    try:
+        np.savetxt(os.path.join(work, "test.xyz"), cloud, fmt="%.6f")
+        subprocess.check_call([dense, str(cell), str(cloud.shape[0])], cwd=work)
+        tgt = os.path.join(work, "target.xyz")
+        if os.path.getsize(tgt) == 0:
+            return np.zeros((0, 3))
+        return np.loadtxt(tgt, ndmin=2)[:, 0:3]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def seed_fixture():
+    """Golden outputs of the reference seed generator: small cases in full, the full-size case (sphere N=5000, cell
+    0.004: ~385 k seeds) as count + SHA-256 of the float64 bytes + head/tail rows."""
+    import hashlib
+    out = {}
+    for name, cloud, cell in (("sphere2048_c030", T.sphere_cloud(2048, 0), 0.03), ("torus2048_c020", T.analytic_cloud("torus", 2048, 1), 0.02),
+                              ("cube300_c050", T.analytic_cloud("cube", 300, 2), 0.05), ("tiny7_c050", T.sphere_cloud(7, 3), 0.05)):
+        seeds = run_reference_dense(cloud, cell)
+        out[name] = seeds.reshape(-1, 3)
+        out[name + "_cell"] = np.float64(cell)
+    big = run_reference_dense(T.sphere_cloud(5000, 0), 0.004)
+    out["sphere5000_c004_count"] = np.int64(big.shape[0])
+    out["sphere5000_c004_sha256"] = np.array(hashlib.sha256(np.ascontiguousarray(big, dtype=np.float64).tobytes()).hexdigest())
+    out["sphere5000_c004_head"] = big[:64]
+    out["sphere5000_c004_tail"] = big[-64:]
+    save("dense_seeds.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-e2e", action="store_true")
+    ap.add_argument("--only-seeds", action="store_true", help="only (re)generate dense_seeds.npz")
     args = ap.parse_args()
+    if args.only_seeds:
+        seed_fixture()
+        return
     torch.manual_seed(0)
     torch.set_num_threads(8)
 
@@ -277,6 +317,9 @@ def main():
     pat = G.gather_centre(cloud, q[:64], idx[:64])
     rot = np.stack([np.matmul(mats[j], pat[j].T).T for j in range(64)], 0)
     save("rotation.npz", normals=nr, matrices=mats, rotated_f32=rot.astype(np.float32))
+
+    # ---- 9b. seed generator outputs
+    seed_fixture()
 
     # ---- 10. end-to-end Generator3D6.upsample on sphere N=2048, dense_spacing 0.03 (~900 seeds)
     if not args.skip_e2e:

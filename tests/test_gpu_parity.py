@@ -415,6 +415,11 @@ def test_upsample_end_to_end_against_reference_run(models):
     assert np.array_equal(g["unfiltered"][keep], g["filtered"])
     filtered = gen.upsample_seeds(cloud, seeds)
     assert filtered.dtype == np.float64 and filtered.shape[1] == 3 and abs(filtered.shape[0] - g["filtered"].shape[0]) <= 60
+    # (4) the drop-in entry point: upsample(data[1,N,3]) generates the same seeds in process and gives the same cloud
+    fn._knn_cache.clear()
+    full = gen.upsample(cloud[None])
+    fn._knn_cache.clear()
+    assert np.array_equal(full, gen.upsample_seeds(cloud, seeds))
 
 
 def test_full_batch_4096_properties(models):

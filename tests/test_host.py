@@ -150,3 +150,21 @@ def test_sharded_upsample_all_gather_gloo_world2(n):
         p.join(60)
     assert all(ok for _, ok, _ in res)
     assert res[0][2][0] == 0 and res[1][2][1] == n and res[0][2][1] == res[1][2][0]
+
+
+def test_inprocess_seed_generator_matches_reference_dense_bit_for_bit():
+    """csrc/dense_seeds.cpp against outputs of the reference's own dense.cpp (tests/golden/dense_seeds.npz,
+    made by oracle/_ref/dense): same seeds, same ORDER, same 6-decimal values; full-size case by SHA-256."""
+    import hashlib
+    from sapcu_amd import testing as T
+    g = golden("dense_seeds.npz")
+    cases = (("sphere2048_c030", T.sphere_cloud(2048, 0)), ("torus2048_c020", T.analytic_cloud("torus", 2048, 1)),
+             ("cube300_c050", T.analytic_cloud("cube", 300, 2)), ("tiny7_c050", T.sphere_cloud(7, 3)))
+    for name, cloud in cases:
+        s = gen.dense_seeds(cloud, float(g[name + "_cell"]))
+        assert np.array_equal(s, g[name].reshape(-1, 3)), name
+    big = gen.dense_seeds(T.sphere_cloud(5000, 0), 0.004)
+    assert big.shape[0] == int(g["sphere5000_c004_count"]) == 385582
+    assert hashlib.sha256(big.tobytes()).hexdigest() == str(g["sphere5000_c004_sha256"])
+    assert np.array_equal(big[:64], g["sphere5000_c004_head"]) and np.array_equal(big[-64:], g["sphere5000_c004_tail"])
+    assert np.array_equal(gen.dense_seeds(T.sphere_cloud(2048, 0), 0.03), golden("e2e_upsample.npz")["seeds"])
