@@ -161,6 +161,18 @@ class Generator3D6(object):
             dists[s:e] = d
         return out, normals, dists
 
+    def check_numeric_guards(self):
+        """Raise if a kernel-side assumption was violated during the forwards so far: an activation beyond the f16
+        range of the split-f16 GEMMs, or an open refractory gate in fd (both counted on the device)."""
+        for name, m in (("fn", self.model1), ("fd", self.model2)):
+            if hasattr(m, "gemm_mode"):
+                split, ovf = m.gemm_mode()
+                if ovf:
+                    raise RuntimeError("%s: %d activation values left the f16 range of the split-f16 GEMMs; "
+                                       "set SAPCU_GEMM=f32 for exact-f32 kernels" % (name, ovf))
+            if hasattr(m, "gate_violations") and m.gate_violations():
+                raise RuntimeError("%s: refractory gate found open at t >= 1 (%d events)" % (name, m.gate_violations()))
+
     def outlier_filter(self, pts_dev):
         """Keep points whose mean distance to their 30 nearest (self included) is below
         outlier_threshold x the global mean (generation.py:176-183)."""
@@ -178,6 +190,7 @@ class Generator3D6(object):
         with torch.no_grad():
             refined, _, _ = self.refine(cloud_dev, seeds_dev)
             keep = self.outlier_filter(refined)
+        self.check_numeric_guards()
         refined = refined.cpu().numpy()
         if return_unfiltered:
             return refined[keep], refined

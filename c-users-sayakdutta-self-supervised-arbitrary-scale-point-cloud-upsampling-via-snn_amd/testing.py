@@ -85,15 +85,25 @@ def sphere_cloud(n=5000, seed=0):
 
 
 def grid_queries(count=4096, seed=0, spacing=0.004, band=(0.011, 0.015), radius=0.5):
-    """Cell centres of the seed grid whose distance to the sphere lies in ``band`` (§8d)."""
+    """Cell centres of the seed grid whose distance to the sphere lies in ``band`` (§8d).
+
+    Candidates are drawn 200 000 cells at a time from one PCG64 stream, so the first rows are the same for every
+    ``count`` (the 4096 of the benchmark are a prefix of the 32 768 an 8-rank run needs)."""
     rng = np.random.default_rng(seed)
-    cells = rng.integers(0, int(round(1.0 / spacing)), (200000, 3))
-    q = cells * spacing + spacing / 2 - 0.5
-    off = np.abs(np.linalg.norm(q, axis=1) - radius)
-    q = q[(off > band[0]) & (off < band[1])]
-    if q.shape[0] < count:
-        raise ValueError("not enough grid cells in the band: %d < %d" % (q.shape[0], count))
-    return np.ascontiguousarray(q[:count], dtype=np.float64)
+    side = int(round(1.0 / spacing))
+    got, total = [], 0
+    for _ in range(4096):
+        cells = rng.integers(0, side, (200000, 3))
+        q = cells * spacing + spacing / 2 - 0.5
+        off = np.abs(np.linalg.norm(q, axis=1) - radius)
+        q = q[(off > band[0]) & (off < band[1])]
+        got.append(q)
+        total += q.shape[0]
+        if total >= count:
+            break
+    if total < count:
+        raise ValueError("not enough grid cells in the band: %d < %d" % (total, count))
+    return np.ascontiguousarray(np.concatenate(got, axis=0)[:count], dtype=np.float64)
 
 
 def analytic_cloud(kind, n=2048, seed=0):

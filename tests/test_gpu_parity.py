@@ -331,6 +331,27 @@ def test_gemm_modes_agree_and_stay_in_range(weights, monkeypatch):
     assert (d16 - d32).abs().max() <= TOL
 
 
+def test_chunking_and_tiny_shapes(weights, monkeypatch):
+    """Results do not depend on the internal chunk size (workspace tiling), batch of 1, patches of 5 points."""
+    fn_a, fd_a, sdn, sdd = U.build_gpu_models(weights)
+    fn_a._engine(), fd_a._engine()
+    monkeypatch.setenv("SAPCU_CHUNK", "7")
+    fn_b, fd_b, _, _ = U.build_gpu_models(weights)
+    fn_a.knn_cache_mode = fn_b.knn_cache_mode = "fresh"
+    patch = U.sphere_patches(20, 48, skip=900).to(U.dev())
+    assert torch.equal(fn_a(patch), fn_b(patch))
+    knn = torch.empty((3, 20, 48, 32), dtype=torch.int32, device=U.dev())
+    da = fd_a(patch, taps={"knn": knn})
+    assert torch.equal(da, fd_b(patch, knn_force=knn))
+    assert torch.equal(fn_a(patch[:1]), fn_a(patch)[:1])
+    small = U.sphere_patches(3, 5, skip=40)
+    with torch.no_grad():
+        ref_n = O.fn_forward(sdn, small, U.FN_HP)
+    assert (fn_a(small.to(U.dev())).cpu() - ref_n).abs().max() <= TOL
+    d_gpu, d_forced, _, _, _ = U.fd_forward_forced(fd_a, sdd, small)
+    assert (d_gpu - d_forced).abs().max() <= TOL
+
+
 def test_fd_forced_tables_are_honoured(models):
     _, fd, _, sdd = models
     patch = U.sphere_patches(8, 48, skip=500)
