@@ -108,8 +108,74 @@ __device__ __forceinline__ float neuron_step(float x, NeuronS& s, const NeuronP&
 //   * for t >= 1 the gate `x * (r <= 0)` is closed — soft_spike() >= 0.199 * 2^-72 > 0, so r > 0 — and the
 //     fed-back input contributes exactly +0;  the state updates after the last spike are dead.
 // W chains are advanced together (independent chains = VALU ILP for the GEMM consumers / pos-enc kernel).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// two spikes at once: the multiplies/adds are written on 2-vectors so that hipcc emits the packed
+// v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 (one instruction, two chains); clamp, exp2 and rcp are per lane.
+// Element-wise the arithmetic is exactly soft_spike()'s.
+__device__ __forceinline__ f32x2 soft_spike2(f32x2 d) {
+    f32x2 x;
+    x.x = clampf(d.x, -10.0f, 10.0f);
+    x.y = clampf(d.y, -10.0f, 10.0f);
+    const f32x2 a = (x * x) * -0.72134752044448170368f;
+    const f32x2 b = x * -14.426950408889634074f;
+    f32x2 g, e;
+    g.x = __builtin_amdgcn_exp2f(a.x);
+    g.y = __builtin_amdgcn_exp2f(a.y);
+    e.x = __builtin_amdgcn_exp2f(b.x);
+    e.y = __builtin_amdgcn_exp2f(b.y);
+    g = g * 0.19947114020071633897f;
+    const f32x2 den = e + 1.0f;
+    f32x2 s;
+    s.x = __builtin_amdgcn_rcpf(den.x);
+    s.y = __builtin_amdgcn_rcpf(den.y);
+    return __builtin_elementwise_fma(f32x2{0.5f, 0.5f}, s, g);
+}
+
 template <int W>
 __device__ __forceinline__ void lif_selfloop_n(float (&v)[W], const NeuronP& p, int T) {
+    if constexpr (W % 2 == 0) {
+        // packed form: chains (2u, 2u+1) share every multiply/add instruction
+        constexpr int H = W / 2;
+        f32x2 m[H], r[H], th[H], s[H];
+#pragma unroll
+        for (int u = 0; u < H; ++u) {
+            m[u] = f32x2{v[2 * u], v[2 * u + 1]};
+            s[u] = soft_spike2(m[u] - p.theta0);
+        }
+        if (T > 1) {
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                m[u] = m[u] * (1.0f - s[u]);
+                r[u] = s[u];
+                const f32x2 t0 = p.theta0 + p.adapt * s[u];
+                th[u] = p.theta0 + (t0 - p.theta0) * 0.95f;
+            }
+            for (int t = 1; t < T - 1; ++t) {
+#pragma unroll
+                for (int u = 0; u < H; ++u) {
+                    const f32x2 mm = (m[u] * p.decay) * (1.0f - r[u]);
+                    const f32x2 sp = soft_spike2(mm - th[u]);
+                    m[u] = mm * (1.0f - sp);
+                    r[u] = r[u] * p.rdecay + sp;
+                    const f32x2 t0 = th[u] + p.adapt * sp;
+                    th[u] = p.theta0 + (t0 - p.theta0) * 0.95f;
+                    s[u] = sp;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                const f32x2 mm = (m[u] * p.decay) * (1.0f - r[u]);
+                s[u] = soft_spike2(mm - th[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < H; ++u) {
+            v[2 * u] = s[u].x;
+            v[2 * u + 1] = s[u].y;
+        }
+        return;
+    }
     float m[W], r[W], th[W];
 #pragma unroll
     for (int u = 0; u < W; ++u) {

@@ -133,7 +133,50 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
         int64_t issued = 0;
         for (; issued < 3 && issued < total_steps; ++issued) issue(issued);
 
+        // Fragment pipeline (half a k-step deep): the ds_reads of one k16 half are in flight while the six MFMAs of
+        // the previous half run, and the k-step barrier sits BETWEEN the two halves of a step, so neither the LDS
+        // latency nor the barrier wait leaves the matrix pipe idle.
+        struct Frags {
+            half8 ah, al, wh[2], wl[2];
+        };
+        auto read_frags = [&](int64_t step, int k16, Frags& f) {
+            const unsigned char* st = smem_raw + (int)(step & (RSLOTS - 1)) * RSLOT;
+            const unsigned char* sA = st + arow_l * (RBK * 2) + (((k16 * 2 + h) ^ asw) * 16);
+            f.ah = *reinterpret_cast<const half8*>(sA);
+            f.al = *reinterpret_cast<const half8*>(sA + RPLANE);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned char* sW = st + 2 * RPLANE + wrow_l[j] * (RBK * 2) + (((k16 * 2 + h) ^ wsw[j]) * 16);
+                f.wh[j] = *reinterpret_cast<const half8*>(sW);
+                f.wl[j] = *reinterpret_cast<const half8*>(sW + RPLANE);
+            }
+        };
         f32x16 acc[2];
+        auto mfma6 = [&](const Frags& f) {
+            // alternate the two accumulators so consecutive MFMAs never depend on each other
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.wh[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.wh[1], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wl[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wl[1], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wh[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wh[1], acc[1], 0, 0, 0);
+        };
+        auto wait_landed = [&](int64_t step) {     // this wave's DMAs of `step` have landed
+            const int64_t ahead = issued - step - 1;
+            if (ahead >= 3) wait_vm<12>();
+            else if (ahead == 2) wait_vm<8>();
+            else if (ahead == 1) wait_vm<4>();
+            else wait_vm<0>();
+        };
+        // step 0 of the first tile
+        wait_landed(0);
+        lds_barrier();
+        if (issued < total_steps) {
+            issue(issued);
+            ++issued;
+        }
+        Frags f0, f1;
+        read_frags(0, 0, f0);
         int64_t gstep = 0;
         for (int64_t ti = 0; ti < my_tiles; ++ti) {
 #pragma unroll
@@ -141,33 +184,20 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
             for (int kt = 0; kt < nk; ++kt, ++gstep) {
-                // this wave's DMAs of step gstep have landed when at most (steps issued beyond gstep) x 4 are pending
-                const int64_t ahead = issued - gstep - 1;
-                if (ahead >= 2) wait_vm<8>();
-                else if (ahead == 1) wait_vm<4>();
-                else wait_vm<0>();
-                lds_barrier();                                      // everyone's pieces of step gstep are in; slot (gstep-1)%4 is free
-                if (issued < total_steps) {
-                    issue(issued);
-                    ++issued;
-                }
-                const unsigned char* st = smem_raw + (int)(gstep & (RSLOTS - 1)) * RSLOT;
-                const unsigned char* sA = st + arow_l * (RBK * 2);
-#pragma unroll
-                for (int k16 = 0; k16 < RBK / 16; ++k16) {
-                    const int ca = ((k16 * 2 + h) ^ asw) * 16;
-                    const half8 ah = *reinterpret_cast<const half8*>(sA + ca);
-                    const half8 al = *reinterpret_cast<const half8*>(sA + RPLANE + ca);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const unsigned char* sW = st + 2 * RPLANE + wrow_l[j] * (RBK * 2) + (((k16 * 2 + h) ^ wsw[j]) * 16);
-                        const half8 wh = *reinterpret_cast<const half8*>(sW);
-                        const half8 wl = *reinterpret_cast<const half8*>(sW + RPLANE);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc[j], 0, 0, 0);
+                read_frags(gstep, 1, f1);                           // second half of this step: lands behind mfma6(f0)
+                mfma6(f0);
+                if (gstep + 1 < total_steps) {
+                    wait_landed(gstep + 1);
+                    lds_barrier();                                  // step gstep+1 is in for everyone; slot gstep%4 fully read
+                    if (issued < total_steps) {
+                        issue(issued);                              // step gstep+4 -> slot gstep%4
+                        ++issued;
                     }
+                    read_frags(gstep + 1, 0, f0);                   // first half of the next step: lands behind mfma6(f1)
+                } else {
+                    lds_barrier();                                  // keep the barrier count per step uniform
                 }
+                mfma6(f1);
             }
             // hand-off in two halves through the 32 KiB area (the ring keeps streaming underneath)
 #pragma unroll
@@ -185,6 +215,7 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
         int prev_col0 = 0;
         // pieces (2 elements) per k-step so that the 16 pieces are done within the next tile's nk steps
         const int pper = (16 + nk - 1) / nk;
+        lds_barrier();                                             // pairs with the producers' "step 0 has landed"
         for (int64_t ti = 0; ti <= my_tiles; ++ti) {               // last round = drain (no barriers on either side)
             const bool have = ti < my_tiles;
             const bool cons_work = prev_row0 >= 0;
@@ -228,8 +259,7 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
                 issue_gather(0);
             }
             for (int kt = 0; kt < nk; ++kt) {
-                if (have) lds_barrier();
-                if (!cons_work) continue;
+                if (cons_work)
                 for (int pi = kt * pper; pi < (kt + 1) * pper && pi < 16; ++pi) {
                     float cq[2] = {nq[0], nq[1]}, ckf[2] = {nkf[0], nkf[1]};
                     if (pi + 1 < 16) issue_gather(pi + 1);
@@ -254,6 +284,7 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
                         }
                     }
                 }
+                if (have) lds_barrier();                            // the producers' mid-step barrier of this k-step
             }
             if (!have) break;
             // take this tile's accumulators: column tile 1 to registers, then column tile 0 stays in the area
