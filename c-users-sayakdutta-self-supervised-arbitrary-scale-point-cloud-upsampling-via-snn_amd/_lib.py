@@ -30,6 +30,8 @@ _SIGNATURES = {
     "sapcu_knn_gather_f64": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sapcu_gather_rotate_f64": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "sapcu_displace_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "sapcu_fps_workspace_bytes": (c_int64, [c_int64]),
+    "sapcu_fps_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     "sapcu_dense_seeds_host": (c_int, [c_void_p, c_int64, c_double, c_void_p, c_int64, POINTER(c_int64)]),
     "sapcu_neuron_selfloop": (c_int, [c_void_p, c_int64, c_int, c_int] + [c_void_p] * 6 + [c_void_p] * 4 + [c_void_p]),
     "sapcu_patch_knn": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

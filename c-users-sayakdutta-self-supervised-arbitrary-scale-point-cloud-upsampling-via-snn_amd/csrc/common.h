@@ -277,4 +277,9 @@ int launch_gather_rotate(const double* cloud, int64_t n, const double* q, int64_
                          int k, const float* normals, float* patch, hipStream_t st);
 int launch_displace(const double* q, const float* nrm, const float* d, int64_t b, double* out, hipStream_t st);
 
+// farthest-point sampling (fps.hip)
+size_t fps_workspace_bytes(int npoint);
+int launch_fps(const float* xyz, int64_t n, int npoint, int start, int64_t* out, void* ws, hipStream_t st);
+int fps_failed(const void* ws, int npoint, int* flag);
+
 }  // namespace sapcu

@@ -469,6 +469,32 @@ int sapcu_displace_f64(const double* queries, const float* normals, const float*
     return launch_displace(queries, normals, dist, b, out, (hipStream_t)stream);
 }
 
+int64_t sapcu_fps_workspace_bytes(int64_t npoint) { return npoint < 0 ? -1 : (int64_t)fps_workspace_bytes((int)npoint); }
+
+int sapcu_fps_f32(const float* xyz, int64_t n, int64_t npoint, int64_t* idx_out, void* workspace, int64_t workspace_bytes,
+                  void* stream) {
+    SAPCU_CHECK_ARG(npoint >= 0 && npoint <= n && n < (int64_t)1 << 31, "fps: need 0 <= npoint <= n < 2^31 (n=%lld npoint=%lld)",
+                    (long long)n, (long long)npoint);
+    if (npoint == 0) return SAPCU_OK;
+    SAPCU_CHECK_ARG(xyz && idx_out && workspace, "fps: null pointer");
+    if (workspace_bytes < (int64_t)fps_workspace_bytes((int)npoint)) {
+        set_error("fps: workspace of %lld bytes, need %lld", (long long)workspace_bytes,
+                  (long long)fps_workspace_bytes((int)npoint));
+        return SAPCU_ERR_WORKSPACE;
+    }
+    int rc = launch_fps(xyz, n, (int)npoint, (int)(n / 2), idx_out, workspace, (hipStream_t)stream);
+    if (rc != SAPCU_OK) return rc;
+    SAPCU_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    int flag = 0;
+    rc = fps_failed(workspace, (int)npoint, &flag);
+    if (rc != SAPCU_OK) return rc;
+    if (flag) {
+        set_error("fps: a workgroup of the persistent grid never arrived at the step barrier (grid not resident)");
+        return SAPCU_ERR_HIP;
+    }
+    return SAPCU_OK;
+}
+
 int sapcu_neuron_selfloop(const float* x, int64_t rows, int channels, int steps, const float* membrane_decay,
                           const float* threshold_adapt, const float* refractory_decay, const float* threshold_base,
                           const float* delta_T, const float* theta_rh, float* spikes_out, float* membrane_out,

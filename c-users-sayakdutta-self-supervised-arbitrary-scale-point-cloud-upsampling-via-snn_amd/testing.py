@@ -125,3 +125,32 @@ def analytic_cloud(kind, n=2048, seed=0):
     else:
         raise ValueError(kind)
     return np.round(p, 6).astype(np.float64)
+
+
+# ---------------------------------------------------------------------------------------------
+# farthest-point-sampling cases (tests/golden/fps.npz holds the reference's indices for each)
+# ---------------------------------------------------------------------------------------------
+FPS_CASES = ("sphere2048", "torus1000_all", "dup200", "lattice216", "tiny5", "one", "big100k", "big400k")
+
+
+def fps_case(name):
+    """(cloud float64 [N,3], npoint) of a named FPS case; deterministic, so the inputs are not stored."""
+    rng = np.random.default_rng([7, FPS_CASES.index(name)])
+    if name == "sphere2048":          # denormalised like generate.py:90 leaves it
+        return sphere_cloud(2048, 0) * 37.5 + np.array([3.0, -8.0, 0.25]), 256
+    if name == "torus1000_all":       # npoint == N
+        return analytic_cloud("torus", 1000, 1), 1000
+    if name == "dup200":              # 5 copies of 40 points: ties at distance 0 once 40 are taken
+        return np.repeat(rng.standard_normal((40, 3)), 5, axis=0), 60
+    if name == "lattice216":          # exact ties at non-zero distance
+        return np.stack(np.meshgrid(*[np.arange(6.0)] * 3, indexing="ij"), -1).reshape(-1, 3), 100
+    if name == "tiny5":
+        return rng.standard_normal((5, 3)), 3
+    if name == "one":
+        return rng.standard_normal((1, 3)), 1
+    if name == "big100k":
+        return rng.standard_normal((100000, 3)) * np.array([1.0, 0.5, 0.25]), 2048
+    if name == "big400k":             # the size of a refined cloud (generation.py: ~385 k points)
+        base = sphere_cloud(5000, 0)
+        return base[rng.integers(0, 5000, 400000)] + 0.01 * rng.standard_normal((400000, 3)), 512
+    raise KeyError(name)

@@ -62,6 +62,17 @@ int sapcu_gather_rotate_f64(const double* cloud, int64_t n, const double* querie
 int sapcu_displace_f64(const double* queries, const float* normals, const float* dist, int64_t b,
                        double* out, void* stream);
 
+/* Farthest-point sampling of the refined cloud down to the target count — generate.py:56-74
+ * (`farthest_point_sample`): f32 points, start index n/2, running minimum of the squared distance
+ * ((dx^2+dy^2)+dz^2, separately rounded) to the chosen set, arg-max with ties to the smallest index.
+ * One persistent launch (one workgroup per CU, points and distances in registers, one 64-bit atomicMax
+ * and one counter barrier per step).  xyz [n,3] f32 device, idx_out [npoint] int64 device; the
+ * workspace holds sapcu_fps_workspace_bytes(npoint) bytes.  n <= #CU * 8192 (2,097,152 on MI355X).
+ * Synchronises `stream` before returning (the indices go to the host next, generate.py:74). */
+int64_t sapcu_fps_workspace_bytes(int64_t npoint);
+int sapcu_fps_f32(const float* xyz, int64_t n, int64_t npoint, int64_t* idx_out, void* workspace,
+                  int64_t workspace_bytes, void* stream);
+
 /* Seed generation in process (HOST pointers, CPU code) — replaces the `./dense <cell> <n>` subprocess and
  * its test.xyz / target.xyz text files (generation.py:112-118, dense.cpp:175-252): breadth-first voxel flood
  * from the occupied voxels, emitting (in the reference's order, rounded to 6 decimals like its "%lf" output)

@@ -143,13 +143,50 @@ def seed_fixture():
     save("dense_seeds.npz", **out)
 
 
+def fps_fixture():
+    """Golden outputs of the reference's own ``normalize_pointcloud`` / ``farthest_point_sample`` (generate.py:43-74).
+    generate.py imports h5py (absent here, never used on this path) and hard-codes device 'cuda' (no GPU in this
+    container): the module is imported with an empty h5py stand-in and, for the duration of the calls, tensors
+    asked to move to 'cuda' stay on the CPU — the arithmetic is torch's own either way."""
+    sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+    import generate as ref_generate
+    real_to = torch.Tensor.to
+
+    def to_cpu(self, *a, **kw):
+        a = tuple("cpu" if (isinstance(x, str) and x.startswith("cuda")) else x for x in a)
+        return real_to(self, *a, **kw)
+
+    cases = {name: T.fps_case(name) for name in T.FPS_CASES}
+    out = {"names": np.array(list(cases))}
+    torch.Tensor.to = to_cpu
+    try:
+        for name, (cloud, npoint) in cases.items():
+            idx = ref_generate.farthest_point_sample(cloud, npoint)
+            out[name + "_idx"] = idx.astype(np.int64)
+            out[name + "_npoint"] = np.int64(npoint)
+            print("fps", name, cloud.shape, npoint, idx[:6])
+        c, loc, scale = ref_generate.normalize_pointcloud(cases["sphere2048"][0])
+        out["norm_cloud"], out["norm_loc"], out["norm_scale"] = c, loc, np.float64(scale)
+        out["norm_in"] = cases["sphere2048"][0]
+        flat = np.tile(np.array([[1.0, 2.0, 3.0]]), (4, 1))          # zero extent: scale_inv falls back to 1
+        c, loc, scale = ref_generate.normalize_pointcloud(flat)
+        out["flat_in"], out["flat_cloud"], out["flat_loc"], out["flat_scale"] = flat, c, loc, np.float64(scale)
+    finally:
+        torch.Tensor.to = real_to
+    save("fps.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-e2e", action="store_true")
+    ap.add_argument("--only-fps", action="store_true", help="only (re)generate fps.npz")
     ap.add_argument("--only-seeds", action="store_true", help="only (re)generate dense_seeds.npz")
     args = ap.parse_args()
     if args.only_seeds:
         seed_fixture()
+        return
+    if args.only_fps:
+        fps_fixture()
         return
     torch.manual_seed(0)
     torch.set_num_threads(8)

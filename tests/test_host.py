@@ -168,3 +168,23 @@ def test_inprocess_seed_generator_matches_reference_dense_bit_for_bit():
     assert hashlib.sha256(big.tobytes()).hexdigest() == str(g["sphere5000_c004_sha256"])
     assert np.array_equal(big[:64], g["sphere5000_c004_head"]) and np.array_equal(big[-64:], g["sphere5000_c004_tail"])
     assert np.array_equal(gen.dense_seeds(T.sphere_cloud(2048, 0), 0.03), golden("e2e_upsample.npz")["seeds"])
+
+
+def test_pipeline_normalisation_and_fps_argument_checks():
+    """generate.py:43-54 mirror is bit-identical to the reference run; FPS has no CPU path and checks its arguments."""
+    from sapcu_amd import pipeline
+    g = golden("fps.npz")
+    c, loc, scale = pipeline.normalize_pointcloud(g["norm_in"])
+    np.testing.assert_array_equal(c, g["norm_cloud"])
+    np.testing.assert_array_equal(loc, g["norm_loc"])
+    assert scale == float(g["norm_scale"])
+    c, loc, scale = pipeline.normalize_pointcloud(g["flat_in"])
+    np.testing.assert_array_equal(c, g["flat_cloud"])
+    assert scale == 0.0
+    with pytest.raises(ValueError):
+        pipeline.farthest_point_sample_device(torch.zeros(8, 3), 4)          # CPU tensor: no CPU path
+    lib = _lib.load()
+    assert lib.sapcu_fps_workspace_bytes(100) >= 100 * 8 + 8
+    assert lib.sapcu_fps_f32(None, 10, 11, None, None, 0, None) == -1       # npoint > n
+    assert lib.sapcu_fps_f32(None, 10, 4, None, None, 0, None) == -1        # null pointers
+    assert lib.sapcu_fps_f32(None, 10, 0, None, None, 0, None) == 0         # nothing to sample

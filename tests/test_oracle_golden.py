@@ -177,3 +177,23 @@ def test_end_to_end_upsample_against_reference_run(weights):
     np.testing.assert_allclose(refined, g["unfiltered"], rtol=0, atol=1e-6)
     keep = G.outlier_filter(g["unfiltered"], 1.5)
     assert np.array_equal(g["unfiltered"][keep], g["filtered"])
+
+
+def test_fps_and_normalisation_against_reference_run():
+    """generate.py:43-74 — the restatement reproduces the reference's own sampled indices (ties included)."""
+    from oracle import fps_path as F
+    from sapcu_amd import testing as T
+    g = golden("fps.npz")
+    for name in g["names"]:
+        if name == "big400k":
+            continue                                   # 400 k x 512 numpy steps: GPU-suite case
+        cloud, npoint = T.fps_case(str(name))
+        assert npoint == int(g[name + "_npoint"])
+        np.testing.assert_array_equal(F.farthest_point_sample(cloud, npoint), g[name + "_idx"], err_msg=str(name))
+    c, loc, scale = F.normalize_pointcloud(g["norm_in"])
+    np.testing.assert_array_equal(c, g["norm_cloud"])
+    np.testing.assert_array_equal(loc, g["norm_loc"])
+    assert scale == float(g["norm_scale"])
+    c, loc, scale = F.normalize_pointcloud(g["flat_in"])
+    np.testing.assert_array_equal(c, g["flat_cloud"])
+    assert scale == 0.0 == float(g["flat_scale"])
