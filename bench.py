@@ -117,7 +117,8 @@ def roofline_leg(dev, reps=3):
     traffic, src = None, None
     for cand in sorted([f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json")], reverse=True):
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", cand))).get("gemm_ring_kernel<6>")
+            recs = json.load(open(os.path.join(ROOT, "profiles", cand)))
+            rec = recs.get("gemm_ring_kernel<6, true>") or recs.get("gemm_ring_kernel<6>")
             if rec:
                 traffic, src = float(rec["hbm_bytes_per_launch"]), "profiles/" + cand
                 break

@@ -40,7 +40,8 @@ struct NeuronP {   // clamped per-channel parameters
     float dT, rh;  // EIF only
 };
 
-__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+// v_med3_f32: one instruction; equals fminf(fmaxf(x, lo), hi) for every non-NaN x (lo <= hi)
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
 __device__ __forceinline__ NeuronP load_lif(const float* __restrict__ p4, int stride, int c) {
     // p4: [4][stride] raw membrane_decay, threshold_adapt, refractory_decay, threshold_base
@@ -207,6 +208,50 @@ __device__ __forceinline__ void lif_selfloop_n(float (&v)[W], const NeuronP& p, 
         const float mm = __fmul_rn(__fmul_rn(m[u], p.decay), __fsub_rn(1.0f, r[u]));
         v[u] = soft_spike(__fsub_rn(mm, th[u]));
     }
+}
+
+// Same loop for chains that sit in DIFFERENT channels (a lane of the ring GEMM's consumer holds 4 consecutive
+// columns of one row): the parameters are 2-vectors too.  Element-wise identical to lif_selfloop_n.
+struct NeuronP2 {
+    f32x2 decay, adapt, rdecay, theta0;
+};
+
+template <int H>
+__device__ __forceinline__ void lif_selfloop_pairs(f32x2 (&v)[H], const NeuronP2 (&p)[H], int T) {
+    f32x2 m[H], r[H], th[H], s[H];
+#pragma unroll
+    for (int u = 0; u < H; ++u) {
+        m[u] = v[u];
+        s[u] = soft_spike2(m[u] - p[u].theta0);
+    }
+    if (T > 1) {
+#pragma unroll
+        for (int u = 0; u < H; ++u) {
+            m[u] = m[u] * (1.0f - s[u]);
+            r[u] = s[u];
+            const f32x2 t0 = p[u].theta0 + p[u].adapt * s[u];
+            th[u] = p[u].theta0 + (t0 - p[u].theta0) * 0.95f;
+        }
+        for (int t = 1; t < T - 1; ++t) {
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                const f32x2 mm = (m[u] * p[u].decay) * (1.0f - r[u]);
+                const f32x2 sp = soft_spike2(mm - th[u]);
+                m[u] = mm * (1.0f - sp);
+                r[u] = r[u] * p[u].rdecay + sp;
+                const f32x2 t0 = th[u] + p[u].adapt * sp;
+                th[u] = p[u].theta0 + (t0 - p[u].theta0) * 0.95f;
+                s[u] = sp;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < H; ++u) {
+            const f32x2 mm = (m[u] * p[u].decay) * (1.0f - r[u]);
+            s[u] = soft_spike2(mm - th[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < H; ++u) v[u] = s[u];
 }
 
 __device__ __forceinline__ float lif_selfloop(float x, const NeuronP& p, int T) {

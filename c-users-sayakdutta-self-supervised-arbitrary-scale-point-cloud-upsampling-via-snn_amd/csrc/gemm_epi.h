@@ -74,6 +74,155 @@ __device__ __forceinline__ void epilogue_group(const GemmArgs& g, const float (&
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row layout (ring GEMM consumers): a lane holds FOUR CONSECUTIVE COLUMNS of one row, so every global access
+// of the epilogue is 8 or 16 bytes per lane (f32: one 16-byte store; split rows: two 8-byte stores; q/k
+// gathers and residuals: 16-byte loads).  The vector-memory path handles a wave instruction at the same
+// rate whatever its width, so this is 4x fewer address cycles than the one-column-per-lane layout above.
+// ---------------------------------------------------------------------------------------------
+struct ColParams4 {          // bias and RAW neuron parameters of 4 consecutive columns (clamped at use, so that a
+    float4 bias;             // reload can stay in flight until the next piece needs it)
+    float4 decay, adapt, rdecay, theta0;
+};
+
+// VEC = false: any n / alignment (element-wise accesses, columns >= n masked) — odd shapes only
+template <bool VEC>
+__device__ __forceinline__ float4 ld4_cols(const float* p, int col, int n) {
+    if (VEC) return ld4(p + col);
+    float4 r;
+    r.x = col < n ? p[col] : 0.f;
+    r.y = col + 1 < n ? p[col + 1] : 0.f;
+    r.z = col + 2 < n ? p[col + 2] : 0.f;
+    r.w = col + 3 < n ? p[col + 3] : 0.f;
+    return r;
+}
+
+template <int EPI, bool VEC>
+__device__ __forceinline__ ColParams4 load_col_params4(const GemmArgs& g, int col, bool valid) {
+    ColParams4 c;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    c.bias = (valid && g.bias) ? ld4_cols<VEC>(g.bias, col, g.n) : z;
+    c.decay = c.adapt = c.rdecay = c.theta0 = z;
+    if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) {
+        const int cc = valid ? col : 0;
+        c.decay = ld4_cols<VEC>(g.lif, cc, g.n);
+        c.adapt = ld4_cols<VEC>(g.lif + g.n, cc, g.n);
+        c.rdecay = ld4_cols<VEC>(g.lif + 2 * (int64_t)g.n, cc, g.n);
+        c.theta0 = ld4_cols<VEC>(g.lif + 3 * (int64_t)g.n, cc, g.n);
+    }
+    return c;
+}
+
+__device__ __forceinline__ void clamp_col_params4(const ColParams4& c, NeuronP2 (&np)[2]) {
+    np[0].decay = f32x2{clampf(c.decay.x, 0.1f, 0.99f), clampf(c.decay.y, 0.1f, 0.99f)};
+    np[1].decay = f32x2{clampf(c.decay.z, 0.1f, 0.99f), clampf(c.decay.w, 0.1f, 0.99f)};
+    np[0].adapt = f32x2{clampf(c.adapt.x, 0.001f, 0.1f), clampf(c.adapt.y, 0.001f, 0.1f)};
+    np[1].adapt = f32x2{clampf(c.adapt.z, 0.001f, 0.1f), clampf(c.adapt.w, 0.001f, 0.1f)};
+    np[0].rdecay = f32x2{clampf(c.rdecay.x, 0.1f, 0.95f), clampf(c.rdecay.y, 0.1f, 0.95f)};
+    np[1].rdecay = f32x2{clampf(c.rdecay.z, 0.1f, 0.95f), clampf(c.rdecay.w, 0.1f, 0.95f)};
+    np[0].theta0 = f32x2{c.theta0.x, c.theta0.y};
+    np[1].theta0 = f32x2{c.theta0.z, c.theta0.w};
+}
+
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+// 4 consecutive values of a row
+template <bool VEC>
+__device__ __forceinline__ void store_f32x4(float* base, int64_t row, int ld, int col, int n, const float (&v)[4]) {
+    if (VEC) {
+        *reinterpret_cast<float4*>(base + row * ld + col) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (col + u < n) base[row * ld + col + u] = v[u];
+    }
+}
+
+// ... of a split row: hi halves at half-index col, lo halves at ld + col (8-byte stores)
+template <bool VEC>
+__device__ __forceinline__ void store_split4(float* base, int64_t row, int ld, int col, int n, const float (&v)[4]) {
+    if (!VEC) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (col + u < n) store_split(base, row, ld, col + u, v[u]);
+        return;
+    }
+    _Float16* rp = reinterpret_cast<_Float16*>(base + row * ld);
+    half4 hi, lo;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        hi[u] = (_Float16)v[u];
+        lo[u] = (_Float16)(v[u] - (float)hi[u]);
+    }
+    *reinterpret_cast<half4*>(rp + col) = hi;
+    *reinterpret_cast<half4*>(rp + ld + col) = lo;
+}
+
+// acc = columns col..col+3 of `row` (row < g.r and col < g.n checked by the caller; n % 4 == 0).
+// Two halves so that the caller can issue loads (next column parameters) between the arithmetic and the stores.
+template <int EPI, bool VEC>
+__device__ __forceinline__ void epilogue_row4_compute(const GemmArgs& g, const float4 acc, int64_t row, int col,
+                                                      const ColParams4& cp, float (&v)[4]) {
+    v[0] = __fadd_rn(acc.x, cp.bias.x);
+    v[1] = __fadd_rn(acc.y, cp.bias.y);
+    v[2] = __fadd_rn(acc.z, cp.bias.z);
+    v[3] = __fadd_rn(acc.w, cp.bias.w);
+    float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == EPI_RESID || EPI == EPI_RESID_GELU) res = ld4_cols<VEC>(g.resid + row * g.ldr, col, g.n);
+#ifndef SAPCU_ABL_NO_LIF          // (profiling ablations: profiles/ablate.sh)
+    if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) {
+        f32x2 pv[2] = {f32x2{v[0], v[1]}, f32x2{v[2], v[3]}};
+        NeuronP2 np[2];
+        clamp_col_params4(cp, np);
+        lif_selfloop_pairs<2>(pv, np, g.lif_T);
+        v[0] = pv[0].x; v[1] = pv[0].y; v[2] = pv[1].x; v[3] = pv[1].y;
+    }
+#endif
+    const float rs[4] = {res.x, res.y, res.z, res.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (EPI == EPI_GELU) v[u] = gelu_erf(v[u]);
+        if (EPI == EPI_LRELU) v[u] = lrelu02(v[u]);
+        if (EPI == EPI_RESID) v[u] = __fadd_rn(v[u], rs[u]);
+        if (EPI == EPI_RESID_GELU) v[u] = gelu_erf(__fadd_rn(v[u], rs[u]));
+    }
+}
+
+template <int EPI, bool VEC>
+__device__ __forceinline__ void epilogue_row4_store(const GemmArgs& g, const float (&v)[4], int64_t row, int col,
+                                                    const float4 q, const float4 kf) {
+    // attn_in = q_i - k_j + pos_enc (fn/snn_coder.py:368), operand of the next GEMM.  Formed BEFORE the first
+    // store of this piece: the wait for the gathers then has only older stores ahead of it in the (in-order)
+    // vector-memory counter, instead of draining this piece's own stores.
+    float ai[4] = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_LIF_ATTN) {
+        ai[0] = __fadd_rn(__fsub_rn(q.x, kf.x), v[0]);
+        ai[1] = __fadd_rn(__fsub_rn(q.y, kf.y), v[1]);
+        ai[2] = __fadd_rn(__fsub_rn(q.z, kf.z), v[2]);
+        ai[3] = __fadd_rn(__fsub_rn(q.w, kf.w), v[3]);
+        asm volatile("" : "+v"(ai[0]), "+v"(ai[1]), "+v"(ai[2]), "+v"(ai[3])::"memory");
+    }
+    if (g.c_split) {
+        store_split4<VEC>(g.c, row, g.ldc, col, g.n, v);
+        if (EPI != EPI_LIF && EPI != EPI_LIF_ATTN && g.ovf) {
+            float big = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (VEC || col + u < g.n) big = fmaxf(big, fabsf(v[u]));     // fmaxf drops a NaN: test it separately
+            const bool nan = (VEC || col < g.n) && !(v[0] == v[0] && v[1] == v[1] && v[2] == v[2] && v[3] == v[3]);
+            if (!(big < 65504.0f) || nan) atomicAdd(g.ovf, 1);
+        }
+    } else {
+        store_f32x4<VEC>(g.c, row, g.ldc, col, g.n, v);
+    }
+#ifndef SAPCU_ABL_NO_C2
+    if (EPI == EPI_LIF_ATTN) {
+        if (g.c2_split) store_split4<VEC>(g.c2, row, g.ldc, col, g.n, ai);
+        else store_f32x4<VEC>(g.c2, row, g.ldc, col, g.n, ai);
+    }
+#endif
+}
+
 template <int EPI>
 __device__ __forceinline__ void epilogue_group4(const GemmArgs& g, const float (&acc)[4], int64_t row, int col,
                                                 float bias, const NeuronP& np, const float (&q)[4],

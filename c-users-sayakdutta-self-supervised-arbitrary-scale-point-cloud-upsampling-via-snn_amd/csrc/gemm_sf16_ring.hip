@@ -16,11 +16,15 @@
 //   waves 0-7   PRODUCERS, 4x2 sub-tiles of 32x64 (2 MFMA tiles, 32 accumulator registers each).
 //               k-step = 32: per step  s_waitcnt vmcnt(keep 2 steps in flight) -> barrier -> issue the DMAs of
 //               step g+3 into the slot read at step g-1 -> 12 MFMAs from slot g%4.
-//   waves 8-15  CONSUMERS (two VALU waves per SIMD): epilogue of the PREVIOUS tile from registers, in
-//               2-element pieces between the k-step barriers (K = 512: 16 steps, 16 pieces: balanced).
-//   hand-off    through a 32 KiB LDS area in two halves: first the column-tile-1 half (consumers copy its 16
+//   waves 8-15  CONSUMERS (two VALU waves per SIMD): epilogue of the PREVIOUS tile, in 8 pieces of one float4
+//               (one row x 4 consecutive columns per lane) between the k-step barriers, so that every global
+//               access of the epilogue is 8-16 bytes per lane (gemm_epi.h, epilogue_row4).
+//   hand-off    through a 32 KiB LDS area in two halves: first the column-tile-1 half (consumers copy their 16
 //               values to registers), then the column-tile-0 half, which STAYS there and is read piece by piece
-//               during the next tile — the ring keeps streaming underneath.
+//               during the next tile — the ring keeps streaming underneath.  The area is where the accumulators
+//               change from the MFMA layout (lane = column, register = row) to the row layout: producers write
+//               row rr of their 32x32 block at slot rr ^ ((rr>>2)&1) (pitch 32 floats: the two rows of one
+//               ds_write_b32 land in different bank halves), consumers read float4s (two rows per 16 lanes).
 //   LDS         4 slots x (A_hi | A_lo | W_hi | W_lo) x [128 rows][32 halves] = 128 KiB + 32 KiB hand-off = 160 KiB.
 //               64-byte rows, 16-byte chunk index XOR-swizzled by (row>>2)&3: conflict-free ds_read_b128; the DMA
 //               destination is lane-linear, so the swizzle is applied to each lane's SOURCE address.
@@ -49,15 +53,7 @@ __device__ __forceinline__ void wait_vm() {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// one 2-element consumer piece of column tile 1 with STATIC register indices (Q = 0..7: registers 2Q, 2Q+1)
-template <int EPI, int Q>
-__device__ __forceinline__ void ring_reg_piece(const GemmArgs& g, const float (&cacc)[16], int64_t row, int col, float bias,
-                                               const NeuronP& np, const float (&cq)[2], const float (&ckf)[2]) {
-    const float a[2] = {cacc[2 * Q], cacc[2 * Q + 1]};
-    epilogue_group<EPI, 2>(g, a, row, col, bias, np, cq, ckf);
-}
-
-template <int EPI>
+template <int EPI, bool VEC>
 __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     float* hand = reinterpret_cast<float*>(smem_raw + RSLOTS * RSLOT);
@@ -205,84 +201,81 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
                 const int j = 1 - jj;                               // column tile 1 first (goes to registers), then 0 (stays)
                 lds_barrier();                                      // consumers are done with what the area held
 #pragma unroll
-                for (int e = 0; e < 16; ++e) hand[(pw * 16 + e) * 64 + lane] = __fmul_rn(acc[j][e], 0.0625f);   // undo W x 16
+                for (int e = 0; e < 16; ++e) {
+                    const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;  // row of the 32x32 block held in register e
+                    hand[pw * 1024 + (rr ^ h) * 32 + r32] = __fmul_rn(acc[j][e], 0.0625f);   // undo W x 16
+                }
                 lds_barrier();                                      // half j is ready
             }
         }
     } else {
-        float cacc[16];                // column tile 1 of the previous tile; column tile 0 stays in the hand-off area
+        // row layout of this wave's 32x64 sub-tile: lane = (row slot s = lane>>3, column group c4 = lane&7);
+        // piece pi = 4*j + p covers row p*8 + s, columns j*32 + c4*4 .. +3 of the sub-tile
+        const int c4 = lane & 7, rs = lane >> 3;
+        auto hand_at = [&](int p) -> const float4* {
+            const int rr = p * 8 + rs;
+            return reinterpret_cast<const float4*>(hand + pw * 1024 + (rr ^ ((rr >> 2) & 1)) * 32 + c4 * 4);
+        };
+        float4 cacc[4];                // column tile 1 of the previous tile; column tile 0 stays in the hand-off area
         int64_t prev_row0 = -1;
         int prev_col0 = 0;
-        // pieces (2 elements) per k-step so that the 16 pieces are done within the next tile's nk steps
-        const int pper = (16 + nk - 1) / nk;
+        const int pper = (8 + nk - 1) / nk;                        // pieces per k-step: all 8 within the next tile's k-loop
         lds_barrier();                                             // pairs with the producers' "step 0 has landed"
         for (int64_t ti = 0; ti <= my_tiles; ++ti) {               // last round = drain (no barriers on either side)
             const bool have = ti < my_tiles;
             const bool cons_work = prev_row0 >= 0;
-            float cbias[2];
-            NeuronP cnp[2];
+            // Column parameters (bias + 4 neuron rows of this lane's 4 columns) are loaded at the first piece of each
+            // column tile; the q/k gathers of a piece are issued at its start and consumed after the neuron loop
+            // (~150 VALU instructions of cover).  Nothing loaded is carried across pieces: a loop-carried in-flight
+            // register makes the compiler park a vmcnt(0) behind every piece's stores.
             bool ccol[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = prev_col0 + wn * 64 + j * 32 + r32;
-                ccol[j] = cons_work && col < g.n;
-                cbias[j] = settle((ccol[j] && g.bias) ? g.bias[col] : 0.f);
-                cnp[j] = NeuronP{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) {
-                    cnp[j] = load_lif(g.lif, g.n, ccol[j] ? col : 0);
-                    cnp[j].theta0 = settle(cnp[j].theta0);
-                }
-            }
-            // EPI_LIF_ATTN: lane l holds the (q row, k row) pair of tile row wm*32 + (l & 31); a piece fetches its
-            // two pairs with ds_bpermute and its q/k gathers are issued one piece AHEAD.
-            int2 tabrow = make_int2(0, 0);
-            float nq[2] = {0.f, 0.f}, nkf[2] = {0.f, 0.f};
-            auto issue_gather = [&](int pi) {      // piece pi: column tile j = pi>>3, accumulator registers e0 = 2*(pi&7), +1
-                if (EPI != EPI_LIF_ATTN) return;
-                const int j = pi >> 3, e0 = 2 * (pi & 7);
-                const int col = prev_col0 + wn * 64 + j * 32 + r32;
-                const int lrow = (e0 & 3) + 8 * (e0 >> 2) + 4 * h;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int qr = __shfl(tabrow.x, lrow + u);
-                    const int kr = __shfl(tabrow.y, lrow + u);
-                    const bool ok = col < g.n && (prev_row0 + wm * 32 + lrow + u) < g.r;
-                    nq[u] = ok ? g.q[(int64_t)qr * g.ldq + col] : 0.f;
-                    nkf[u] = ok ? g.kf[(int64_t)kr * g.ldq + col] : 0.f;
-                }
-            };
+            for (int j = 0; j < 2; ++j) ccol[j] = cons_work && (prev_col0 + wn * 64 + j * 32 + c4 * 4) < g.n;
+            ColParams4 cp = load_col_params4<EPI, VEC>(g, 0, false);
+            int2 tabrow = make_int2(0, 0);       // EPI_LIF_ATTN: lane l holds the (q row, k row) pair of tile row wm*32 + (l & 31)
             if (cons_work && EPI == EPI_LIF_ATTN) {
                 const int64_t trow = prev_row0 + wm * 32 + (lane & 31);
                 if (trow < g.r) tabrow = g.tab[trow];
                 tabrow.x = __builtin_bit_cast(int, settle(__builtin_bit_cast(float, tabrow.x)));
                 tabrow.y = __builtin_bit_cast(int, settle(__builtin_bit_cast(float, tabrow.y)));
-                issue_gather(0);
             }
             for (int kt = 0; kt < nk; ++kt) {
                 if (cons_work)
-                for (int pi = kt * pper; pi < (kt + 1) * pper && pi < 16; ++pi) {
-                    float cq[2] = {nq[0], nq[1]}, ckf[2] = {nkf[0], nkf[1]};
-                    if (pi + 1 < 16) issue_gather(pi + 1);
-                    const int j = pi >> 3, e0 = 2 * (pi & 7);
-                    if (!(j ? ccol[1] : ccol[0])) continue;
-                    const int64_t row = prev_row0 + wm * 32 + (e0 & 3) + 8 * (e0 >> 2) + 4 * h;
-                    if (row >= g.r) continue;
-                    const int col = prev_col0 + wn * 64 + j * 32 + r32;
-                    if (pi < 8) {        // column tile 0: straight from the hand-off area
-                        const float a[2] = {hand[(pw * 16 + e0) * 64 + lane], hand[(pw * 16 + e0 + 1) * 64 + lane]};
-                        epilogue_group<EPI, 2>(g, a, row, col, cbias[0], cnp[0], cq, ckf);
-                    } else {             // column tile 1: from registers, static indices per piece
-                        switch (pi) {
-                            case 8: ring_reg_piece<EPI, 0>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
-                            case 9: ring_reg_piece<EPI, 1>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
-                            case 10: ring_reg_piece<EPI, 2>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
-                            case 11: ring_reg_piece<EPI, 3>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
-                            case 12: ring_reg_piece<EPI, 4>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
-                            case 13: ring_reg_piece<EPI, 5>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
-                            case 14: ring_reg_piece<EPI, 6>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
-                            default: ring_reg_piece<EPI, 7>(g, cacc, row, col, cbias[1], cnp[1], cq, ckf); break;
-                        }
+                for (int pi = kt * pper; pi < (kt + 1) * pper && pi < 8; ++pi) {
+                    const int j = pi >> 2, p4 = pi & 3, rr = p4 * 8 + rs;
+                    const int64_t row = prev_row0 + wm * 32 + rr;
+                    const int col = prev_col0 + wn * 64 + j * 32 + c4 * 4;
+                    const bool active = (j ? ccol[1] : ccol[0]) && row < g.r;
+                    if (p4 == 0) {
+                        cp = load_col_params4<EPI, VEC>(g, col, j ? ccol[1] : ccol[0]);
+                        cp.bias.x = settle(cp.bias.x);
+                        if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) cp.theta0.w = settle(cp.theta0.w);
                     }
+                    float4 cq = make_float4(0.f, 0.f, 0.f, 0.f), ckf = cq;
+                    if (EPI == EPI_LIF_ATTN) {
+                        const int qr = __shfl(tabrow.x, rr);
+                        const int kr = __shfl(tabrow.y, rr);
+#ifndef SAPCU_ABL_NO_GATHER
+                        if (active) {
+                            cq = ld4_cols<VEC>(g.q + (int64_t)qr * g.ldq, col, g.n);
+                            ckf = ld4_cols<VEC>(g.kf + (int64_t)kr * g.ldq, col, g.n);
+                        }
+#else
+                        cq.x = __int_as_float(qr & 1); ckf.x = __int_as_float(kr & 1);
+#endif
+                    }
+                    if (!active) continue;
+                    float4 a;
+                    if (j == 0) a = *hand_at(p4);            // column tile 0: straight from the hand-off area
+                    else switch (p4) {                        // column tile 1: registers, static indices
+                        case 0: a = cacc[0]; break;
+                        case 1: a = cacc[1]; break;
+                        case 2: a = cacc[2]; break;
+                        default: a = cacc[3]; break;
+                    }
+                    float v[4];
+                    epilogue_row4_compute<EPI, VEC>(g, a, row, col, cp, v);
+                    epilogue_row4_store<EPI, VEC>(g, v, row, col, cq, ckf);
                 }
                 if (have) lds_barrier();                            // the producers' mid-step barrier of this k-step
             }
@@ -291,7 +284,7 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
             lds_barrier();                                          // (we are done with the area: producers may overwrite)
             lds_barrier();                                          // column tile 1 is in
 #pragma unroll
-            for (int e = 0; e < 16; ++e) cacc[e] = hand[(pw * 16 + e) * 64 + lane];
+            for (int p = 0; p < 4; ++p) cacc[p] = *hand_at(p);
             lds_barrier();                                          // copied out
             lds_barrier();                                          // column tile 0 is in (and stays)
             const int64_t logical = x_begin + ti * wgs_per_x + wg_in_x;
@@ -303,11 +296,11 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
 
 static int g_num_cus_ring = 0;
 
-template <int EPI>
-static int launch_ring_t(const GemmArgs& g, hipStream_t st) {
+template <int EPI, bool VEC>
+static int launch_ring_tv(const GemmArgs& g, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        SAPCU_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<EPI>),
+        SAPCU_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<EPI, VEC>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
         attr_set = true;
     }
@@ -320,9 +313,24 @@ static int launch_ring_t(const GemmArgs& g, hipStream_t st) {
     }
     const int64_t tiles = ((g.r + RBM - 1) / RBM) * ((g.n + RBN - 1) / RBN);
     const int64_t grid = tiles < g_num_cus_ring ? tiles : g_num_cus_ring;
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI>), dim3((unsigned)grid), dim3(1024), RING_LDS_BYTES, st, g);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, VEC>), dim3((unsigned)grid), dim3(1024), RING_LDS_BYTES, st, g);
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
+}
+
+// the consumers work on float4 column groups (16-byte loads, 8-16-byte stores) when every operand allows it
+static bool ring_vec_ok(const GemmArgs& g) {
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    bool ok = g.n % 4 == 0 && g.ldc % 4 == 0 && al16(g.c) && (!g.bias || al16(g.bias));
+    if (g.epi == EPI_LIF || g.epi == EPI_LIF_ATTN) ok = ok && al16(g.lif);
+    if (g.epi == EPI_RESID || g.epi == EPI_RESID_GELU) ok = ok && g.ldr % 4 == 0 && al16(g.resid);
+    if (g.epi == EPI_LIF_ATTN) ok = ok && g.ldq % 4 == 0 && al16(g.q) && al16(g.kf) && al16(g.c2);
+    return ok;
+}
+
+template <int EPI>
+static int launch_ring_t(const GemmArgs& g, hipStream_t st) {
+    return ring_vec_ok(g) ? launch_ring_tv<EPI, true>(g, st) : launch_ring_tv<EPI, false>(g, st);
 }
 
 int launch_gemm_sf16_ring(const GemmArgs& g, hipStream_t st) {
@@ -332,6 +340,8 @@ int launch_gemm_sf16_ring(const GemmArgs& g, hipStream_t st) {
     SAPCU_CHECK_ARG(g.lda % 8 == 0 && ((uintptr_t)g.a & 15) == 0 && g.w16_hi && g.w16_lo &&
                         ((uintptr_t)g.w16_hi & 15) == 0 && ((uintptr_t)g.w16_lo & 15) == 0,
                     "gemm_ring: operands must be 16-byte aligned with lda %% 8 == 0 (lda=%d)", g.lda);
+    if (g.epi == EPI_LIF || g.epi == EPI_LIF_ATTN) SAPCU_CHECK_ARG(g.lif, "gemm_ring: missing neuron parameters");
+    if (g.epi == EPI_RESID || g.epi == EPI_RESID_GELU) SAPCU_CHECK_ARG(g.resid, "gemm_ring: missing residual");
     switch (g.epi) {
         case EPI_BIAS: return launch_ring_t<EPI_BIAS>(g, st);
         case EPI_LIF: return launch_ring_t<EPI_LIF>(g, st);

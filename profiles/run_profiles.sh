@@ -14,7 +14,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpu
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_f.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_w.log 2>&1
 cd $R
-python3 profiles/make_summary.py gpurun_out/trace "round 1: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (1 x MI355X)" > gpurun_out/r01_summary.md
+python3 profiles/make_summary.py gpurun_out/trace "round 1: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (1 x MI355X)" gpurun_out/r01_gemm_launches.json > gpurun_out/r01_summary.md
 python3 profiles/pmc_to_json.py gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/r01_pmc.json
 cp gpurun_out/trace/*/*_kernel_stats.csv gpurun_out/r01_kernel_stats.csv
 # keep the merged-back payload small
