@@ -163,10 +163,11 @@ __device__ __forceinline__ void store_split4(float* base, int64_t row, int ld, i
 template <int EPI, bool VEC>
 __device__ __forceinline__ void epilogue_row4_compute(const GemmArgs& g, const float4 acc, int64_t row, int col,
                                                       const ColParams4& cp, float (&v)[4]) {
-    v[0] = __fadd_rn(acc.x, cp.bias.x);
-    v[1] = __fadd_rn(acc.y, cp.bias.y);
-    v[2] = __fadd_rn(acc.z, cp.bias.z);
-    v[3] = __fadd_rn(acc.w, cp.bias.w);
+    // acc carries the x16 of the pre-scaled weights: acc/16 is exact, so one FMA equals the separate multiply and add
+    v[0] = __fmaf_rn(acc.x, 0.0625f, cp.bias.x);
+    v[1] = __fmaf_rn(acc.y, 0.0625f, cp.bias.y);
+    v[2] = __fmaf_rn(acc.z, 0.0625f, cp.bias.z);
+    v[3] = __fmaf_rn(acc.w, 0.0625f, cp.bias.w);
     float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
     if (EPI == EPI_RESID || EPI == EPI_RESID_GELU) res = ld4_cols<VEC>(g.resid + row * g.ldr, col, g.n);
 #ifndef SAPCU_ABL_NO_LIF          // (profiling ablations: profiles/ablate.sh)

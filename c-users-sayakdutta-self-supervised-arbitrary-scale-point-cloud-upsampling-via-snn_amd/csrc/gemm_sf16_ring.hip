@@ -38,6 +38,14 @@ typedef __attribute__((address_space(3))) unsigned char lds_byte;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 
 constexpr int RBM = 128, RBN = 128, RBK = 32;
+// issue the DMAs of a k-step one at a time between MFMAs instead of in a burst behind the barrier: measured SLOWER
+// (bias GEMM r=1179648, k=n=512: 2928 us vs 2645 us), kept for reference
+constexpr bool RING_INTERLEAVE_DMA = false;
+#ifdef SAPCU_RING_TILES_INTERLEAVED
+constexpr bool RING_TILES_INTERLEAVED = true;
+#else
+constexpr bool RING_TILES_INTERLEAVED = false;
+#endif
 constexpr int RPLANE = RBM * RBK * 2;            // 8 KiB
 constexpr int RSLOT = 4 * RPLANE;                // 32 KiB
 constexpr int RSLOTS = 4;
@@ -53,12 +61,22 @@ __device__ __forceinline__ void wait_vm() {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+#ifdef SAPCU_RING_STAMPS   // diagnostic build only (profiles/ablate.sh): where a producer wave's k-step goes
+__device__ unsigned long long g_ring_stamps[256][8];
+#define RING_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define RING_SEG(i, t0, t1) do { seg[i] += (t1) - (t0); } while (0)
+#else
+#define RING_STAMP(t) do { } while (0)
+#define RING_SEG(i, t0, t1) do { } while (0)
+#endif
+
 template <int EPI, bool VEC>
 __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     float* hand = reinterpret_cast<float*>(smem_raw + RSLOTS * RSLOT);
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform: keep it (and all it feeds) in scalar registers
     const bool producer = wave < 8;
     const int pw = wave & 7;
     const int wm = pw >> 1, wn = pw & 1;
@@ -67,17 +85,37 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
     const int ntn = (g.n + RBN - 1) / RBN;
     const int64_t ntm = (g.r + RBM - 1) / RBM;
     const int64_t ntiles = ntm * ntn;
-    const int nx = gridDim.x < 8 ? 1 : 8;
-    const int xcd = nx == 1 ? 0 : (int)(blockIdx.x & 7);
-    const int wg_in_x = nx == 1 ? (int)blockIdx.x : (int)(blockIdx.x >> 3);
-    const int wgs_per_x = nx == 1 ? (int)gridDim.x : (int)((gridDim.x - xcd + 7) >> 3);
-    const int64_t qd = ntiles / nx, rem = ntiles % nx;
-    const int64_t x_begin = xcd * qd + (xcd < rem ? xcd : rem);
-    const int64_t x_count = qd + (xcd < rem ? 1 : 0);
     const int nk = g.k / RBK;
-    // this workgroup's tiles: local indices wg_in_x, wg_in_x + wgs_per_x, ... < x_count
-    const int64_t my_tiles = x_count > wg_in_x ? (x_count - wg_in_x + wgs_per_x - 1) / wgs_per_x : 0;
+    // Tile order: every workgroup owns a CONTIGUOUS run of tiles, columns fastest — it walks the n-tiles of one
+    // 128-row panel one after the other, so the A panel comes from HBM once (first n-tile) and from L2 for the
+    // others (the ring is latency-bound: 96 KiB in flight per CU; an L2 hit returns in a third of an HBM miss).
+    // RING_TILES_INTERLEAVED = the previous order (the n-tiles of a panel run concurrently on one XCD).
+    int64_t first_logical, my_tiles, step_tm;
+    int step_tn;
+    if (RING_TILES_INTERLEAVED) {
+        const int nx = gridDim.x < 8 ? 1 : 8;
+        const int xcd = nx == 1 ? 0 : (int)(blockIdx.x & 7);
+        const int wg_in_x = nx == 1 ? (int)blockIdx.x : (int)(blockIdx.x >> 3);
+        const int wgs_per_x = nx == 1 ? (int)gridDim.x : (int)((gridDim.x - xcd + 7) >> 3);
+        const int64_t qd = ntiles / nx, rem = ntiles % nx;
+        const int64_t x_begin = xcd * qd + (xcd < rem ? xcd : rem);
+        const int64_t x_count = qd + (xcd < rem ? 1 : 0);
+        // this workgroup's tiles: local indices wg_in_x, wg_in_x + wgs_per_x, ... < x_count
+        my_tiles = x_count > wg_in_x ? (x_count - wg_in_x + wgs_per_x - 1) / wgs_per_x : 0;
+        first_logical = x_begin + wg_in_x;
+        step_tm = wgs_per_x / ntn;
+        step_tn = wgs_per_x - (int)step_tm * ntn;
+    } else {
+        const int64_t qd = ntiles / gridDim.x, rem = ntiles % gridDim.x;
+        my_tiles = qd + ((int64_t)blockIdx.x < rem ? 1 : 0);
+        first_logical = blockIdx.x * qd + ((int64_t)blockIdx.x < rem ? (int64_t)blockIdx.x : rem);
+        step_tm = 0;
+        step_tn = 1;
+    }
     if (my_tiles == 0) return;
+    // tile walk without divisions in the loops: (tile row, tile column) of the first tile + increment per tile
+    const int64_t first_tm = first_logical / ntn;
+    const int first_tn = (int)(first_logical - first_tm * ntn);
 
     if (producer) {
         // DMA role: wave w moves piece w (rows 16w..16w+15) of each of the 4 planes; lane -> 16-byte chunk
@@ -92,38 +130,88 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
             wrow_l[j] = wn * 64 + j * 32 + r32;
             wsw[j] = (wrow_l[j] >> 2) & 3;
         }
-        const _Float16* a16 = reinterpret_cast<const _Float16*>(g.a);
-        const int64_t a_pitch = 2 * (int64_t)g.lda;               // halves per A row
+        // DMA sources = wave-uniform base of the tile (scalar registers, all per-step arithmetic on the scalar unit)
+        // + one 32-bit per-lane byte offset per operand that only changes with the tile (edge clamps)
+        const char* a8 = reinterpret_cast<const char*>(g.a);
+        const int64_t a_pitch_b = 4 * (int64_t)g.lda;              // bytes per A row (hi halves, then lo halves at +2*lda)
         const int64_t total_steps = my_tiles * nk;
 
         // prefetch cursor: global step index -> (tile, k-step)
         int64_t pf_tile = 0;
         int pf_kt = 0;
-        const _Float16* pf_a = nullptr;
-        int pf_woff = 0;
+        const char* pf_abase = nullptr;                            // uniform: first row of the tile
+        const char* pf_wbase = nullptr;                            // uniform: first weight row (hi plane) of the tile
+        const int64_t wlo_delta = reinterpret_cast<const char*>(g.w16_lo) - reinterpret_cast<const char*>(g.w16_hi);
+        unsigned pf_aoff = 0, pf_woff = 0;                         // per lane
+        const unsigned aoff_full = (unsigned)(drow * (int)a_pitch_b + dsrc * 2);   // interior tiles
+        const unsigned woff_full = (unsigned)(drow * g.k * 2 + dsrc * 2);
+        int64_t pf_tm = first_tm;                                  // tile coordinates of the cursor
+        int pf_tn = first_tn;
         auto pf_setup = [&]() {
-            const int64_t logical = x_begin + pf_tile * wgs_per_x + wg_in_x;
-            const int64_t row0 = (logical / ntn) * RBM;
-            const int col0 = (int)(logical % ntn) * RBN;
-            int64_t ar = row0 + drow;
-            if (ar >= g.r) ar = g.r - 1;                           // clamped rows only feed masked outputs
-            pf_a = a16 + ar * a_pitch + dsrc;
-            int nn = col0 + drow;
-            if (nn >= g.n) nn = g.n - 1;
-            pf_woff = nn * g.k + dsrc;
-        };
-        auto issue = [&](int64_t gstep) {                          // DMAs of global step gstep (cursor must be on it)
-            lds_byte* sbase = (lds_byte*)(smem_raw + (int)(gstep & (RSLOTS - 1)) * RSLOT + pw * 1024);
-            const int k0 = pf_kt * RBK;
-            __builtin_amdgcn_global_load_lds((gptr_t)(pf_a + k0), sbase, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(pf_a + g.lda + k0), sbase + RPLANE, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(g.w16_hi + pf_woff + k0), sbase + 2 * RPLANE, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(g.w16_lo + pf_woff + k0), sbase + 3 * RPLANE, 16, 0, 0);
-            if (++pf_kt == nk) {
-                pf_kt = 0;
-                ++pf_tile;
-                if (pf_tile < my_tiles) pf_setup();
+            const int64_t row0 = pf_tm * RBM;
+            const int col0 = pf_tn * RBN;
+            const int64_t rows_left = g.r - row0;                  // >= 1
+            pf_abase = a8 + row0 * a_pitch_b;
+            pf_wbase = reinterpret_cast<const char*>(g.w16_hi) + (int64_t)col0 * g.k * 2;
+            const int cols_left = g.n - col0;
+            pf_aoff = aoff_full;
+            pf_woff = woff_full;
+            if (rows_left < RBM || cols_left < RBN) {              // edge tile (uniform, rare): clamped rows only feed masked outputs
+                const int dr = pw * 16 + (lane >> 2);
+                const int ds = ((lane & 3) ^ ((dr >> 2) & 3)) * 16;
+                const int ar = dr < rows_left ? dr : (int)(rows_left - 1);
+                const int nn = dr < cols_left ? dr : cols_left - 1;
+                pf_aoff = (unsigned)(ar * (int)a_pitch_b + ds);
+                pf_woff = (unsigned)(nn * g.k * 2 + ds);
             }
+        };
+        // the four DMAs of one k-step are issued ONE AT A TIME between MFMAs (issue_piece 0..3): a DMA issue holds the
+        // wave for 60-180 cycles, which hides behind the matrix pipe only if MFMAs are already queued
+        auto issue_piece = [&](int64_t gstep, int piece) {         // cursor must be on gstep
+            lds_byte* sbase = (lds_byte*)(smem_raw + (int)(gstep & (RSLOTS - 1)) * RSLOT + pw * 1024);
+#ifdef SAPCU_ABL_LINE128   // traffic experiment (results are garbage): hi and lo of a k-step come from ONE 128-byte line
+            const int k0b = pf_kt * 128;
+            if (piece == 0) __builtin_amdgcn_global_load_lds((gptr_t)(pf_abase + k0b + pf_aoff), sbase, 16, 0, 0);
+            else if (piece == 1) __builtin_amdgcn_global_load_lds((gptr_t)(pf_abase + (k0b + 64) + pf_aoff), sbase + RPLANE, 16, 0, 0);
+            const char* wexp = pf_wbase + (pf_wbase - reinterpret_cast<const char*>(g.w16_hi));   // row pitch 4k bytes
+            const unsigned woffx = pf_woff + (unsigned)(drow * g.k * 2);
+            if (piece == 2) __builtin_amdgcn_global_load_lds((gptr_t)(wexp + k0b + woffx), sbase + 2 * RPLANE, 16, 0, 0);
+            else if (piece == 3) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(wexp + (64 + k0b) + woffx), sbase + 3 * RPLANE, 16, 0, 0);
+                if (++pf_kt == nk) {
+                    pf_kt = 0;
+                    ++pf_tile;
+                    pf_tm += step_tm;
+                    pf_tn += step_tn;
+                    if (pf_tn >= ntn) { pf_tn -= ntn; ++pf_tm; }
+                    if (pf_tile < my_tiles) pf_setup();
+                }
+            }
+#else
+            const int k0b = pf_kt * RBK * 2;
+            if (piece == 0) __builtin_amdgcn_global_load_lds((gptr_t)(pf_abase + k0b + pf_aoff), sbase, 16, 0, 0);
+            else if (piece == 1) __builtin_amdgcn_global_load_lds((gptr_t)(pf_abase + (k0b + 2 * g.lda) + pf_aoff), sbase + RPLANE, 16, 0, 0);
+            else if (piece == 2) __builtin_amdgcn_global_load_lds((gptr_t)(pf_wbase + k0b + pf_woff), sbase + 2 * RPLANE, 16, 0, 0);
+            else {
+                __builtin_amdgcn_global_load_lds((gptr_t)(pf_wbase + (wlo_delta + k0b) + pf_woff), sbase + 3 * RPLANE, 16, 0, 0);
+                if (++pf_kt == nk) {
+                    pf_kt = 0;
+                    ++pf_tile;
+                    pf_tm += step_tm;
+                    pf_tn += step_tn;
+                    if (pf_tn >= ntn) { pf_tn -= ntn; ++pf_tm; }
+                    if (pf_tile < my_tiles) pf_setup();
+                }
+            }
+#endif
+        };
+        auto issue = [&](int64_t gstep) {
+#ifdef SAPCU_ABL_NO_DMA       // compute-only experiment: the ring is never refilled (garbage operands)
+            if (++pf_kt == nk) { pf_kt = 0; ++pf_tile; }
+            return;
+#endif
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) issue_piece(gstep, pc);
         };
         pf_setup();
         int64_t issued = 0;
@@ -136,6 +224,9 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
             half8 ah, al, wh[2], wl[2];
         };
         auto read_frags = [&](int64_t step, int k16, Frags& f) {
+#ifdef SAPCU_ABL_NO_MFMA      // delivery-only experiment: DMAs, waits and barriers, no LDS reads, no MFMAs
+            return;
+#endif
             const unsigned char* st = smem_raw + (int)(step & (RSLOTS - 1)) * RSLOT;
             const unsigned char* sA = st + arow_l * (RBK * 2) + (((k16 * 2 + h) ^ asw) * 16);
             f.ah = *reinterpret_cast<const half8*>(sA);
@@ -149,12 +240,36 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
         };
         f32x16 acc[2];
         auto mfma6 = [&](const Frags& f) {
+#ifdef SAPCU_ABL_NO_MFMA
+            return;
+#endif
             // alternate the two accumulators so consecutive MFMAs never depend on each other
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.wh[0], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.wh[1], acc[1], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wl[0], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wl[1], acc[1], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wh[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wh[1], acc[1], 0, 0, 0);
+        };
+        // the same six MFMAs with the DMAs of step `dstep` issued in the gaps
+        auto mfma6_dma = [&](const Frags& f, int64_t dstep) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.wh[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.wh[1], acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_piece(dstep, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wl[0], acc[0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_piece(dstep, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wl[1], acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_piece(dstep, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wh[0], acc[0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_piece(dstep, 3);
+            __builtin_amdgcn_sched_barrier(0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wh[1], acc[1], 0, 0, 0);
         };
         auto wait_landed = [&](int64_t step) {     // this wave's DMAs of `step` have landed
@@ -171,30 +286,54 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
             issue(issued);
             ++issued;
         }
+        float* const hand_even = hand + pw * 1024 + 5 * h * 32 + r32;
+        float* const hand_odd = hand + pw * 1024 + 3 * h * 32 + r32;
         Frags f0, f1;
         read_frags(0, 0, f0);
         int64_t gstep = 0;
+#ifdef SAPCU_RING_STAMPS
+        unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0, tb = 0, tc = 0, td = 0, te = 0, tf = 0;
+#endif
         for (int64_t ti = 0; ti < my_tiles; ++ti) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
             for (int kt = 0; kt < nk; ++kt, ++gstep) {
+                RING_STAMP(ta);
                 read_frags(gstep, 1, f1);                           // second half of this step: lands behind mfma6(f0)
                 mfma6(f0);
+                RING_STAMP(tb);
+                RING_SEG(0, ta, tb);                                // reads(f1) + 6 MFMAs issued (+ drain of the reads)
+                bool dma = false;
                 if (gstep + 1 < total_steps) {
                     wait_landed(gstep + 1);
+                    RING_STAMP(tc);
+                    RING_SEG(1, tb, tc);                            // own DMAs of the next step landed
                     lds_barrier();                                  // step gstep+1 is in for everyone; slot gstep%4 fully read
-                    if (issued < total_steps) {
+                    RING_STAMP(td);
+                    RING_SEG(2, tc, td);                            // barrier
+                    if (!RING_INTERLEAVE_DMA && issued < total_steps) {
                         issue(issued);                              // step gstep+4 -> slot gstep%4
                         ++issued;
                     }
+                    RING_STAMP(te);
+                    RING_SEG(3, td, te);                            // DMA issue
                     read_frags(gstep + 1, 0, f0);                   // first half of the next step: lands behind mfma6(f1)
+                    dma = RING_INTERLEAVE_DMA && issued < total_steps;
                 } else {
                     lds_barrier();                                  // keep the barrier count per step uniform
                 }
-                mfma6(f1);
+                if (dma) {
+                    mfma6_dma(f1, issued);                          // step gstep+4 -> slot gstep%4, issued between the MFMAs
+                    ++issued;
+                } else {
+                    mfma6(f1);
+                }
+                RING_STAMP(tf);
+                RING_SEG(4, te, tf);                                // reads(f0') + 6 MFMAs issued
             }
+            RING_STAMP(ta);
             // hand-off in two halves through the 32 KiB area (the ring keeps streaming underneath)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
@@ -202,12 +341,23 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
                 lds_barrier();                                      // consumers are done with what the area held
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;  // row of the 32x32 block held in register e
-                    hand[pw * 1024 + (rr ^ h) * 32 + r32] = __fmul_rn(acc[j][e], 0.0625f);   // undo W x 16
+                    // register e holds row rr = (e&3) + 8*(e>>2) + 4h of the 32x32 block; slot rr ^ h = rr + 5h - ... :
+                    // even e -> (e&3) + 8*(e>>2) + 5h, odd e -> (e&3) + 8*(e>>2) + 3h: two lane bases + constant offsets
+                    float* hb = (e & 1) ? hand_odd : hand_even;
+                    hb[((e & 3) + 8 * (e >> 2)) * 32] = acc[j][e];  // still x16 (weights pre-scaled): undone in the epilogue
                 }
                 lds_barrier();                                      // half j is ready
             }
+            RING_STAMP(tb);
+            RING_SEG(5, ta, tb);                                    // hand-off (waits for the MFMAs, 4 barriers, 32 ds_write)
         }
+#ifdef SAPCU_RING_STAMPS
+        if (wave == 0 && lane == 0 && blockIdx.x < 256) {
+            seg[6] = (unsigned long long)total_steps;
+            seg[7] = (unsigned long long)my_tiles;
+            for (int i = 0; i < 8; ++i) g_ring_stamps[blockIdx.x][i] = seg[i];
+        }
+#endif
     } else {
         // row layout of this wave's 32x64 sub-tile: lane = (row slot s = lane>>3, column group c4 = lane&7);
         // piece pi = 4*j + p covers row p*8 + s, columns j*32 + c4*4 .. +3 of the sub-tile
@@ -219,6 +369,8 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
         float4 cacc[4];                // column tile 1 of the previous tile; column tile 0 stays in the hand-off area
         int64_t prev_row0 = -1;
         int prev_col0 = 0;
+        int64_t cur_tm = first_tm;                                 // tile whose accumulators are handed over next
+        int cur_tn = first_tn;
         const int pper = (8 + nk - 1) / nk;                        // pieces per k-step: all 8 within the next tile's k-loop
         lds_barrier();                                             // pairs with the producers' "step 0 has landed"
         for (int64_t ti = 0; ti <= my_tiles; ++ti) {               // last round = drain (no barriers on either side)
@@ -287,9 +439,11 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
             for (int p = 0; p < 4; ++p) cacc[p] = *hand_at(p);
             lds_barrier();                                          // copied out
             lds_barrier();                                          // column tile 0 is in (and stays)
-            const int64_t logical = x_begin + ti * wgs_per_x + wg_in_x;
-            prev_row0 = (logical / ntn) * RBM;
-            prev_col0 = (int)(logical % ntn) * RBN;
+            prev_row0 = cur_tm * RBM;
+            prev_col0 = cur_tn * RBN;
+            cur_tm += step_tm;
+            cur_tn += step_tn;
+            if (cur_tn >= ntn) { cur_tn -= ntn; ++cur_tm; }
         }
     }
 }
@@ -355,5 +509,13 @@ int launch_gemm_sf16_ring(const GemmArgs& g, hipStream_t st) {
         default: set_error("gemm_ring: unknown epilogue %d", g.epi); return SAPCU_ERR_ARG;
     }
 }
+
+#ifdef SAPCU_RING_STAMPS
+}  // namespace sapcu
+extern "C" int sapcu_debug_ring_stamps(unsigned long long* out_host) {
+    return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(sapcu::g_ring_stamps), sizeof(sapcu::g_ring_stamps));
+}
+namespace sapcu {
+#endif
 
 }  // namespace sapcu
