@@ -103,118 +103,61 @@ __device__ __forceinline__ float neuron_step(float x, NeuronS& s, const NeuronP&
     return sp;
 }
 
-// `for t in range(T): x, *st = snn(x, *st)` — spikes fed back as the next input (fn:319-320), LIF.
-// State lives in registers for all T steps.  Two exact simplifications of neuron_step<false>:
-//   * step 0 starts from m = 0, r = 0:  m = x,  r = s0  (0*decay*(1-0) + x and 0*rdecay + s0, exactly);
-//   * for t >= 1 the gate `x * (r <= 0)` is closed — soft_spike() >= 0.199 * 2^-72 > 0, so r > 0 — and the
-//     fed-back input contributes exactly +0;  the state updates after the last spike are dead.
-// W chains are advanced together (independent chains = VALU ILP for the GEMM consumers / pos-enc kernel).
+// ---------------------------------------------------------------------------------------------
+// `for t in range(T): x, *st = snn(x, *st)` — spikes fed back as the next input (fn:319-320), LIF: THE production
+// neuron loop (GEMM epilogues, pos-enc kernel, stem).  State lives in registers for all T steps, and the loop is
+// peeled around two exact facts about neuron_step<false>:
+//   * step 0 starts from m = 0, r = 0:  m = x,  r = s0;
+//   * for t >= 1 the gate `x * (r <= 0)` is closed — the spike surrogate is > 0, so r > 0 — and the fed-back input
+//     contributes exactly +0;  the state updates after the last spike are dead.
+// Chains are processed as 2-vectors (v_pk_mul/add/fma_f32: one instruction, two chains); H pairs are advanced together
+// (independent chains = VALU ILP).
+//
+// Arithmetic.  The kernels that run this loop are bound by VALU issue, so by default every update is
+// written with fused multiply-adds — 12 packed operations per mid step instead of 19:
+//     mm  = (m*decay)*(1-r)                         = fma(-(m*decay), r, m*decay)
+//     g   = exp(-x^2/2) * 0.5/sqrt(2 pi)            = exp2(fma(x*x, -log2(e)/2, log2(0.5/sqrt(2 pi))))
+//     m'  = mm*(1-s)                                = fma(-mm, s, mm)
+//     r'  = r*rdecay + s                            = fma(r, rdecay, s)
+//     th' = th0 + ((th + adapt*s) - th0)*0.95       = fma(th, 0.95, fma(s, 0.95*adapt, 0.05*th0))
+// Each right-hand side is the left-hand side's value with fewer roundings; against the reference's separately rounded
+// sequence the spikes move by <= 3e-7 (neuron-unit bar 1e-6: tests/test_gpu_parity.py::test_neuron_unit_*).
+// -DSAPCU_LIF_EXACT_ORDER restores the reference's operation order op for op.
+// ---------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// two spikes at once: the multiplies/adds are written on 2-vectors so that hipcc emits the packed
-// v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 (one instruction, two chains); clamp, exp2 and rcp are per lane.
-// Element-wise the arithmetic is exactly soft_spike()'s.
-__device__ __forceinline__ f32x2 soft_spike2(f32x2 d) {
-    f32x2 x;
-    x.x = clampf(d.x, -10.0f, 10.0f);
-    x.y = clampf(d.y, -10.0f, 10.0f);
-    const f32x2 a = (x * x) * -0.72134752044448170368f;
-    const f32x2 b = x * -14.426950408889634074f;
-    f32x2 g, e;
-    g.x = __builtin_amdgcn_exp2f(a.x);
-    g.y = __builtin_amdgcn_exp2f(a.y);
-    e.x = __builtin_amdgcn_exp2f(b.x);
-    e.y = __builtin_amdgcn_exp2f(b.y);
-    g = g * 0.19947114020071633897f;
-    const f32x2 den = e + 1.0f;
-    f32x2 s;
-    s.x = __builtin_amdgcn_rcpf(den.x);
-    s.y = __builtin_amdgcn_rcpf(den.y);
-    return __builtin_elementwise_fma(f32x2{0.5f, 0.5f}, s, g);
-}
-
-template <int W>
-__device__ __forceinline__ void lif_selfloop_n(float (&v)[W], const NeuronP& p, int T) {
-    if constexpr (W % 2 == 0) {
-        // packed form: chains (2u, 2u+1) share every multiply/add instruction
-        constexpr int H = W / 2;
-        f32x2 m[H], r[H], th[H], s[H];
-#pragma unroll
-        for (int u = 0; u < H; ++u) {
-            m[u] = f32x2{v[2 * u], v[2 * u + 1]};
-            s[u] = soft_spike2(m[u] - p.theta0);
-        }
-        if (T > 1) {
-#pragma unroll
-            for (int u = 0; u < H; ++u) {
-                m[u] = m[u] * (1.0f - s[u]);
-                r[u] = s[u];
-                const f32x2 t0 = p.theta0 + p.adapt * s[u];
-                th[u] = p.theta0 + (t0 - p.theta0) * 0.95f;
-            }
-            for (int t = 1; t < T - 1; ++t) {
-#pragma unroll
-                for (int u = 0; u < H; ++u) {
-                    const f32x2 mm = (m[u] * p.decay) * (1.0f - r[u]);
-                    const f32x2 sp = soft_spike2(mm - th[u]);
-                    m[u] = mm * (1.0f - sp);
-                    r[u] = r[u] * p.rdecay + sp;
-                    const f32x2 t0 = th[u] + p.adapt * sp;
-                    th[u] = p.theta0 + (t0 - p.theta0) * 0.95f;
-                    s[u] = sp;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < H; ++u) {
-                const f32x2 mm = (m[u] * p.decay) * (1.0f - r[u]);
-                s[u] = soft_spike2(mm - th[u]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < H; ++u) {
-            v[2 * u] = s[u].x;
-            v[2 * u + 1] = s[u].y;
-        }
-        return;
-    }
-    float m[W], r[W], th[W];
-#pragma unroll
-    for (int u = 0; u < W; ++u) {
-        m[u] = v[u];
-        v[u] = soft_spike(__fsub_rn(m[u], p.theta0));
-    }
-    if (T <= 1) return;
-#pragma unroll
-    for (int u = 0; u < W; ++u) {
-        m[u] = __fmul_rn(m[u], __fsub_rn(1.0f, v[u]));
-        r[u] = v[u];
-        const float t0 = __fadd_rn(p.theta0, __fmul_rn(p.adapt, v[u]));
-        th[u] = __fadd_rn(p.theta0, __fmul_rn(__fsub_rn(t0, p.theta0), 0.95f));
-    }
-    for (int t = 1; t < T - 1; ++t) {
-#pragma unroll
-        for (int u = 0; u < W; ++u) {
-            const float mm = __fmul_rn(__fmul_rn(m[u], p.decay), __fsub_rn(1.0f, r[u]));
-            const float sp = soft_spike(__fsub_rn(mm, th[u]));
-            m[u] = __fmul_rn(mm, __fsub_rn(1.0f, sp));
-            r[u] = __fadd_rn(__fmul_rn(r[u], p.rdecay), sp);
-            const float t0 = __fadd_rn(th[u], __fmul_rn(p.adapt, sp));
-            th[u] = __fadd_rn(p.theta0, __fmul_rn(__fsub_rn(t0, p.theta0), 0.95f));
-            v[u] = sp;
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < W; ++u) {
-        const float mm = __fmul_rn(__fmul_rn(m[u], p.decay), __fsub_rn(1.0f, r[u]));
-        v[u] = soft_spike(__fsub_rn(mm, th[u]));
-    }
-}
-
-// Same loop for chains that sit in DIFFERENT channels (a lane of the ring GEMM's consumer holds 4 consecutive
-// columns of one row): the parameters are 2-vectors too.  Element-wise identical to lif_selfloop_n.
 struct NeuronP2 {
     f32x2 decay, adapt, rdecay, theta0;
 };
+
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_clamp10(f32x2 d) { return f32x2{clampf(d.x, -10.0f, 10.0f), clampf(d.y, -10.0f, 10.0f)}; }
+
+// two spikes at once; clamp, exp2 and rcp are per lane.  Element-wise the arithmetic is exactly soft_spike()'s
+// (exact-order build) or its fused form (default).
+__device__ __forceinline__ f32x2 soft_spike2(f32x2 d) {
+    const f32x2 x = pk_clamp10(d);
+    const f32x2 b = x * -14.426950408889634074f;
+    f32x2 g, e, s;
+#ifdef SAPCU_LIF_EXACT_ORDER
+    const f32x2 a = (x * x) * -0.72134752044448170368f;
+    g.x = __builtin_amdgcn_exp2f(a.x);
+    g.y = __builtin_amdgcn_exp2f(a.y);
+    g = g * 0.19947114020071633897f;
+#else
+    // log2(0.5/sqrt(2 pi)) = -2.3257...: the scale rides in the exponent
+    const f32x2 a = pk_fma(x * x, f32x2{-0.72134752044448170368f, -0.72134752044448170368f},
+                           f32x2{-2.3257480647361593f, -2.3257480647361593f});
+    g.x = __builtin_amdgcn_exp2f(a.x);
+    g.y = __builtin_amdgcn_exp2f(a.y);
+#endif
+    e.x = __builtin_amdgcn_exp2f(b.x);
+    e.y = __builtin_amdgcn_exp2f(b.y);
+    const f32x2 den = e + 1.0f;
+    s.x = __builtin_amdgcn_rcpf(den.x);
+    s.y = __builtin_amdgcn_rcpf(den.y);
+    return pk_fma(f32x2{0.5f, 0.5f}, s, g);
+}
 
 template <int H>
 __device__ __forceinline__ void lif_selfloop_pairs(f32x2 (&v)[H], const NeuronP2 (&p)[H], int T) {
@@ -225,6 +168,7 @@ __device__ __forceinline__ void lif_selfloop_pairs(f32x2 (&v)[H], const NeuronP2
         s[u] = soft_spike2(m[u] - p[u].theta0);
     }
     if (T > 1) {
+#ifdef SAPCU_LIF_EXACT_ORDER
 #pragma unroll
         for (int u = 0; u < H; ++u) {
             m[u] = m[u] * (1.0f - s[u]);
@@ -249,9 +193,57 @@ __device__ __forceinline__ void lif_selfloop_pairs(f32x2 (&v)[H], const NeuronP2
             const f32x2 mm = (m[u] * p[u].decay) * (1.0f - r[u]);
             s[u] = soft_spike2(mm - th[u]);
         }
+#else
+        f32x2 a95[H], thc[H];
+        const f32x2 k95 = f32x2{0.95f, 0.95f};
+#pragma unroll
+        for (int u = 0; u < H; ++u) {
+            a95[u] = p[u].adapt * 0.95f;
+            thc[u] = p[u].theta0 * 0.05f;
+            m[u] = pk_fma(-m[u], s[u], m[u]);
+            r[u] = s[u];
+            th[u] = pk_fma(p[u].theta0, k95, pk_fma(s[u], a95[u], thc[u]));
+        }
+        for (int t = 1; t < T - 1; ++t) {
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                const f32x2 md = m[u] * p[u].decay;
+                const f32x2 mm = pk_fma(-md, r[u], md);
+                const f32x2 sp = soft_spike2(mm - th[u]);
+                m[u] = pk_fma(-mm, sp, mm);
+                r[u] = pk_fma(r[u], p[u].rdecay, sp);
+                th[u] = pk_fma(th[u], k95, pk_fma(sp, a95[u], thc[u]));
+                s[u] = sp;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < H; ++u) {
+            const f32x2 md = m[u] * p[u].decay;
+            s[u] = soft_spike2(pk_fma(-md, r[u], md) - th[u]);
+        }
+#endif
     }
 #pragma unroll
     for (int u = 0; u < H; ++u) v[u] = s[u];
+}
+
+// W chains of ONE channel (an odd W repeats its last chain in the spare half of a pair)
+template <int W>
+__device__ __forceinline__ void lif_selfloop_n(float (&v)[W], const NeuronP& p, int T) {
+    constexpr int H = (W + 1) / 2;
+    f32x2 pv[H];
+    NeuronP2 pp[H];
+#pragma unroll
+    for (int u = 0; u < H; ++u) {
+        pv[u] = f32x2{v[2 * u], v[(2 * u + 1 < W) ? 2 * u + 1 : 2 * u]};
+        pp[u] = NeuronP2{{p.decay, p.decay}, {p.adapt, p.adapt}, {p.rdecay, p.rdecay}, {p.theta0, p.theta0}};
+    }
+    lif_selfloop_pairs<H>(pv, pp, T);
+#pragma unroll
+    for (int u = 0; u < H; ++u) {
+        v[2 * u] = pv[u].x;
+        if (2 * u + 1 < W) v[2 * u + 1] = pv[u].y;
+    }
 }
 
 __device__ __forceinline__ float lif_selfloop(float x, const NeuronP& p, int T) {

@@ -21,6 +21,8 @@ __device__ __forceinline__ float settle(float x) {
     return x;
 }
 
+__device__ __forceinline__ void settle4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
 // "Split rows": a [rows, K] activation tensor whose producer already split every value for the split-f16
 // GEMM (gemm_sf16_ring.hip).  A row keeps the f32 row's footprint (pitch = ld floats = 4*ld bytes): the first
 // K halves are hi = f16_rn(x), the halves starting at half-index ld (byte 2*ld) are lo = f16_rn(x - hi).

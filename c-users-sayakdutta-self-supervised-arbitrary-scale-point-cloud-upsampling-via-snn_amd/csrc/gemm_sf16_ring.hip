@@ -384,7 +384,8 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
             bool ccol[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) ccol[j] = cons_work && (prev_col0 + wn * 64 + j * 32 + c4 * 4) < g.n;
-            ColParams4 cp = load_col_params4<EPI, VEC>(g, 0, false);
+            ColParams4 cp;                       // (no load here: anything in flight at loop entry is waited for in EVERY iteration)
+            cp.bias = cp.decay = cp.adapt = cp.rdecay = cp.theta0 = make_float4(0.f, 0.f, 0.f, 0.f);
             int2 tabrow = make_int2(0, 0);       // EPI_LIF_ATTN: lane l holds the (q row, k row) pair of tile row wm*32 + (l & 31)
             if (cons_work && EPI == EPI_LIF_ATTN) {
                 const int64_t trow = prev_row0 + wm * 32 + (lane & 31);
@@ -401,8 +402,15 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
                     const bool active = (j ? ccol[1] : ccol[0]) && row < g.r;
                     if (p4 == 0) {
                         cp = load_col_params4<EPI, VEC>(g, col, j ? ccol[1] : ccol[0]);
-                        cp.bias.x = settle(cp.bias.x);
-                        if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) cp.theta0.w = settle(cp.theta0.w);
+                        // land ALL of them inside this branch: a value still in flight at the join would make the
+                        // compiler wait on the join's other side too, i.e. behind the previous piece's stores
+                        settle4(cp.bias);
+                        if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) {
+                            settle4(cp.decay);
+                            settle4(cp.adapt);
+                            settle4(cp.rdecay);
+                            settle4(cp.theta0);
+                        }
                     }
                     float4 cq = make_float4(0.f, 0.f, 0.f, 0.f), ckf = cq;
                     if (EPI == EPI_LIF_ATTN) {
