@@ -252,6 +252,72 @@ __device__ __forceinline__ float lif_selfloop(float x, const NeuronP& p, int T) 
     return v[0];
 }
 
+// Two chains of ONE channel stepped together with per-step outputs (fd's encoder keeps the spikes of every step,
+// fd:432-474): input only at step 0, zero afterwards (closed gate, counted by the caller).  Same fused arithmetic as
+// lif_selfloop_pairs; EIF adds dT*exp(clamp((m_prev - rh)/(dT + 1e-6), +-5)) un-gated (fd:245-252), the division as a
+// multiplication by the once-computed reciprocal.  -DSAPCU_LIF_EXACT_ORDER: neuron_step<EIF> per lane.
+struct NeuronS2 {
+    f32x2 m, th, r;
+};
+
+template <bool EIF>
+struct NeuronStep2 {
+    NeuronP p;
+    f32x2 decay, rdecay, a95, thc, theta0;
+    float inv_dT;
+    NeuronS2 s;
+#ifdef SAPCU_LIF_EXACT_ORDER
+    NeuronS sx, sy;
+#endif
+    __device__ __forceinline__ explicit NeuronStep2(const NeuronP& pp) : p(pp) {
+        decay = f32x2{p.decay, p.decay};
+        rdecay = f32x2{p.rdecay, p.rdecay};
+        a95 = f32x2{p.adapt * 0.95f, p.adapt * 0.95f};
+        thc = f32x2{p.theta0 * 0.05f, p.theta0 * 0.05f};
+        theta0 = f32x2{p.theta0, p.theta0};
+        inv_dT = EIF ? __fdiv_rn(1.0f, __fadd_rn(p.dT, 1e-6f)) : 0.f;
+        s.m = f32x2{0.f, 0.f};
+        s.r = f32x2{0.f, 0.f};
+        s.th = theta0;
+#ifdef SAPCU_LIF_EXACT_ORDER
+        sx = neuron_init(p);
+        sy = neuron_init(p);
+#endif
+    }
+    __device__ __forceinline__ bool gate_open() const {
+#ifdef SAPCU_LIF_EXACT_ORDER
+        return sx.r <= 0.f || sy.r <= 0.f;
+#else
+        return s.r.x <= 0.f || s.r.y <= 0.f;
+#endif
+    }
+    // one step; x is the input (added only while the gate is open, i.e. at step 0 in eval mode)
+    __device__ __forceinline__ f32x2 step(f32x2 x, bool first) {
+#ifdef SAPCU_LIF_EXACT_ORDER
+        return f32x2{neuron_step<EIF>(x.x, sx, p), neuron_step<EIF>(x.y, sy, p)};
+#else
+        f32x2 mm;
+        if (first) {
+            mm = x;                                             // 0*decay*(1-0) + x
+        } else {
+            const f32x2 md = s.m * decay;
+            mm = pk_fma(-md, s.r, md);
+        }
+        if (EIF) {
+            f32x2 a = (s.m - p.rh) * inv_dT;
+            a = f32x2{clampf(a.x, -5.0f, 5.0f), clampf(a.y, -5.0f, 5.0f)} * 1.4426950408889634074f;
+            const f32x2 e = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+            mm = pk_fma(e, f32x2{p.dT, p.dT}, mm);
+        }
+        const f32x2 sp = soft_spike2(mm - s.th);
+        s.m = pk_fma(-mm, sp, mm);
+        s.r = first ? sp : pk_fma(s.r, rdecay, sp);
+        s.th = pk_fma(s.th, f32x2{0.95f, 0.95f}, pk_fma(sp, a95, thc));
+        return sp;
+#endif
+    }
+};
+
 // IEEE-correct f64 square root: the hardware/OCML result refined by one Markstein step
 // (s + (d - s*s) / (2 s) with the residual from an FMA), so that distances equal libm's sqrt.
 __device__ __forceinline__ double sqrt_cr(double d) {

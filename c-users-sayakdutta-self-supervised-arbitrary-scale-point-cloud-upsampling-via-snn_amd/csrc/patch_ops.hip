@@ -598,19 +598,25 @@ __global__ __launch_bounds__(FDE_CH) void fd_edge_neuron_kernel(const float* __r
     if (!live) return;
     const NeuronP p = EIF ? load_eif(prm, C, c) : load_lif(prm, C, c);
     const float sh = shift[c];
-    for (int i = 0; i < m; ++i) {
-        const int64_t row = row0 + i;
-        const int32_t* ir = idx + row * kk;
-        float mx = -__builtin_huge_valf();
-        for (int j = 0; j < kk; ++j) mx = fmaxf(mx, sA[ir[j] * FDE_CH + tx]);
-        const float pre = lrelu02(__fadd_rn(__fsub_rn(mx, in[row * ldi + C + c]), sh));
-        NeuronS s = neuron_init(p);
+    // two points per pass: their neuron chains share every packed instruction (an odd m repeats the last point)
+    for (int i = 0; i < m; i += 2) {
+        const int i1 = (i + 1 < m) ? i + 1 : i;
+        const int64_t ra = row0 + i, rb = row0 + i1;
+        const int32_t* ia = idx + ra * kk;
+        const int32_t* ib = idx + rb * kk;
+        float ma = -__builtin_huge_valf(), mb = ma;
+        for (int j = 0; j < kk; ++j) {
+            ma = fmaxf(ma, sA[ia[j] * FDE_CH + tx]);
+            mb = fmaxf(mb, sA[ib[j] * FDE_CH + tx]);
+        }
+        const f32x2 pre = f32x2{lrelu02(__fadd_rn(__fsub_rn(ma, in[ra * ldi + C + c]), sh)),
+                                lrelu02(__fadd_rn(__fsub_rn(mb, in[rb * ldi + C + c]), sh))};
+        NeuronStep2<EIF> ns(p);
         for (int step = 0; step < T; ++step) {
-            float x = 0.f;
-            if (step == 0) x = pre;
-            else if (s.r <= 0.f) atomicAdd(gate_violations, 1);
-            const float sp = neuron_step<EIF>(x, s, p);
-            spk[((int64_t)step * pts + row) * ldo + coff + c] = sp;
+            if (step > 0 && ns.gate_open()) atomicAdd(gate_violations, 1);
+            const f32x2 sp = ns.step(step == 0 ? pre : f32x2{0.f, 0.f}, step == 0);
+            spk[((int64_t)step * pts + ra) * ldo + coff + c] = sp.x;
+            if (i1 != i) spk[((int64_t)step * pts + rb) * ldo + coff + c] = sp.y;
         }
     }
 }
