@@ -265,11 +265,98 @@ __global__ __launch_bounds__(256) void fn_pe1_kernel(const float* __restrict__ p
     }
 }
 
+// Same stage with a lane owning FOUR CONSECUTIVE CHANNELS of a row (d/4 threads per row, 256/(d/4) rows per pass, two
+// passes' rows stepped together = 4 packed neuron chains): the outputs leave as 8-byte (split rows) or 16-byte stores
+// instead of 2/4-byte ones — the one-channel-per-lane form spent as long on store issue as on the neuron loop.
+// Needs d % 4 == 0 with d/4 a power of two <= 256 (the model's 128/256/512); other widths use fn_pe1_kernel.
+__global__ __launch_bounds__(256) void fn_pe1_vec4_kernel(const float* __restrict__ patch, const int32_t* __restrict__ idx,
+                                                          int64_t rows, int m, int kk, int d,
+                                                          const float* __restrict__ w /*[d][3]*/,
+                                                          const float* __restrict__ bias, const float* __restrict__ lif,
+                                                          int T, float* __restrict__ out, int split) {
+    __shared__ float pd[PE_ROWS][3];
+    const int64_t row0 = (int64_t)blockIdx.x * PE_ROWS;
+    if (threadIdx.x < PE_ROWS) {
+        const int64_t r = row0 + threadIdx.x;
+        float dx = 0.f, dy = 0.f, dz = 0.f;
+        if (r < rows) {
+            const int64_t pt = r / kk;
+            const int64_t patch_i = pt / m;
+            const float* pi = patch + pt * 3;
+            const float* pj = patch + (patch_i * m + idx[r]) * 3;
+            dx = __fsub_rn(pi[0], pj[0]);
+            dy = __fsub_rn(pi[1], pj[1]);
+            dz = __fsub_rn(pi[2], pj[2]);
+        }
+        pd[threadIdx.x][0] = dx;
+        pd[threadIdx.x][1] = dy;
+        pd[threadIdx.x][2] = dz;
+    }
+    __syncthreads();
+    const int tpr = d >> 2;                               // threads per row
+    const int rpp = 256 / tpr;                            // rows per pass
+    const int rsub = threadIdx.x / tpr;
+    const int c = (threadIdx.x - rsub * tpr) * 4;
+    float wx[4], wy[4], wz[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        wx[u] = w[(c + u) * 3];
+        wy[u] = w[(c + u) * 3 + 1];
+        wz[u] = w[(c + u) * 3 + 2];
+    }
+    const float4 bb = ld4(bias + c);
+    const float4 pdc = ld4(lif + c), pad = ld4(lif + d + c), prd = ld4(lif + 2 * (int64_t)d + c), pth = ld4(lif + 3 * (int64_t)d + c);
+    NeuronP2 np[2];
+    np[0].decay = f32x2{clampf(pdc.x, 0.1f, 0.99f), clampf(pdc.y, 0.1f, 0.99f)};
+    np[1].decay = f32x2{clampf(pdc.z, 0.1f, 0.99f), clampf(pdc.w, 0.1f, 0.99f)};
+    np[0].adapt = f32x2{clampf(pad.x, 0.001f, 0.1f), clampf(pad.y, 0.001f, 0.1f)};
+    np[1].adapt = f32x2{clampf(pad.z, 0.001f, 0.1f), clampf(pad.w, 0.001f, 0.1f)};
+    np[0].rdecay = f32x2{clampf(prd.x, 0.1f, 0.95f), clampf(prd.y, 0.1f, 0.95f)};
+    np[1].rdecay = f32x2{clampf(prd.z, 0.1f, 0.95f), clampf(prd.w, 0.1f, 0.95f)};
+    np[0].theta0 = f32x2{pth.x, pth.y};
+    np[1].theta0 = f32x2{pth.z, pth.w};
+    const NeuronP2 np4[4] = {np[0], np[1], np[0], np[1]};
+    const float bs[4] = {bb.x, bb.y, bb.z, bb.w};
+    const int nrow = (int)((rows - row0) < PE_ROWS ? (rows - row0) : PE_ROWS);
+    for (int r = rsub; r < nrow; r += 2 * rpp) {
+        const int rb = r + rpp < PE_ROWS ? r + rpp : r;    // second row of the pair (may be past nrow: computed, not stored)
+        float va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float a = __fmul_rn(wx[u], pd[r][0]);
+            a = __fmaf_rn(wy[u], pd[r][1], a);
+            a = __fmaf_rn(wz[u], pd[r][2], a);
+            va[u] = __fadd_rn(a, bs[u]);
+            float b2 = __fmul_rn(wx[u], pd[rb][0]);
+            b2 = __fmaf_rn(wy[u], pd[rb][1], b2);
+            b2 = __fmaf_rn(wz[u], pd[rb][2], b2);
+            vb[u] = __fadd_rn(b2, bs[u]);
+        }
+        f32x2 pv[4] = {f32x2{va[0], va[1]}, f32x2{va[2], va[3]}, f32x2{vb[0], vb[1]}, f32x2{vb[2], vb[3]}};
+        lif_selfloop_pairs<4>(pv, np4, T);
+        const float oa[4] = {pv[0].x, pv[0].y, pv[1].x, pv[1].y}, ob[4] = {pv[2].x, pv[2].y, pv[3].x, pv[3].y};
+        if (split) store_split4<true>(out, row0 + r, d, c, d, oa);     // operand of the pos-enc ring GEMM
+        else store_f32x4<true>(out, row0 + r, d, c, d, oa);
+        if (rb != r && rb < nrow) {
+            if (split) store_split4<true>(out, row0 + rb, d, c, d, ob);
+            else store_f32x4<true>(out, row0 + rb, d, c, d, ob);
+        }
+    }
+}
+
 int launch_fn_pe1(const float* patch, const int32_t* idx, int64_t rows, int m, int kk, int d, const float* w,
                   const float* bias, const float* lif, int T, float* out, int split, hipStream_t st) {
     if (rows == 0) return SAPCU_OK;
     const int64_t strips = (rows + PE_ROWS - 1) / PE_ROWS;
     SAPCU_CHECK_ARG(strips < 0x7fffffffLL, "pe1: too many rows");
+    const int tpr = d / 4;
+    const bool al16 = (((uintptr_t)bias | (uintptr_t)lif | (uintptr_t)out) & 15) == 0;
+    if (d % 4 == 0 && tpr >= 1 && tpr <= 256 && (tpr & (tpr - 1)) == 0 && al16) {
+        hipLaunchKernelGGL(fn_pe1_vec4_kernel, dim3((unsigned)strips), dim3(256), 0, st, patch, idx, rows, m, kk, d, w, bias, lif,
+                           T, out, split);
+        SAPCU_CHECK_LAUNCH();
+        return SAPCU_OK;
+    }
     const int bx = d < 256 ? ((d + 63) / 64) * 64 : 256;
     hipLaunchKernelGGL(fn_pe1_kernel, dim3((unsigned)strips, (unsigned)((d + bx - 1) / bx)), dim3(bx), 0, st, patch, idx,
                        rows, m, kk, d, w, bias, lif, T, out, split);
