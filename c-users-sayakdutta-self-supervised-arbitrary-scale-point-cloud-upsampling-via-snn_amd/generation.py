@@ -59,6 +59,8 @@ def knn_gather(cloud_dev, queries_dev, k, want_dist=False, want_patch=True):
     """Outer kNN on the device: (idx int64 [b,k], dist f64 [b,k] | None, patch f32 [b,k,3] | None)."""
     lib = _lib.load()
     b, n = queries_dev.shape[0], cloud_dev.shape[0]
+    if k > n:      # sklearn's KDTree.query raises the same way (generation.py:127)
+        raise ValueError("k must be less than or equal to the number of training points (k=%d, N=%d)" % (k, n))
     dev = cloud_dev.device
     idx = torch.empty((b, k), dtype=torch.int64, device=dev)
     dist = torch.empty((b, k), dtype=torch.float64, device=dev) if want_dist else None
@@ -187,6 +189,9 @@ class Generator3D6(object):
     def upsample_seeds(self, data, seeds, return_unfiltered=False):
         cloud_dev = torch.as_tensor(np.ascontiguousarray(data, dtype=np.float64), device=self.device)
         seeds_dev = torch.as_tensor(np.ascontiguousarray(seeds, dtype=np.float64), device=self.device)
+        if seeds_dev.shape[0] == 0:        # nothing in the distance band (the reference fails inside np.loadtxt here)
+            empty = np.zeros((0, 3), dtype=np.float64)
+            return (empty, empty) if return_unfiltered else empty
         with torch.no_grad():
             refined, _, _ = self.refine(cloud_dev, seeds_dev)
             keep = self.outlier_filter(refined)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Whole-cloud run of Generator3D6.upsample (seeds in process -> hot path -> outlier filter), stage-timed."""
+"""Whole-cloud run of generate.py's per-cloud body (seeds in process -> hot path -> outlier filter -> FPS to 4N), stage-timed."""
 import os
 import sys
 import time
@@ -36,9 +36,17 @@ def main():
         t4 = time.perf_counter()
     out = refined.cpu().numpy()[keep]
     t5 = time.perf_counter()
+    from sapcu_amd import pipeline
+    target = min(4 * n, out.shape[0])                      # generate.py: FPS to 4x the input size
+    pipeline.farthest_point_sample(out[:1000], 8)         # (library warm-up)
+    t6 = time.perf_counter()
+    picked = pipeline.farthest_point_sample(out, target)
+    t7 = time.perf_counter()
     print("cloud N=%d: %d seeds | seeds %.2f s | hot path %.2f s (%.0f query-points/s) | outlier filter %.2f s | copy-out %.2f s | "
-          "kept %d | radius mean %.4f std %.4f" % (n, seeds.shape[0], t1 - t0, t3 - t2, seeds.shape[0] / (t3 - t2), t4 - t3, t5 - t4,
-                                                     out.shape[0], np.linalg.norm(out, axis=1).mean(), np.linalg.norm(out, axis=1).std()))
+          "FPS to %d: %.3f s | kept %d | radius mean %.4f std %.4f" % (
+              n, seeds.shape[0], t1 - t0, t3 - t2, seeds.shape[0] / (t3 - t2), t4 - t3, t5 - t4, target, t7 - t6, out.shape[0],
+              np.linalg.norm(out, axis=1).mean(), np.linalg.norm(out, axis=1).std()))
+    assert np.unique(picked).shape[0] == target
 
 
 if __name__ == "__main__":

@@ -539,3 +539,28 @@ def test_process_cloud_pipeline_end_to_end(weights):
     cloud, loc, scale = F.normalize_pointcloud(raw)
     up = np.array(gen.upsample(cloud[None])) * scale + loc
     np.testing.assert_array_equal(out, up[F.farthest_point_sample(up, 512)])
+
+
+@pytest.mark.gpu
+def test_generator_edge_cases(weights):
+    """no seeds, one seed, a ragged last batch, fewer cloud points than neighbours (KDTree.query's ValueError)"""
+    import sapcu_amd
+    from sapcu_amd import testing as T
+    fn_gpu, fd_gpu, sdn, sdd = U.build_gpu_models(weights)
+    fn_gpu.knn_cache_mode = "fresh"
+    gen = sapcu_amd.Generator3D6(fn_gpu, fd_gpu, U.dev(), k_neighbors=48, batch_size=7)
+    cloud = T.sphere_cloud(500, 0)
+    assert gen.upsample_seeds(cloud, np.zeros((0, 3))).shape == (0, 3)
+    q = T.grid_queries(23, 0)
+    kept, full = gen.upsample_seeds(cloud, q, return_unfiltered=True)          # batches of 7/8 queries (array_split), last ragged
+    assert full.shape == (23, 3) and np.isfinite(full).all()
+    one, full1 = gen.upsample_seeds(cloud, q[:1], return_unfiltered=True)
+    assert full1.shape == (1, 3)
+    # batch composition must not matter in 'fresh' mode: one big batch gives the same points
+    gen_big = sapcu_amd.Generator3D6(fn_gpu, fd_gpu, U.dev(), k_neighbors=48, batch_size=4096)
+    _, full_big = gen_big.upsample_seeds(cloud, q, return_unfiltered=True)
+    np.testing.assert_allclose(full, full_big, rtol=0, atol=2e-4)              # fd feature-kNN near-ties may flip: distribution bar
+    assert np.median(np.abs(full - full_big)) < 1e-6
+    np.testing.assert_allclose(full1[0], full_big[0], rtol=0, atol=2e-4)
+    with pytest.raises(ValueError):
+        gen.upsample_seeds(cloud[:40], q)                                      # 40 points < 48 neighbours
