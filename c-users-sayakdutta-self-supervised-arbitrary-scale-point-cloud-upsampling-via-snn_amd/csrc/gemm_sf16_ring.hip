@@ -9,23 +9,24 @@
 //
 // Why: with one k-step of prefetch the f32-A kernel was bound by operand latency (bias-only GEMM at
 // r=294912, k=n=512: 690 us against ~200 us of matrix-pipe time; removing the A loads, the W loads or the
-// MFMAs each saved only 15-25 %).  Here a 4-slot ring keeps THREE k-steps (96 KiB per CU) in flight across
-// tile boundaries, and the producer waves execute nothing but ds_read + MFMA + 4 DMA issues per k-step.
+// MFMAs each saved only 15-25 %).  Here the rings keep several k-steps in flight across tile boundaries, and the
+// producer waves execute nothing but ds_read + MFMA + 4 DMA issues per k-step.
 //
 // Structure: ONE 1024-thread workgroup per CU, persistent over 128x128 tiles.
 //   waves 0-7   PRODUCERS, 4x2 sub-tiles of 32x64 (2 MFMA tiles, 32 accumulator registers each).
-//               k-step = 32: per step  s_waitcnt vmcnt(keep 2 steps in flight) -> barrier -> issue the DMAs of
-//               step g+3 into the slot read at step g-1 -> 12 MFMAs from slot g%4.
+//               k-step = 32: per step  s_waitcnt vmcnt(own DMAs of the next step landed) -> barrier -> issue the DMAs
+//               that refill the slots just read -> 12 MFMAs.  Waves 0-3 stream the activation operand (5-slot ring,
+//               4 steps ahead: first touches, HBM latency), waves 4-7 the weight operand (3-slot ring, L2 hits).
 //   waves 8-15  CONSUMERS (two VALU waves per SIMD): epilogue of the PREVIOUS tile, in 8 pieces of one float4
 //               (one row x 4 consecutive columns per lane) between the k-step barriers, so that every global
 //               access of the epilogue is 8-16 bytes per lane (gemm_epi.h, epilogue_row4).
 //   hand-off    through a 32 KiB LDS area in two halves: first the column-tile-1 half (consumers copy their 16
 //               values to registers), then the column-tile-0 half, which STAYS there and is read piece by piece
-//               during the next tile — the ring keeps streaming underneath.  The area is where the accumulators
+//               during the next tile — the rings keep streaming underneath.  The area is where the accumulators
 //               change from the MFMA layout (lane = column, register = row) to the row layout: producers write
 //               row rr of their 32x32 block at slot rr ^ ((rr>>2)&1) (pitch 32 floats: the two rows of one
 //               ds_write_b32 land in different bank halves), consumers read float4s (two rows per 16 lanes).
-//   LDS         4 slots x (A_hi | A_lo | W_hi | W_lo) x [128 rows][32 halves] = 128 KiB + 32 KiB hand-off = 160 KiB.
+//   LDS         8 operand slots x (hi | lo) x [128 rows][32 halves] = 128 KiB + 32 KiB hand-off = 160 KiB.
 //               64-byte rows, 16-byte chunk index XOR-swizzled by (row>>2)&3: conflict-free ds_read_b128; the DMA
 //               destination is lane-linear, so the swizzle is applied to each lane's SOURCE address.
 #include "common.h"
@@ -38,9 +39,6 @@ typedef __attribute__((address_space(3))) unsigned char lds_byte;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 
 constexpr int RBM = 128, RBN = 128, RBK = 32;
-// issue the DMAs of a k-step one at a time between MFMAs instead of in a burst behind the barrier: measured SLOWER
-// (bias GEMM r=1179648, k=n=512: 2928 us vs 2645 us), kept for reference
-constexpr bool RING_INTERLEAVE_DMA = false;
 // Tile order.  Interleaved (default): the n-tiles of one 128-row panel run at the same time on workgroups of ONE XCD, so
 // the A panel leaves HBM once and its other readers hit that XCD's L2.  Contiguous (-DSAPCU_RING_TILES_CONTIGUOUS): each
 // workgroup walks a contiguous run of tiles; measured the same speed (+-2 %) but 3.8x the HBM fetch traffic
@@ -51,15 +49,20 @@ constexpr bool RING_TILES_INTERLEAVED = false;
 constexpr bool RING_TILES_INTERLEAVED = true;
 #endif
 constexpr int RPLANE = RBM * RBK * 2;            // 8 KiB
-constexpr int RSLOT = 4 * RPLANE;                // 32 KiB
-constexpr int RSLOTS = 4;
+constexpr int ROPSLOT = 2 * RPLANE;              // 16 KiB: one operand's hi | lo planes of one k-step
+// ring depths (8 operand slots = 128 KiB in all): activations 5 + weights 3; for k <= 128 activations 6 + weights 2
+// (those launches are HBM-bound on the activation stream and a tile has only 4 k-steps).  Measured per launch on one box,
+// 5+3 against the former 4+4 joint ring: d=512 bias 2768 -> 2592 us, d=256 bias 1300 -> 1214 us; 6+2 at d=512: 2775 us.
+constexpr int RING_SLOTS = 8;
+constexpr int RING_BYTES = RING_SLOTS * ROPSLOT;   // 128 KiB
 constexpr int RHAND = 8 * 16 * 64 * 4;           // 32 KiB: one column-tile half of the accumulators
-constexpr int RING_LDS_BYTES = RSLOTS * RSLOT + RHAND;
+constexpr int RING_LDS_BYTES = RING_BYTES + RHAND;
 
 // wait until at most N of this wave's vector-memory operations (the ring's DMAs) are outstanding
 template <int N>
 __device__ __forceinline__ void wait_vm() {
-    if (N >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if (N >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -77,7 +80,9 @@ __device__ unsigned long long g_ring_stamps[256][8];
 template <int EPI, bool VEC>
 __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
-    float* hand = reinterpret_cast<float*>(smem_raw + RSLOTS * RSLOT);
+    float* hand = reinterpret_cast<float*>(smem_raw + RING_BYTES);
+    const int RA_SLOTS = g.k <= 128 ? 6 : 5, RW_SLOTS = RING_SLOTS - RA_SLOTS;     // wave-uniform
+    const int RA_BYTES = RA_SLOTS * ROPSLOT;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform: keep it (and all it feeds) in scalar registers
@@ -119,9 +124,16 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
     const int first_tn = (int)(first_logical - first_tm * ntn);
 
     if (producer) {
-        // DMA role: wave w moves piece w (rows 16w..16w+15) of each of the 4 planes; lane -> 16-byte chunk
-        const int drow = pw * 16 + (lane >> 2);
-        const int dsrc = ((lane & 3) ^ ((drow >> 2) & 3)) * 8;     // source k offset (halves) of this lane's LDS chunk
+        // DMA role.  Waves 0-3 stream the ACTIVATION operand, waves 4-7 the WEIGHT operand: a wave's vector-memory
+        // counter is in order, so two streams with different look-ahead cannot share a wave.  The activation rows are
+        // first touches (HBM latency, ~2.7 us under load: measured 2272 us delivery-only against 1339 us when the A
+        // panel is L2-hot), the weight tile is always an L2 hit: A runs 4 k-steps ahead in a 5-slot ring, W 2 k-steps
+        // ahead in a 3-slot ring.  Per k-step a wave issues 4 DMAs of 1 KiB: rows 32*sub .. 32*sub+31 of its operand
+        // (two 16-row pieces) x (hi plane, lo plane); lane -> (row = lane>>2, 16-byte chunk = lane&3).
+        const bool is_a = pw < 4;
+        const int sub = pw & 3;
+        const int depth = is_a ? RA_SLOTS : RW_SLOTS;
+        const int dsb = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;     // source byte offset of this lane's (swizzled) LDS chunk
         // fragment rows / swizzles
         const int arow_l = wm * 32 + r32;
         const int asw = (arow_l >> 2) & 3;
@@ -132,91 +144,65 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
             wsw[j] = (wrow_l[j] >> 2) & 3;
         }
         // DMA sources = wave-uniform base of the tile (scalar registers, all per-step arithmetic on the scalar unit)
-        // + one 32-bit per-lane byte offset per operand that only changes with the tile (edge clamps)
-        const char* a8 = reinterpret_cast<const char*>(g.a);
-        const int64_t a_pitch_b = 4 * (int64_t)g.lda;              // bytes per A row (hi halves, then lo halves at +2*lda)
+        // + two 32-bit per-lane byte offsets (first / second 16-row piece) that only change with the tile (edge clamps)
+        const int64_t pitch_b = is_a ? 4 * (int64_t)g.lda : 2 * (int64_t)g.k;     // bytes per operand row (hi plane)
+        const int64_t lo_delta = is_a ? 2 * (int64_t)g.lda
+                                      : reinterpret_cast<const char*>(g.w16_lo) - reinterpret_cast<const char*>(g.w16_hi);
+        const char* const op_base = is_a ? reinterpret_cast<const char*>(g.a) : reinterpret_cast<const char*>(g.w16_hi);
         const int64_t total_steps = my_tiles * nk;
 
-        // prefetch cursor: global step index -> (tile, k-step)
+        // prefetch cursor of this wave's stream: global step index -> (tile, k-step)
         int64_t pf_tile = 0;
         int pf_kt = 0;
-        const char* pf_abase = nullptr;                            // uniform: first row of the tile
-        const char* pf_wbase = nullptr;                            // uniform: first weight row (hi plane) of the tile
-        const int64_t wlo_delta = reinterpret_cast<const char*>(g.w16_lo) - reinterpret_cast<const char*>(g.w16_hi);
-        unsigned pf_aoff = 0, pf_woff = 0;                         // per lane
-        const unsigned aoff_full = (unsigned)(drow * (int)a_pitch_b + dsrc * 2);   // interior tiles
-        const unsigned woff_full = (unsigned)(drow * g.k * 2 + dsrc * 2);
+        const char* pf_base = nullptr;                             // uniform: first row of the tile's operand
+        unsigned pf_off0 = 0, pf_off1 = 0;                         // per lane
+        const int lrow = 32 * sub + (lane >> 2);
+        const unsigned off0_full = (unsigned)(lrow * (int)pitch_b + dsb);          // interior tiles
+        const unsigned off1_full = (unsigned)((lrow + 16) * (int)pitch_b + dsb);
         int64_t pf_tm = first_tm;                                  // tile coordinates of the cursor
         int pf_tn = first_tn;
         auto pf_setup = [&]() {
-            const int64_t row0 = pf_tm * RBM;
-            const int col0 = pf_tn * RBN;
-            const int64_t rows_left = g.r - row0;                  // >= 1
-            pf_abase = a8 + row0 * a_pitch_b;
-            pf_wbase = reinterpret_cast<const char*>(g.w16_hi) + (int64_t)col0 * g.k * 2;
-            const int cols_left = g.n - col0;
-            pf_aoff = aoff_full;
-            pf_woff = woff_full;
-            if (rows_left < RBM || cols_left < RBN) {              // edge tile (uniform, rare): clamped rows only feed masked outputs
-                const int dr = pw * 16 + (lane >> 2);
-                const int ds = ((lane & 3) ^ ((dr >> 2) & 3)) * 16;
-                const int ar = dr < rows_left ? dr : (int)(rows_left - 1);
-                const int nn = dr < cols_left ? dr : cols_left - 1;
-                pf_aoff = (unsigned)(ar * (int)a_pitch_b + ds);
-                pf_woff = (unsigned)(nn * g.k * 2 + ds);
-            }
-        };
-        // the four DMAs of one k-step are issued ONE AT A TIME between MFMAs (issue_piece 0..3): a DMA issue holds the
-        // wave for 60-180 cycles, which hides behind the matrix pipe only if MFMAs are already queued
-        auto issue_piece = [&](int64_t gstep, int piece) {         // cursor must be on gstep
-            lds_byte* sbase = (lds_byte*)(smem_raw + (int)(gstep & (RSLOTS - 1)) * RSLOT + pw * 1024);
-#ifdef SAPCU_ABL_LINE128   // traffic experiment (results are garbage): hi and lo of a k-step come from ONE 128-byte line
-            const int k0b = pf_kt * 128;
-            if (piece == 0) __builtin_amdgcn_global_load_lds((gptr_t)(pf_abase + k0b + pf_aoff), sbase, 16, 0, 0);
-            else if (piece == 1) __builtin_amdgcn_global_load_lds((gptr_t)(pf_abase + (k0b + 64) + pf_aoff), sbase + RPLANE, 16, 0, 0);
-            const char* wexp = pf_wbase + (pf_wbase - reinterpret_cast<const char*>(g.w16_hi));   // row pitch 4k bytes
-            const unsigned woffx = pf_woff + (unsigned)(drow * g.k * 2);
-            if (piece == 2) __builtin_amdgcn_global_load_lds((gptr_t)(wexp + k0b + woffx), sbase + 2 * RPLANE, 16, 0, 0);
-            else if (piece == 3) {
-                __builtin_amdgcn_global_load_lds((gptr_t)(wexp + (64 + k0b) + woffx), sbase + 3 * RPLANE, 16, 0, 0);
-                if (++pf_kt == nk) {
-                    pf_kt = 0;
-                    ++pf_tile;
-                    pf_tm += step_tm;
-                    pf_tn += step_tn;
-                    if (pf_tn >= ntn) { pf_tn -= ntn; ++pf_tm; }
-                    if (pf_tile < my_tiles) pf_setup();
-                }
-            }
+            const int64_t first = is_a ? pf_tm * RBM : (int64_t)pf_tn * RBN;      // first operand row of the tile
+            const int64_t left = (is_a ? g.r : (int64_t)g.n) - first;             // >= 1
+#ifdef SAPCU_ABL_A_HOT      // latency experiment (garbage results): every tile reads the FIRST row panel -> all A reads hit L2
+            pf_base = op_base + (is_a ? 0 : first * pitch_b);
 #else
-            const int k0b = pf_kt * RBK * 2;
-            if (piece == 0) __builtin_amdgcn_global_load_lds((gptr_t)(pf_abase + k0b + pf_aoff), sbase, 16, 0, 0);
-            else if (piece == 1) __builtin_amdgcn_global_load_lds((gptr_t)(pf_abase + (k0b + 2 * g.lda) + pf_aoff), sbase + RPLANE, 16, 0, 0);
-            else if (piece == 2) __builtin_amdgcn_global_load_lds((gptr_t)(pf_wbase + k0b + pf_woff), sbase + 2 * RPLANE, 16, 0, 0);
-            else {
-                __builtin_amdgcn_global_load_lds((gptr_t)(pf_wbase + (wlo_delta + k0b) + pf_woff), sbase + 3 * RPLANE, 16, 0, 0);
-                if (++pf_kt == nk) {
-                    pf_kt = 0;
-                    ++pf_tile;
-                    pf_tm += step_tm;
-                    pf_tn += step_tn;
-                    if (pf_tn >= ntn) { pf_tn -= ntn; ++pf_tm; }
-                    if (pf_tile < my_tiles) pf_setup();
-                }
+            pf_base = op_base + first * pitch_b;
+#endif
+            pf_off0 = off0_full;
+            pf_off1 = off1_full;
+            if (left < 128) {                                      // edge tile (uniform, rare): clamped rows only feed masked outputs
+                const int r0 = lrow < left ? lrow : (int)(left - 1);
+                const int r1 = lrow + 16 < left ? lrow + 16 : (int)(left - 1);
+                pf_off0 = (unsigned)(r0 * (int)pitch_b + dsb);
+                pf_off1 = (unsigned)(r1 * (int)pitch_b + dsb);
             }
-#endif
         };
-        auto issue = [&](int64_t gstep) {
-#ifdef SAPCU_ABL_NO_DMA       // compute-only experiment: the ring is never refilled (garbage operands)
-            if (++pf_kt == nk) { pf_kt = 0; ++pf_tile; }
-            return;
+        lds_byte* const ring0 = (lds_byte*)(smem_raw + (is_a ? 0 : RA_BYTES) + sub * 2048);
+        int issue_slot = 0;                                        // slot the next issued step goes to (wraps at depth)
+        int64_t issued = 0;                                        // steps issued by this wave
+        auto issue = [&]() {                                       // the 4 DMAs of this wave's next step
+#ifndef SAPCU_ABL_NO_DMA       // (compute-only experiment: the rings are never refilled)
+            lds_byte* sb = ring0 + issue_slot * ROPSLOT;
+            const char* src = pf_base + pf_kt * (RBK * 2);
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + pf_off0), sb, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + pf_off1), sb + 1024, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + lo_delta + pf_off0), sb + RPLANE, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + lo_delta + pf_off1), sb + RPLANE + 1024, 16, 0, 0);
 #endif
-#pragma unroll
-            for (int pc = 0; pc < 4; ++pc) issue_piece(gstep, pc);
+            ++issued;
+            if (++issue_slot == depth) issue_slot = 0;
+            if (++pf_kt == nk) {
+                pf_kt = 0;
+                ++pf_tile;
+                pf_tm += step_tm;
+                pf_tn += step_tn;
+                if (pf_tn >= ntn) { pf_tn -= ntn; ++pf_tm; }
+                if (pf_tile < my_tiles) pf_setup();
+            }
         };
         pf_setup();
-        int64_t issued = 0;
-        for (; issued < 3 && issued < total_steps; ++issued) issue(issued);
+        while (issued < depth && issued < total_steps) issue();
 
         // Fragment pipeline (half a k-step deep): the ds_reads of one k16 half are in flight while the six MFMAs of
         // the previous half run, and the k-step barrier sits BETWEEN the two halves of a step, so neither the LDS
@@ -224,17 +210,16 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
         struct Frags {
             half8 ah, al, wh[2], wl[2];
         };
-        auto read_frags = [&](int64_t step, int k16, Frags& f) {
+        auto read_frags = [&](int a_slot, int w_slot, int k16, Frags& f) {
 #ifdef SAPCU_ABL_NO_MFMA      // delivery-only experiment: DMAs, waits and barriers, no LDS reads, no MFMAs
             return;
 #endif
-            const unsigned char* st = smem_raw + (int)(step & (RSLOTS - 1)) * RSLOT;
-            const unsigned char* sA = st + arow_l * (RBK * 2) + (((k16 * 2 + h) ^ asw) * 16);
+            const unsigned char* sA = smem_raw + a_slot * ROPSLOT + arow_l * (RBK * 2) + (((k16 * 2 + h) ^ asw) * 16);
             f.ah = *reinterpret_cast<const half8*>(sA);
             f.al = *reinterpret_cast<const half8*>(sA + RPLANE);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const unsigned char* sW = st + 2 * RPLANE + wrow_l[j] * (RBK * 2) + (((k16 * 2 + h) ^ wsw[j]) * 16);
+                const unsigned char* sW = smem_raw + RA_BYTES + w_slot * ROPSLOT + wrow_l[j] * (RBK * 2) + (((k16 * 2 + h) ^ wsw[j]) * 16);
                 f.wh[j] = *reinterpret_cast<const half8*>(sW);
                 f.wl[j] = *reinterpret_cast<const half8*>(sW + RPLANE);
             }
@@ -252,30 +237,10 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wh[0], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wh[1], acc[1], 0, 0, 0);
         };
-        // the same six MFMAs with the DMAs of step `dstep` issued in the gaps
-        auto mfma6_dma = [&](const Frags& f, int64_t dstep) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.wh[0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.wh[1], acc[1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            issue_piece(dstep, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wl[0], acc[0], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            issue_piece(dstep, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wl[1], acc[1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            issue_piece(dstep, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wh[0], acc[0], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            issue_piece(dstep, 3);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wh[1], acc[1], 0, 0, 0);
-        };
-        auto wait_landed = [&](int64_t step) {     // this wave's DMAs of `step` have landed
+        auto wait_landed = [&](int64_t step) {     // this wave's DMAs of `step` have landed (4 DMAs per step, in order)
             const int64_t ahead = issued - step - 1;
-            if (ahead >= 3) wait_vm<12>();
+            if (ahead >= 4) wait_vm<16>();
+            else if (ahead == 3) wait_vm<12>();
             else if (ahead == 2) wait_vm<8>();
             else if (ahead == 1) wait_vm<4>();
             else wait_vm<0>();
@@ -283,14 +248,12 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
         // step 0 of the first tile
         wait_landed(0);
         lds_barrier();
-        if (issued < total_steps) {
-            issue(issued);
-            ++issued;
-        }
+        int ca = 0, cw = 0;                                         // ring slots of the current step
+        int na = 1, nw = 1;                                         // ... of the next step (both rings have >= 2 slots)
         float* const hand_even = hand + pw * 1024 + 5 * h * 32 + r32;
         float* const hand_odd = hand + pw * 1024 + 3 * h * 32 + r32;
         Frags f0, f1;
-        read_frags(0, 0, f0);
+        read_frags(ca, cw, 0, f0);
         int64_t gstep = 0;
 #ifdef SAPCU_RING_STAMPS
         unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0, tb = 0, tc = 0, td = 0, te = 0, tf = 0;
@@ -302,35 +265,29 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
                 for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
             for (int kt = 0; kt < nk; ++kt, ++gstep) {
                 RING_STAMP(ta);
-                read_frags(gstep, 1, f1);                           // second half of this step: lands behind mfma6(f0)
+                read_frags(ca, cw, 1, f1);                          // second half of this step: lands behind mfma6(f0)
                 mfma6(f0);
                 RING_STAMP(tb);
                 RING_SEG(0, ta, tb);                                // reads(f1) + 6 MFMAs issued (+ drain of the reads)
-                bool dma = false;
                 if (gstep + 1 < total_steps) {
                     wait_landed(gstep + 1);
                     RING_STAMP(tc);
                     RING_SEG(1, tb, tc);                            // own DMAs of the next step landed
-                    lds_barrier();                                  // step gstep+1 is in for everyone; slot gstep%4 fully read
+                    lds_barrier();                                  // step gstep+1 is in for everyone; this step's slots fully read
                     RING_STAMP(td);
                     RING_SEG(2, tc, td);                            // barrier
-                    if (!RING_INTERLEAVE_DMA && issued < total_steps) {
-                        issue(issued);                              // step gstep+4 -> slot gstep%4
-                        ++issued;
-                    }
+                    if (issued < total_steps) issue();              // step gstep+depth -> the slot just read
                     RING_STAMP(te);
                     RING_SEG(3, td, te);                            // DMA issue
-                    read_frags(gstep + 1, 0, f0);                   // first half of the next step: lands behind mfma6(f1)
-                    dma = RING_INTERLEAVE_DMA && issued < total_steps;
+                    read_frags(na, nw, 0, f0);                      // first half of the next step: lands behind mfma6(f1)
                 } else {
                     lds_barrier();                                  // keep the barrier count per step uniform
                 }
-                if (dma) {
-                    mfma6_dma(f1, issued);                          // step gstep+4 -> slot gstep%4, issued between the MFMAs
-                    ++issued;
-                } else {
-                    mfma6(f1);
-                }
+                mfma6(f1);
+                ca = na;
+                cw = nw;
+                if (++na == RA_SLOTS) na = 0;
+                if (++nw == RW_SLOTS) nw = 0;
                 RING_STAMP(tf);
                 RING_SEG(4, te, tf);                                // reads(f0') + 6 MFMAs issued
             }
