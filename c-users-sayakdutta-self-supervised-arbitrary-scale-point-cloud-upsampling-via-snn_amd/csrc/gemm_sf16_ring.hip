@@ -80,9 +80,13 @@ __device__ unsigned long long g_ring_stamps[256][8];
 template <int EPI, bool VEC>
 __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
-    float* hand = reinterpret_cast<float*>(smem_raw + RING_BYTES);
-    const int RA_SLOTS = g.k <= 128 ? 6 : 5, RW_SLOTS = RING_SLOTS - RA_SLOTS;     // wave-uniform
+    // EPI_SOFTMAX_AGG keeps the WHOLE tile's accumulators in LDS (the epilogue reduces over rows): 64 KiB hand-off area,
+    // 6 operand slots (activations 4, weights 2); its row tiles hold whole points: floor(128 / kk) * kk valid rows.
+    constexpr bool SMX = EPI == EPI_SOFTMAX_AGG;
+    const int RA_SLOTS = SMX ? 4 : (g.k <= 128 ? 6 : 5), RW_SLOTS = (SMX ? 6 : RING_SLOTS) - RA_SLOTS;     // wave-uniform
     const int RA_BYTES = RA_SLOTS * ROPSLOT;
+    float* hand = reinterpret_cast<float*>(smem_raw + (SMX ? 6 * ROPSLOT : RING_BYTES));
+    const int row_step = SMX ? (RBM / g.sm_kk) * g.sm_kk : RBM;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform: keep it (and all it feeds) in scalar registers
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
     const int r32 = lane & 31, h = lane >> 5;
 
     const int ntn = (g.n + RBN - 1) / RBN;
-    const int64_t ntm = (g.r + RBM - 1) / RBM;
+    const int64_t ntm = (g.r + row_step - 1) / row_step;
     const int64_t ntiles = ntm * ntn;
     const int nk = g.k / RBK;
     // tile order: see RING_TILES_INTERLEAVED
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
         int64_t pf_tm = first_tm;                                  // tile coordinates of the cursor
         int pf_tn = first_tn;
         auto pf_setup = [&]() {
-            const int64_t first = is_a ? pf_tm * RBM : (int64_t)pf_tn * RBN;      // first operand row of the tile
+            const int64_t first = is_a ? pf_tm * row_step : (int64_t)pf_tn * RBN;   // first operand row of the tile
             const int64_t left = (is_a ? g.r : (int64_t)g.n) - first;             // >= 1
 #ifdef SAPCU_ABL_A_HOT      // latency experiment (garbage results): every tile reads the FIRST row panel -> all A reads hit L2
             pf_base = op_base + (is_a ? 0 : first * pitch_b);
@@ -293,6 +297,17 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
             }
             RING_STAMP(ta);
             // hand-off in two halves through the 32 KiB area (the ring keeps streaming underneath)
+            if constexpr (SMX) {                                    // whole tile at once: block (pw, j) at (pw*2 + j) * 1024 floats
+                lds_barrier();                                      // consumers are done with the previous tile
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float* hb = (e & 1) ? hand_odd : hand_even;
+                        hb[pw * 1024 + j * 1024 + ((e & 3) + 8 * (e >> 2)) * 32] = acc[j][e];
+                    }
+                lds_barrier();                                      // tile is ready
+            } else
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 1 - jj;                               // column tile 1 first (goes to registers), then 0 (stays)
@@ -316,6 +331,115 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
             for (int i = 0; i < 8; ++i) g_ring_stamps[blockIdx.x][i] = seg[i];
         }
 #endif
+    } else if constexpr (SMX) {
+        // ---- fused softmax + aggregation (fn:378-389).  Consumer wave cw owns point cw (and cw+8, ...) of the tile; lane =
+        // one of the 64 columns of a column half jh (lanes 0-31: column block wn = 0, lanes 32-63: wn = 1).  A pair =
+        // (point, half): pass A turns the point's kk logits in the hand-off area into softmax numerators in place
+        // (max, exp, sum: same operation order as fn_softmax_agg_kernel), pass B walks the kk rows: weight from LDS,
+        // v[neighbour] and pe[row] from memory (row addresses are wave-uniform), one FMA.  The row walk is cut into
+        // slices between the k-step barriers; loads of a slice are issued together.
+        const int kk = g.sm_kk;
+        const int npt = row_step / kk;                             // points per tile
+        const int rounds = (npt + 7) >> 3;
+        const int npairs = 2 * rounds;
+        const int upk = (npairs * kk + nk - 1) / nk;               // row units per k-step
+        const int cwn = lane >> 5, cc = lane & 31;
+        const float inv_sqrt_hd = __fdiv_rn(1.0f, g.sm_sqrt_hd);
+        auto hand_idx = [&](int row_local, int jh) {               // accumulator (row_local, column lane) of half jh
+            const int rr = row_local & 31;
+            return (((row_local >> 5) * 2 + cwn) * 2 + jh) * 1024 + ((rr ^ ((rr >> 2) & 1)) * 32) + cc;
+        };
+        int64_t prev_row0 = -1;
+        int prev_col0 = 0;
+        int64_t cur_tm = first_tm;
+        int cur_tn = first_tn;
+        lds_barrier();                                             // pairs with the producers' "step 0 has landed"
+        for (int64_t ti = 0; ti <= my_tiles; ++ti) {               // last round = drain
+            const bool have = ti < my_tiles;
+            const bool cons_work = prev_row0 >= 0;
+            int p = 0, j = 0;                                      // cursor: pair, row inside the pair
+            float inv_den = 1.f, accv = 0.f;
+            int idxreg = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                int budget = cons_work ? upk : 0;
+                while (budget > 0 && p < npairs) {
+                    const int rnd = p >> 1, jh = p & 1;
+                    const int pt_local = pw + 8 * rnd;
+                    const int64_t row_first = prev_row0 + (int64_t)pt_local * kk;        // first edge row of the point
+                    const bool pt_ok = pt_local < npt && row_first < g.r;                // wave-uniform
+                    const int col = prev_col0 + cwn * 64 + jh * 32 + cc;
+                    const bool ok = pt_ok && col < g.n;
+                    const int64_t pt_global = row_first / kk;
+                    // rows of this slice: up to 12 per batch of loads, issued BEFORE pass A so that the logit pass covers them
+                    int cnt = kk - j;
+                    if (cnt > budget) cnt = budget;
+                    if (cnt > 12) cnt = 12;
+                    float vb[12], pb[12];
+                    if (j == 0 && pt_ok) idxreg = lane < kk ? g.sm_idx[row_first + lane] : 0;
+                    if (pt_ok) {
+                        const int64_t patch_row0 = (pt_global / g.sm_m) * g.sm_m;
+#pragma unroll
+                        for (int u = 0; u < 12; ++u) {
+                            vb[u] = 0.f;
+                            pb[u] = 0.f;
+                            if (u < cnt) {
+                                const int nbr = __builtin_amdgcn_readlane(idxreg, j + u);
+                                if (ok) {
+                                    vb[u] = g.sm_v[(patch_row0 + nbr) * g.sm_ldv + col];
+                                    pb[u] = g.sm_pe[(row_first + j + u) * g.sm_ldpe + col];
+                                }
+                            }
+                        }
+                    }
+                    if (j == 0 && pt_ok) {                         // pass A
+                        const float biasv = (ok && g.bias) ? g.bias[col] : 0.f;
+                        float mx = -__builtin_huge_valf();
+                        for (int jj = 0; jj < kk; ++jj) {
+                            float* hp = hand + hand_idx(pt_local * kk + jj, jh);
+                            const float x = __fmul_rn(__fmaf_rn(*hp, 0.0625f, biasv), inv_sqrt_hd);
+                            *hp = x;
+                            mx = fmaxf(mx, x);
+                        }
+                        float den = 0.f;
+                        for (int jj = 0; jj < kk; ++jj) {
+                            float* hp = hand + hand_idx(pt_local * kk + jj, jh);
+                            const float e = fast_exp(__fsub_rn(*hp, mx));
+                            *hp = e;
+                            den = __fadd_rn(den, e);
+                        }
+                        inv_den = __fdiv_rn(1.0f, den);
+                        accv = 0.f;
+                    }
+                    if (pt_ok) {
+#pragma unroll
+                        for (int u = 0; u < 12; ++u)
+                            if (u < cnt) {
+                                const float w = hand[hand_idx(pt_local * kk + j + u, jh)];
+                                accv = __fmaf_rn(__fmul_rn(w, inv_den), __fadd_rn(vb[u], pb[u]), accv);
+                            }
+                    }
+                    j += cnt;
+                    budget -= cnt;
+                    if (j == kk) {
+                        if (ok) {
+                            if (g.c_split) store_split(g.c, pt_global, g.ldc, col, accv);
+                            else g.c[pt_global * g.ldc + col] = accv;
+                        }
+                        j = 0;
+                        ++p;
+                    }
+                }
+                if (have) lds_barrier();                            // the producers' mid-step barrier of this k-step
+            }
+            if (!have) break;
+            lds_barrier();                                          // (we are done with the area: producers may overwrite)
+            lds_barrier();                                          // the tile is in
+            prev_row0 = cur_tm * row_step;
+            prev_col0 = cur_tn * RBN;
+            cur_tm += step_tm;
+            cur_tn += step_tn;
+            if (cur_tn >= ntn) { cur_tn -= ntn; ++cur_tm; }
+        }
     } else {
         // row layout of this wave's 32x64 sub-tile: lane = (row slot s = lane>>3, column group c4 = lane&7);
         // piece pi = 4*j + p covers row p*8 + s, columns j*32 + c4*4 .. +3 of the sub-tile
@@ -431,7 +555,8 @@ static int launch_ring_tv(const GemmArgs& g, hipStream_t st) {
         SAPCU_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
         g_num_cus_ring = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const int64_t tiles = ((g.r + RBM - 1) / RBM) * ((g.n + RBN - 1) / RBN);
+    const int row_step = EPI == EPI_SOFTMAX_AGG ? (RBM / g.sm_kk) * g.sm_kk : RBM;
+    const int64_t tiles = ((g.r + row_step - 1) / row_step) * ((g.n + RBN - 1) / RBN);
     const int64_t grid = tiles < g_num_cus_ring ? tiles : g_num_cus_ring;
     hipLaunchKernelGGL((gemm_ring_kernel<EPI, VEC>), dim3((unsigned)grid), dim3(1024), RING_LDS_BYTES, st, g);
     SAPCU_CHECK_LAUNCH();
@@ -469,6 +594,11 @@ int launch_gemm_sf16_ring(const GemmArgs& g, hipStream_t st) {
         case EPI_RESID: return launch_ring_t<EPI_RESID>(g, st);
         case EPI_LRELU: return launch_ring_t<EPI_LRELU>(g, st);
         case EPI_RESID_GELU: return launch_ring_t<EPI_RESID_GELU>(g, st);
+        case EPI_SOFTMAX_AGG:
+            SAPCU_CHECK_ARG(g.sm_kk >= 1 && g.sm_kk <= 64 && g.sm_m >= 1 && g.r % g.sm_kk == 0 && g.sm_idx && g.sm_pe && g.sm_v &&
+                                g.sm_ldpe >= g.n && g.sm_ldv >= g.n && g.sm_sqrt_hd > 0.f && g.c,
+                            "gemm_ring: bad softmax-aggregate operands (kk=%d)", g.sm_kk);
+            return launch_ring_tv<EPI_SOFTMAX_AGG, true>(g, st);
         case EPI_LIF_ATTN:
             SAPCU_CHECK_ARG(g.ldq > 0 && g.tab && g.q && g.kf && g.c2, "gemm_ring: bad attn operands");
             return launch_ring_t<EPI_LIF_ATTN>(g, st);

@@ -406,12 +406,15 @@ __global__ __launch_bounds__(256) void fn_softmax_agg_kernel(const float* __rest
     const float* ar = a + pt * kk * d + c;
     const float* pr = pe + pt * kk * d + c;
     const int32_t* ir = idx + pt * kk;
+    // 1/sqrt(hd) and 1/sum as correctly rounded reciprocals, then multiplications (two roundings where torch's division
+    // has one: <= 1 ulp on a logit / weight); the fused form in gemm_sf16_ring.hip computes exactly the same
+    const float inv_sqrt_hd = __fdiv_rn(1.0f, sqrt_hd);
     if (KK > 0) {
         float x[KK > 0 ? KK : 1];
         float mx = -__builtin_huge_valf();
 #pragma unroll
         for (int j = 0; j < KK; ++j) {
-            x[j] = __fdiv_rn(ar[(int64_t)j * d], sqrt_hd);
+            x[j] = __fmul_rn(ar[(int64_t)j * d], inv_sqrt_hd);
             mx = fmaxf(mx, x[j]);
         }
         float den = 0.f;
@@ -420,22 +423,24 @@ __global__ __launch_bounds__(256) void fn_softmax_agg_kernel(const float* __rest
             x[j] = fast_exp(__fsub_rn(x[j], mx));
             den = __fadd_rn(den, x[j]);
         }
+        const float inv_den = __fdiv_rn(1.0f, den);
         float acc = 0.f;
 #pragma unroll
         for (int j = 0; j < KK; ++j) {
             const float vv = __fadd_rn(v[(patch_i * m + ir[j]) * ldv + c], pr[(int64_t)j * d]);
-            acc = __fmaf_rn(__fdiv_rn(x[j], den), vv, acc);
+            acc = __fmaf_rn(__fmul_rn(x[j], inv_den), vv, acc);
         }
         if (split) store_split(res, pt, d, c, acc);
         else res[t] = acc;
     } else {
         float mx = -__builtin_huge_valf();
-        for (int j = 0; j < kk; ++j) mx = fmaxf(mx, __fdiv_rn(ar[(int64_t)j * d], sqrt_hd));
+        for (int j = 0; j < kk; ++j) mx = fmaxf(mx, __fmul_rn(ar[(int64_t)j * d], inv_sqrt_hd));
         float den = 0.f;
-        for (int j = 0; j < kk; ++j) den = __fadd_rn(den, fast_exp(__fsub_rn(__fdiv_rn(ar[(int64_t)j * d], sqrt_hd), mx)));
+        for (int j = 0; j < kk; ++j) den = __fadd_rn(den, fast_exp(__fsub_rn(__fmul_rn(ar[(int64_t)j * d], inv_sqrt_hd), mx)));
+        const float inv_den = __fdiv_rn(1.0f, den);
         float acc = 0.f;
         for (int j = 0; j < kk; ++j) {
-            const float wj = __fdiv_rn(fast_exp(__fsub_rn(__fdiv_rn(ar[(int64_t)j * d], sqrt_hd), mx)), den);
+            const float wj = __fmul_rn(fast_exp(__fsub_rn(__fmul_rn(ar[(int64_t)j * d], inv_sqrt_hd), mx)), inv_den);
             const float vv = __fadd_rn(v[(patch_i * m + ir[j]) * ldv + c], pr[(int64_t)j * d]);
             acc = __fmaf_rn(wj, vv, acc);
         }

@@ -331,6 +331,22 @@ def test_gemm_modes_agree_and_stay_in_range(weights, monkeypatch):
     assert (d16 - d32).abs().max() <= TOL
 
 
+def test_fused_softmax_aggregate_is_bit_identical_to_the_two_kernel_form(weights, monkeypatch):
+    """fc_gamma2 + per-point softmax + aggregation in one kernel (EPI_SOFTMAX_AGG: the logits never leave LDS) against
+    the bias GEMM followed by fn_softmax_agg_kernel: same operations in the same order -> identical normals, for full
+    48-point patches (kk = 24/18/12: 5/7/10 points per row tile, ragged last tile) and for 5-point patches (kk = 5)."""
+    fn_b, _, _, _ = U.build_gpu_models(weights)          # default: two kernels
+    fn_b._engine()
+    monkeypatch.setenv("SAPCU_FUSED_SOFTMAX", "1")
+    fn_a, _, _, _ = U.build_gpu_models(weights)
+    fn_a._engine()
+    fn_a.knn_cache_mode = fn_b.knn_cache_mode = "fresh"
+    for nq, mpts in ((37, 48), (3, 5), (1, 48), (64, 20)):
+        patch = U.sphere_patches(nq, mpts, skip=300).to(U.dev())
+        assert torch.equal(fn_a(patch), fn_b(patch)), (nq, mpts)
+    assert fn_a.gemm_mode() == (True, 0)
+
+
 def test_chunking_and_tiny_shapes(weights, monkeypatch):
     """Results do not depend on the internal chunk size (workspace tiling), batch of 1, patches of 5 points."""
     fn_a, fd_a, sdn, sdd = U.build_gpu_models(weights)
