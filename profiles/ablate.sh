@@ -1,17 +1,27 @@
 #!/bin/bash
-# Profiling ablations of the ring GEMM epilogue: builds variants of the library with one piece of the epilogue
-# compiled out (-DSAPCU_ABL_*) into profiles/abl/ (git-ignored .so files) — run here, before gpurun.
+# Diagnostic builds of the ring GEMM (profiles/abl/*.so, git-ignored) — run here before gpurun, then point a
+# microbenchmark at one with SAPCU_LIB=profiles/abl/libsapcu_<NAME>.so.
+#   epilogue ablations   NO_GATHER  NO_C2  NO_LIF          one piece of the attention/LIF epilogue compiled out
+#   delivery / compute   NO_MFMA (DMAs, waits, barriers only)   NO_DMA (LDS reads + MFMAs, rings never refilled)
+#   latency              A_HOT (every tile reads the first row panel: all activation reads hit L2)
+#   tile order           CONTIG (-DSAPCU_RING_TILES_CONTIGUOUS: same speed, 3.8x the HBM fetches)
+#   stamps               STAMPS (s_memtime per producer k-step segment; read with profiles/ring_stamps.py)
+# Usage: bash profiles/ablate.sh [NAME ...]      (default: all)
 set -e
 cd "$(dirname "$0")/.."
 SRC=c-users-sayakdutta-self-supervised-arbitrary-scale-point-cloud-upsampling-via-snn_amd/csrc
 mkdir -p profiles/abl
-for v in ${ABL_VARIANTS:-NO_GATHER NO_C2 NO_LIF} ; do
-  name=$v
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -DSAPCU_ABL_$v -c $SRC/gemm_sf16_ring.hip -o profiles/abl/ring_$name.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o profiles/abl/libsapcu_$name.so profiles/abl/ring_$name.o \
+make -C $SRC > /dev/null
+build() {   # name, extra flags
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off $2 -c $SRC/gemm_sf16_ring.hip -o profiles/abl/ring_$1.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o profiles/abl/libsapcu_$1.so profiles/abl/ring_$1.o \
       $(ls $SRC/*.o | grep -v gemm_sf16_ring.o)
+}
+for v in ${@:-NO_GATHER NO_C2 NO_LIF NO_MFMA NO_DMA A_HOT CONTIG STAMPS}; do
+  case $v in
+    CONTIG) build $v -DSAPCU_RING_TILES_CONTIGUOUS ;;
+    STAMPS) build $v -DSAPCU_RING_STAMPS ;;
+    *)      build $v -DSAPCU_ABL_$v ;;
+  esac
 done
-# in-kernel stamps (s_memtime) of a producer wave's k-step segments: read with profiles/ring_stamps.py
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -DSAPCU_RING_STAMPS -c $SRC/gemm_sf16_ring.hip -o profiles/abl/ring_STAMPS.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o profiles/abl/libsapcu_STAMPS.so profiles/abl/ring_STAMPS.o $(ls $SRC/*.o | grep -v gemm_sf16_ring.o)
 ls -la profiles/abl/*.so
