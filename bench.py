@@ -133,6 +133,26 @@ def roofline_leg(dev, reps=3):
             "neuron_element_steps_per_s": round(steps / avg_s, 0)}
 
 
+def knn_leg(dev, cloud, seeds, reps=20):
+    """The outer kNN kernel alone on the bench workload, in the north-star's accounting: every query streams the whole
+    f64 cloud (B * N * 24 bytes) against the HBM peak.  (The kernel tiles the cloud through LDS, so its real HBM traffic
+    is far smaller; DESIGN.md section 4 discusses the model.)"""
+    from sapcu_amd import generation as gen
+    gen.knn_gather(cloud, seeds, M_PTS)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        gen.knn_gather(cloud, seeds, M_PTS)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / reps
+    streamed = float(seeds.shape[0]) * cloud.shape[0] * 24.0
+    return {"kernel": "knn_outer_kernel", "us": round(t * 1e6, 1), "model": "B*N*24 bytes streamed per launch",
+            "achieved": round(streamed / t / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(streamed / t / 1e9 / PEAK_HBM_GBS, 4)}
+
+
 def cpu_baseline(sdn, sdd, sample=64):
     """Oracle on `sample` of the same queries (kNN + fn + rotate + fd + displace), all host threads."""
     from sapcu_amd import testing as T
@@ -247,6 +267,7 @@ def main():
         if not args.no_roofline:
             line["roofline"] = roofline_leg(dev)
             log("roofline leg done: %s" % line["roofline"])
+            line["knn_kernel"] = knn_leg(dev, cloud, seeds)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sdn, sdd)
             log("cpu baseline done: %s" % line["cpu_baseline"])

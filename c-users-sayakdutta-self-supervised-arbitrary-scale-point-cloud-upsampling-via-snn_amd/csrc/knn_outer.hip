@@ -37,6 +37,9 @@ __device__ __forceinline__ double readlane_d(double v, int lane_uniform) {
                             __builtin_amdgcn_readlane(__double2loint(v), lane_uniform));
 }
 
+// TWO = the list needs the second slot per lane (k > 64); the model's k = 48 and the outlier filter's k = 30 run the
+// one-slot instance, whose insertion is a third shorter.
+template <bool TWO>
 __global__ __launch_bounds__(256) void knn_outer_kernel(const double* __restrict__ cloud, int64_t n,
                                                         const double* __restrict__ queries, int64_t b, int k,
                                                         int64_t* __restrict__ idx_out,
@@ -85,19 +88,18 @@ __global__ __launch_bounds__(256) void knn_outer_kernel(const double* __restrict
                 if (!(cd < tau)) continue;
                 const int ci = (int)(base + off + src);
                 // position = number of entries <= candidate (all have smaller point index)
-                const int pos = __popcll(__ballot(s0.d <= cd)) + __popcll(__ballot(s1.d <= cd));
+                int pos = __popcll(__ballot(s0.d <= cd));
+                if (TWO) pos += __popcll(__ballot(s1.d <= cd));
                 // shift entries at positions >= pos up by one, drop the last
                 const double u0d = shr1_d(s0.d);
                 const int u0i = shr1_i(s0.i);
-                double u1d = shr1_d(s1.d);
-                int u1i = shr1_i(s1.i);
-                const double l63d = readlane_d(s0.d, 63);
-                const int l63i = __builtin_amdgcn_readlane(s0.i, 63);
-                if (lane == 0) {
-                    u1d = l63d;
-                    u1i = l63i;
-                }
                 const int p0 = lane, p1 = lane + 64;
+                double l63d = 0.0;                                  // entry 63 moves into the second slot's lane 0
+                int l63i = 0;
+                if (TWO) {
+                    l63d = readlane_d(s0.d, 63);
+                    l63i = __builtin_amdgcn_readlane(s0.i, 63);
+                }
                 if (p0 == pos) {
                     s0.d = cd;
                     s0.i = ci;
@@ -105,16 +107,24 @@ __global__ __launch_bounds__(256) void knn_outer_kernel(const double* __restrict
                     s0.d = u0d;
                     s0.i = u0i;
                 }
-                if (p1 == pos) {
-                    s1.d = cd;
-                    s1.i = ci;
-                } else if (p1 > pos) {
-                    s1.d = u1d;
-                    s1.i = u1i;
+                if (TWO) {
+                    double u1d = shr1_d(s1.d);
+                    int u1i = shr1_i(s1.i);
+                    if (lane == 0) {
+                        u1d = l63d;
+                        u1i = l63i;
+                    }
+                    if (p1 == pos) {
+                        s1.d = cd;
+                        s1.i = ci;
+                    } else if (p1 > pos) {
+                        s1.d = u1d;
+                        s1.i = u1i;
+                    }
                 }
                 // new k-th distance
                 const int kl = (k - 1) & 63;
-                tau = (k - 1) < 64 ? readlane_d(s0.d, kl) : readlane_d(s1.d, kl);
+                tau = (!TWO || (k - 1) < 64) ? readlane_d(s0.d, kl) : readlane_d(s1.d, kl);
             }
         }
     }
@@ -140,8 +150,10 @@ int launch_knn_outer(const double* cloud, int64_t n, const double* q, int64_t b,
                      double* dist, float* patch, hipStream_t st) {
     if (b == 0) return SAPCU_OK;
     const int64_t grid = (b + KNN_WAVES - 1) / KNN_WAVES;
-    hipLaunchKernelGGL(knn_outer_kernel, dim3((unsigned)grid), dim3(256), 0, st, cloud, n, q, b, k, idx, dist,
-                       patch);
+    if (k > 64)
+        hipLaunchKernelGGL(knn_outer_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, cloud, n, q, b, k, idx, dist, patch);
+    else
+        hipLaunchKernelGGL(knn_outer_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, cloud, n, q, b, k, idx, dist, patch);
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
 }
