@@ -211,8 +211,10 @@ class ImprovedSNNNormalEstimation(_HipModel):
     def _knn_table_len(self, b, m):
         return sum(b * m * min(k, m) for k in self.k_values)
 
-    def forward(self, point_cloud, taps=None):
-        """[B,M,3] | [B,3,M] -> [B,3];  [B,N,M,3] -> [B,N,3]  (fn/snn_coder.py:670-699)."""
+    def forward(self, point_cloud, taps=None, knn_in=None):
+        """[B,M,3] | [B,3,M] -> [B,3];  [B,N,M,3] -> [B,N,3]  (fn/snn_coder.py:670-699).
+        knn_in (ours, optional): explicit in-patch neighbour tables (flat int32, three [B,M,k] blocks) — used by
+        Generator3D6 to run several reference batches in one device pass; bypasses the shape-keyed cache."""
         if point_cloud.ndim == 4:
             B, N, M, C = point_cloud.shape
             return self.forward(point_cloud.reshape(B * N, M, C), taps).view(B, N, 3)
@@ -224,8 +226,11 @@ class ImprovedSNNNormalEstimation(_HipModel):
         out = torch.empty((b, 3), dtype=torch.float32, device=dev)
         if b == 0:
             return out
-        knn_in = knn_out = None
-        if self.knn_cache_mode == "reference":
+        knn_out = None
+        if knn_in is not None:
+            if knn_in.numel() != self._knn_table_len(b, m) or knn_in.dtype != torch.int32 or knn_in.device != dev:
+                raise ValueError("knn_in: expected %d int32 entries on %s" % (self._knn_table_len(b, m), dev))
+        elif self.knn_cache_mode == "reference":
             key = (b, m)
             if key in self._knn_cache:
                 knn_in = self._knn_cache[key]
@@ -243,6 +248,18 @@ class ImprovedSNNNormalEstimation(_HipModel):
             if len(self._knn_cache) > 32:          # KNNCache.max_size eviction, fn/snn_coder.py:56-57
                 del self._knn_cache[next(iter(self._knn_cache))]
         return out
+
+    def tiled_knn_tables(self, b, m, times):
+        """The cached tables of batch shape (b, m) repeated `times` along the batch axis, in the flat layout forward()
+        takes as knn_in for a batch of times*b patches (every sub-batch replays the cached batch's neighbours, which is
+        what the reference's shape-keyed cache does to consecutive batches of one shape)."""
+        flat = self._knn_cache[(b, m)]
+        out, off = [], 0
+        for k in self.k_values:
+            cnt = b * m * min(k, m)
+            out.append(flat[off:off + cnt].repeat(times))
+            off += cnt
+        return torch.cat(out)
 
     def knn_tables(self, b, m):
         """The cached in-patch neighbour tables for batch shape (b, m): three int32 [b,m,k] tensors."""

@@ -580,3 +580,27 @@ def test_generator_edge_cases(weights):
     np.testing.assert_allclose(full1[0], full_big[0], rtol=0, atol=2e-4)
     with pytest.raises(ValueError):
         gen.upsample_seeds(cloud[:40], q)                                      # 40 points < 48 neighbours
+
+
+def test_fused_batches_equal_batch_by_batch(weights):
+    """Generator3D6.refine runs consecutive reference batches of one shape as one device pass (fuse_queries) — in
+    'reference' mode with the cached neighbour tables of the first batch of that shape, as fn's shape-keyed cache would.
+    The refined cloud must equal the batch-by-batch run bit for bit, in both cache modes."""
+    import sapcu_amd
+    from sapcu_amd import testing as T
+    cloud = _dev(T.sphere_cloud(800, 0))
+    seeds = _dev(T.grid_queries(100, 0))                        # batch_size 8 -> 4 batches of 9, then 8 of 8
+    for mode in ("reference", "fresh"):
+        outs = []
+        for fuse in (0, 4096, 20):
+            fn, fd, _, _ = U.build_gpu_models(weights)
+            fn.knn_cache_mode = mode
+            gen = sapcu_amd.Generator3D6(fn, fd, U.dev(), k_neighbors=48, batch_size=8)
+            gen.fuse_queries = fuse
+            with torch.no_grad():
+                outs.append(gen.refine(cloud, seeds))
+            if mode == "reference":
+                assert sorted(fn._knn_cache) == [(8, 48), (9, 48)]          # only the reference's own batch shapes
+        for other in outs[1:]:
+            for a, b in zip(outs[0], other):
+                assert torch.equal(a, b), mode
