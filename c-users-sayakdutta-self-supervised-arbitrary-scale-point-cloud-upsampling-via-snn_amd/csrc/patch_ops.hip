@@ -23,49 +23,60 @@ struct KnnOut {
     int n;
 };
 
-template <int MAXP>   // pairs per thread: ceil(m*m / 256) <= MAXP (16 for m <= 64, 64 for m <= 128)
+// Thread (bi, bj) of the 16 x 16 thread grid owns the BT x BT block of pairs (i, j), i in [bi*BT, bi*BT+BT), j likewise:
+// per channel it reads BT + BT values from LDS for BT*BT FMAs (one-pair-per-thread needed 2 reads per FMA and was bound
+// by LDS bandwidth in feature space, c = 64..256).  Every pair still sees ITS chain in ascending channel order, so the
+// scores are bit-identical.  BT = ceil(m / 16): 3 for the model's 48-point patches, up to 8 for m = 128.
+template <int BT>
 __global__ __launch_bounds__(256) void patch_knn_kernel(const float* __restrict__ feat, int64_t pstride, int m,
                                                         int c, int ld, const KnnOut out) {
     extern __shared__ float sm[];
     float* S = sm;                      // [m][m+1]
     float* xx = S + m * (m + 1);        // [m]
-    float* F = xx + m;                  // [m][PK_CH+1]
+    float* F = xx + m;                  // [16*BT][PK_CH+1]  (rows >= m zero)
     const int tid = threadIdx.x;
     const float* base = feat + (int64_t)blockIdx.x * pstride;
-    const int npairs = m * m;
-    float acc[MAXP];
+    const int bi = tid >> 4, bj = tid & 15;
+    const int mpad = 16 * BT;
+    float acc[BT][BT];
 #pragma unroll
-    for (int t = 0; t < MAXP; ++t) acc[t] = 0.f;
+    for (int u = 0; u < BT; ++u)
+#pragma unroll
+        for (int v = 0; v < BT; ++v) acc[u][v] = 0.f;
     float myxx = 0.f;
     for (int c0 = 0; c0 < c; c0 += PK_CH) {
         const int cw = min(PK_CH, c - c0);
         __syncthreads();
-        for (int e = tid; e < m * cw; e += 256) {
+        for (int e = tid; e < mpad * cw; e += 256) {
             const int i = e / cw, cc = e % cw;
-            F[i * (PK_CH + 1) + cc] = base[(int64_t)i * ld + c0 + cc];
+            F[i * (PK_CH + 1) + cc] = i < m ? base[(int64_t)i * ld + c0 + cc] : 0.f;
         }
         __syncthreads();
+        const float* fi = F + (bi * BT) * (PK_CH + 1);
+        const float* fj = F + (bj * BT) * (PK_CH + 1);
+        for (int cc = 0; cc < cw; ++cc) {
+            float a[BT], bb[BT];
 #pragma unroll
-        for (int t = 0; t < MAXP; ++t) {
-            const int p = tid + 256 * t;
-            if (p < npairs) {
-                const int i = p / m, j = p % m;
-                const float* fi = F + i * (PK_CH + 1);
-                const float* fj = F + j * (PK_CH + 1);
-                float a = acc[t];
-                if (c0 == 0) {
-                    a = __fmul_rn(fi[0], fj[0]);
-                    for (int cc = 1; cc < cw; ++cc) a = __fmaf_rn(fi[cc], fj[cc], a);
-                } else {
-                    for (int cc = 0; cc < cw; ++cc) a = __fmaf_rn(fi[cc], fj[cc], a);
-                }
-                acc[t] = a;
+            for (int u = 0; u < BT; ++u) {
+                a[u] = fi[u * (PK_CH + 1) + cc];
+                bb[u] = fj[u * (PK_CH + 1) + cc];
+            }
+            if (c0 == 0 && cc == 0) {
+#pragma unroll
+                for (int u = 0; u < BT; ++u)
+#pragma unroll
+                    for (int v = 0; v < BT; ++v) acc[u][v] = __fmul_rn(a[u], bb[v]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < BT; ++u)
+#pragma unroll
+                    for (int v = 0; v < BT; ++v) acc[u][v] = __fmaf_rn(a[u], bb[v], acc[u][v]);
             }
         }
         if (tid < m) {
-            const float* fi = F + tid * (PK_CH + 1);
+            const float* fr = F + tid * (PK_CH + 1);
             for (int cc = 0; cc < cw; ++cc) {
-                const float sq = __fmul_rn(fi[cc], fi[cc]);
+                const float sq = __fmul_rn(fr[cc], fr[cc]);
                 myxx = (c0 == 0 && cc == 0) ? sq : __fadd_rn(myxx, sq);
             }
         }
@@ -73,14 +84,15 @@ __global__ __launch_bounds__(256) void patch_knn_kernel(const float* __restrict_
     if (tid < m) xx[tid] = myxx;
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < MAXP; ++t) {
-        const int p = tid + 256 * t;
-        if (p < npairs) {
-            const int i = p / m, j = p % m;
-            const float inner = __fmul_rn(-2.0f, acc[t]);
-            S[i * (m + 1) + j] = __fsub_rn(__fsub_rn(-xx[j], inner), xx[i]);
+    for (int u = 0; u < BT; ++u)
+#pragma unroll
+        for (int v = 0; v < BT; ++v) {
+            const int i = bi * BT + u, j = bj * BT + v;
+            if (i < m && j < m) {
+                const float inner = __fmul_rn(-2.0f, acc[u][v]);
+                S[i * (m + 1) + j] = __fsub_rn(__fsub_rn(-xx[j], inner), xx[i]);
+            }
         }
-    }
     __syncthreads();
     // rank by counting: one wave per row, lane owns columns lane and lane+64
     const int lane = tid & 63, wave = tid >> 6;
@@ -115,11 +127,15 @@ int launch_patch_knn_multi(const float* feat, int64_t b, int64_t pstride, int m,
         out.k[t] = t < ntab ? ks[t] : 0;
         if (t < ntab) SAPCU_CHECK_ARG(ks[t] >= 1 && ks[t] <= m && idx[t], "patch_knn: need 1<=k<=m (k=%d m=%d)", ks[t], m);
     }
-    const size_t lds = (size_t)(m * (m + 1) + m + m * (PK_CH + 1)) * sizeof(float);
-    if (m <= 64)
-        hipLaunchKernelGGL(patch_knn_kernel<16>, dim3((unsigned)b), dim3(256), lds, st, feat, pstride, m, c, ld, out);
+    const int bt = (m + 15) / 16;                                   // 1..8
+    const int btk = bt <= 3 ? 3 : (bt <= 4 ? 4 : 8);
+    const size_t lds = (size_t)(m * (m + 1) + m + 16 * btk * (PK_CH + 1)) * sizeof(float);
+    if (btk == 3)
+        hipLaunchKernelGGL(patch_knn_kernel<3>, dim3((unsigned)b), dim3(256), lds, st, feat, pstride, m, c, ld, out);
+    else if (btk == 4)
+        hipLaunchKernelGGL(patch_knn_kernel<4>, dim3((unsigned)b), dim3(256), lds, st, feat, pstride, m, c, ld, out);
     else
-        hipLaunchKernelGGL(patch_knn_kernel<64>, dim3((unsigned)b), dim3(256), lds, st, feat, pstride, m, c, ld, out);
+        hipLaunchKernelGGL(patch_knn_kernel<8>, dim3((unsigned)b), dim3(256), lds, st, feat, pstride, m, c, ld, out);
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
 }
