@@ -631,9 +631,57 @@ __global__ __launch_bounds__(256) void fd_edge0_kernel(const float* __restrict__
     out[t] = lrelu02(__fadd_rn(mx, bias[col]));
 }
 
+// Same stage, one workgroup per patch: the patch's coordinates and neighbour lists are staged in LDS once (the
+// thread-per-output form re-loaded them from global memory for every channel), a thread keeps its column's six weights
+// in registers and walks the patch's points.  Same operations in the same order per output.
+constexpr int FDE0_MAXM = 64, FDE0_MAXK = 64;
+
+__global__ __launch_bounds__(256) void fd_edge0_patch_kernel(const float* __restrict__ patch, const int32_t* __restrict__ idx,
+                                                             int kmax, int m, int nscale,
+                                                             const int32_t* __restrict__ ks /*[S] device*/,
+                                                             const float* __restrict__ w /*[S][64][6]*/,
+                                                             const float* __restrict__ bias /*[S][64]*/,
+                                                             float* __restrict__ out) {
+    __shared__ float sp[FDE0_MAXM][3];
+    __shared__ int si[FDE0_MAXM][FDE0_MAXK];
+    const int64_t pt0 = (int64_t)blockIdx.x * m;
+    for (int e = threadIdx.x; e < m * 3; e += 256) sp[e / 3][e % 3] = patch[pt0 * 3 + e];
+    for (int e = threadIdx.x; e < m * kmax; e += 256) si[e / kmax][e % kmax] = idx[pt0 * kmax + e];
+    __syncthreads();
+    const int cs = 64 * nscale;
+    for (int col = threadIdx.x; col < cs; col += 256) {
+        const int s = col >> 6;
+        const float* ww = w + (int64_t)col * 6;
+        const float w0 = ww[0], w1 = ww[1], w2 = ww[2], w3 = ww[3], w4 = ww[4], w5 = ww[5], bb = bias[col];
+        const int kuse = min(ks[s], m);
+        for (int i = 0; i < m; ++i) {
+            const float xi = sp[i][0], yi = sp[i][1], zi = sp[i][2];
+            float mx = -__builtin_huge_valf();
+            for (int j = 0; j < kuse; ++j) {
+                const int nb = si[i][j];
+                const float xj = sp[nb][0], yj = sp[nb][1], zj = sp[nb][2];
+                float a = __fmul_rn(w0, __fsub_rn(xj, xi));
+                a = __fmaf_rn(w1, __fsub_rn(yj, yi), a);
+                a = __fmaf_rn(w2, __fsub_rn(zj, zi), a);
+                a = __fmaf_rn(w3, xj, a);
+                a = __fmaf_rn(w4, yj, a);
+                a = __fmaf_rn(w5, zj, a);
+                mx = fmaxf(mx, a);
+            }
+            out[(pt0 + i) * cs + col] = lrelu02(__fadd_rn(mx, bb));
+        }
+    }
+}
+
 int launch_fd_edge0(const float* patch, const int32_t* idx, int kmax, int64_t pts, int m, int nscale,
                     const int32_t* ks_dev, const float* w, const float* bias, float* out, hipStream_t st) {
     if (pts == 0) return SAPCU_OK;
+    if (m <= FDE0_MAXM && kmax <= FDE0_MAXK && pts % m == 0) {
+        hipLaunchKernelGGL(fd_edge0_patch_kernel, dim3((unsigned)(pts / m)), dim3(256), 0, st, patch, idx, kmax, m, nscale,
+                           ks_dev, w, bias, out);
+        SAPCU_CHECK_LAUNCH();
+        return SAPCU_OK;
+    }
     const int64_t total = pts * 64 * nscale;
     hipLaunchKernelGGL(fd_edge0_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, patch, idx, kmax, pts,
                        m, nscale, ks_dev, w, bias, out);
