@@ -114,13 +114,14 @@ def roofline_leg(dev, reps=3):
     gbs = byts / avg_s / 1e9
     # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
     # command, corrected as MI355X_MICROARCH.md prescribes) — condensed by profiles/pmc_to_json.py
-    traffic, src = None, None
+    traffic, src, busy = None, None, None
     for cand in sorted([f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json")], reverse=True):
         try:
             recs = json.load(open(os.path.join(ROOT, "profiles", cand)))
             rec = recs.get("gemm_ring_kernel<6, true>") or recs.get("gemm_ring_kernel<6>")
             if rec:
                 traffic, src = float(rec["hbm_bytes_per_launch"]), "profiles/" + cand
+                busy = rec.get("mfma_busy_frac")      # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs), third PMC pass
                 break
         except (OSError, ValueError, KeyError):
             pass
@@ -129,7 +130,8 @@ def roofline_leg(dev, reps=3):
             "kernel": "gemm_ring_kernel<EPI_LIF_ATTN>", "avg_launch_ms": round(avg_s * 1e3, 4),
             "bytes_per_launch": byts, "launches_timed": n_launch, "chunk_patches": chunk,
             "mfma": {"algorithmic_tflops": round(flop / avg_s / 1e12, 2), "issued_f16_tflops": round(3 * flop / avg_s / 1e12, 2),
-                     "peak_f16_dense_tflops": PEAK_F16_MFMA_TFLOPS, "issued_frac": round(3 * flop / avg_s / 1e12 / PEAK_F16_MFMA_TFLOPS, 4)},
+                     "peak_f16_dense_tflops": PEAK_F16_MFMA_TFLOPS, "issued_frac": round(3 * flop / avg_s / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+                     "busy_frac_pmc": busy},
             "neuron_element_steps_per_s": round(steps / avg_s, 0)}
 
 

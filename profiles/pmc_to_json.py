@@ -22,8 +22,26 @@ def per_kernel(d, counter):
     return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
 
 
-def main(fetch_dir, write_dir, out):
+def per_kernel_raw(d, counter):
+    """like per_kernel, but the counter's own unit (cycles), averaged per launch"""
+    fs = glob.glob(d + "/*/*_counter_collection.csv")
+    if not fs:
+        return {}
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].split("(")[0].replace("void sapcu::", "").replace("sapcu::", "")
+        agg[name].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def main(fetch_dir, write_dir, out, mfma_dir=None):
     fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    # third pass (optional): matrix-pipe busy cycles (= 32 per v_mfma_f32_32x32x16, summed over the chip's SIMDs) and
+    # GRBM_GUI_ACTIVE (summed over the 8 XCDs) -> busy fraction = busy / (gui_active / 8 * 1024 SIMDs)
+    mb = per_kernel_raw(mfma_dir, "SQ_VALU_MFMA_BUSY_CYCLES") if mfma_dir else {}
+    ga = per_kernel_raw(mfma_dir, "GRBM_GUI_ACTIVE") if mfma_dir else {}
     res = {}
     for k in sorted(set(fe) | set(wr)):
         if not k.startswith(("gemm", "fn_", "fd_", "patch_", "knn_", "rowgroup", "edge_", "gather", "displace")):
@@ -32,9 +50,13 @@ def main(fetch_dir, write_dir, out):
         w, nw = wr.get(k, (0.0, 0))
         res[k] = {"launches": max(nf, nw), "fetch_bytes_raw": round(f), "fetch_bytes_corrected": round(2 * f),
                   "write_bytes": round(w), "hbm_bytes_per_launch": round(2 * f + w)}
+        if k in mb and ga.get(k):
+            res[k]["mfma_busy_cycles"] = round(mb[k])
+            res[k]["gui_active_sum_xcd"] = round(ga[k])
+            res[k]["mfma_busy_frac"] = round(mb[k] / (ga[k] / 8.0 * 1024.0), 4)
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
-    print(json.dumps(res.get("gemm_sf16_kernel<6>"), indent=1))
+    print(json.dumps(res.get("gemm_ring_kernel<6, true>"), indent=1))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
