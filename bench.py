@@ -197,12 +197,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
-    dev = torch.device("cuda", local)
+    # SAPCU_BENCH_REHEARSE=1: every rank on cuda:0 with the gloo backend — exercises the N > 1 code path (sharding, barriers,
+    # all-gather, max-over-ranks timing) on a one-GPU box; the numbers of such a run mean nothing.
+    rehearse = os.environ.get("SAPCU_BENCH_REHEARSE") == "1"
+    dev = torch.device("cuda", 0 if rehearse else local)
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import sapcu_amd
     from sapcu_amd import testing as T
