@@ -185,6 +185,40 @@ def test_gemm_against_float64(r, k, n, split):
     assert ovf == 0 and err <= 2e-6 * np.sqrt(k) * 4, err
 
 
+@pytest.mark.parametrize("r,k,n,csplit", [(1, 32, 4, 0), (300, 96, 132, 1), (257, 128, 128, 1), (5000, 256, 260, 0), (4099, 512, 512, 1)])
+def test_ring_gemm_neuron_epilogue_and_split_row_output(r, k, n, csplit):
+    """The ring kernel's row-layout consumer end to end through the C ABI: A in split rows, T = 4 neuron self-loop on
+    every output (per-column parameters), output as f32 or as split rows; ragged row/column tiles (r, n not multiples
+    of 128).  Oracle: float64 GEMM + the oracle's neuron step (the reference's arithmetic)."""
+    from sapcu_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(r * 7 + n)
+    a = rng.normal(size=(r, k)).astype(np.float32)
+    w = (rng.normal(size=(n, k)) / np.sqrt(k)).astype(np.float32)
+    bias = rng.normal(size=n).astype(np.float32)
+    raw = np.stack([rng.uniform(0.05, 1.1, n), rng.uniform(0.0, 0.2, n), rng.uniform(0.05, 1.0, n), rng.normal(0.5, 0.3, n)]).astype(np.float32)
+    A, W, Bv, L = _dev(a), _dev(w), _dev(bias), _dev(raw)
+    As = torch.empty_like(A)
+    _lib.check(lib.sapcu_to_split_rows(_lib.ptr(A), r, k, k, _lib.ptr(As), k, _lib.current_stream()))
+    C = torch.full((r, n), float("nan"), device=U.dev())
+    ws = torch.zeros(4 * n * k + 16, dtype=torch.uint8, device=U.dev())
+    _lib.check(lib.sapcu_gemm_f32(_lib.ptr(As), r, k, k, _lib.ptr(W), n, _lib.ptr(Bv), _lib.ptr(L), 4, _lib.ptr(C), n,
+                                  _lib.ptr(ws), 1, csplit, _lib.current_stream()))
+    torch.cuda.synchronize()
+    got = C.cpu()
+    if csplit:                                   # decode split rows: hi halves at [0, n), lo halves at [n, 2n) of each row
+        halves = got.view(torch.float16).view(r, 2 * n).float()
+        got = halves[:, :n] + halves[:, n:]
+    pre = torch.from_numpy((a.astype(np.float64) @ w.astype(np.float64).T + bias).astype(np.float32))
+    names = ["membrane_decay", "threshold_adapt", "refractory_decay", "threshold_base"]
+    prm = O.neuron_params({"n." + names[i]: torch.from_numpy(raw[i]) for i in range(4)}, "n")
+    v, st = pre, None
+    for _ in range(4):
+        v, st = O.neuron_step(v, st, prm)
+    err = (got - v).abs().max().item()
+    assert err <= 2e-5, err                      # pre-activation error 1e-6*sqrt(k) through a slope <= 2.6 per step
+
+
 def test_split_f16_gemm_error_bound_on_mixed_magnitudes():
     """Spikes down to 1e-6, weights spanning 1e-4..10, activations up to 2e4.  Bound: f32-level relative error
     on sum|a||w| plus the f16 subnormal quantum (2^-25 per activation below 0.25, 2^-29 per weight below
