@@ -219,6 +219,53 @@ def test_ring_gemm_neuron_epilogue_and_split_row_output(r, k, n, csplit):
     assert err <= 2e-5, err                      # pre-activation error 1e-6*sqrt(k) through a slope <= 2.6 per step
 
 
+@pytest.mark.parametrize("mode", ["f32", "sf16", "ring"])
+@pytest.mark.parametrize("b,m,kk,d", [(3, 5, 4, 64), (7, 48, 12, 128), (2, 48, 24, 256)])
+def test_posenc_gemm_attention_epilogue(mode, b, m, kk, d):
+    """sapcu_posenc_gemm_f32 (fn/snn_coder.py:360-368) through the C ABI in its three forms: exact-f32 MFMA, split-f16
+    with f32 operands, and the production ring form (pe1 and attn_in as split rows): pe = LIF x4 (W pe1 + b),
+    attn_in = q[point] - k[neighbour] + pe, against float64 GEMM + the oracle's neuron step."""
+    from sapcu_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(b * 1000 + d)
+    r = b * m * kk
+    pe1 = rng.random((r, d)).astype(np.float32)
+    w = (rng.normal(size=(d, d)) / np.sqrt(d)).astype(np.float32)
+    bias = rng.normal(size=d).astype(np.float32)
+    raw = np.stack([rng.uniform(0.05, 1.1, d), rng.uniform(0.0, 0.2, d), rng.uniform(0.05, 1.0, d), rng.normal(0.5, 0.3, d)]).astype(np.float32)
+    qkv = rng.random((b * m, 3 * d)).astype(np.float32)
+    idx = rng.integers(0, m, size=(b, m, kk)).astype(np.int32)
+    P1, W, Bv, L, Q, I = _dev(pe1), _dev(w), _dev(bias), _dev(raw), _dev(qkv), _dev(idx)
+    split = 1 if mode == "ring" else 0
+    if split:
+        tmp = torch.empty_like(P1)
+        _lib.check(lib.sapcu_to_split_rows(_lib.ptr(P1), r, d, d, _lib.ptr(tmp), d, _lib.current_stream()))
+        P1 = tmp
+    pe = torch.full((r, d), float("nan"), device=U.dev())
+    att = torch.full((r, d), float("nan"), device=U.dev())
+    tab = torch.empty((r, 2), dtype=torch.int32, device=U.dev())
+    ws = None if mode == "f32" else torch.zeros(4 * d * d + 16, dtype=torch.uint8, device=U.dev())
+    _lib.check(lib.sapcu_posenc_gemm_f32(_lib.ptr(P1), r, d, _lib.ptr(W), _lib.ptr(Bv), _lib.ptr(L), 4, _lib.ptr(Q), _lib.ptr(I), kk, m,
+                                         _lib.ptr(pe), _lib.ptr(att), _lib.ptr(tab), _lib.ptr(ws), split, _lib.current_stream()))
+    torch.cuda.synchronize()
+    pe, att = pe.cpu(), att.cpu()
+    if split:                                    # attn_in leaves as split rows (pe stays f32)
+        halves = att.view(torch.float16).view(r, 2 * d).float()
+        att = halves[:, :d] + halves[:, d:]
+    pre = torch.from_numpy((pe1.astype(np.float64) @ w.astype(np.float64).T + bias).astype(np.float32))
+    names = ["membrane_decay", "threshold_adapt", "refractory_decay", "threshold_base"]
+    prm = O.neuron_params({"n." + names[i]: torch.from_numpy(raw[i]) for i in range(4)}, "n")
+    v, st = pre, None
+    for _ in range(4):
+        v, st = O.neuron_step(v, st, prm)
+    rows = np.arange(r)
+    pt = rows // kk
+    nbr = (pt // m) * m + idx.reshape(-1)
+    want_att = torch.from_numpy(qkv[pt, :d] - qkv[nbr, d:2 * d]) + v
+    assert (pe - v).abs().max().item() <= 2e-5
+    assert (att - want_att).abs().max().item() <= 2e-5 + (2e-7 if split else 0.0)
+
+
 def test_split_f16_gemm_error_bound_on_mixed_magnitudes():
     """Spikes down to 1e-6, weights spanning 1e-4..10, activations up to 2e4.  Bound: f32-level relative error
     on sum|a||w| plus the f16 subnormal quantum (2^-25 per activation below 0.25, 2^-29 per weight below
