@@ -291,28 +291,12 @@ __global__ __launch_bounds__(256) void fn_pe1_vec4_kernel(const float* __restric
                                                           const float* __restrict__ bias, const float* __restrict__ lif,
                                                           int T, float* __restrict__ out, int split) {
     __shared__ float pd[PE_ROWS][3];
-    const int64_t row0 = (int64_t)blockIdx.x * PE_ROWS;
-    if (threadIdx.x < PE_ROWS) {
-        const int64_t r = row0 + threadIdx.x;
-        float dx = 0.f, dy = 0.f, dz = 0.f;
-        if (r < rows) {
-            const int64_t pt = r / kk;
-            const int64_t patch_i = pt / m;
-            const float* pi = patch + pt * 3;
-            const float* pj = patch + (patch_i * m + idx[r]) * 3;
-            dx = __fsub_rn(pi[0], pj[0]);
-            dy = __fsub_rn(pi[1], pj[1]);
-            dz = __fsub_rn(pi[2], pj[2]);
-        }
-        pd[threadIdx.x][0] = dx;
-        pd[threadIdx.x][1] = dy;
-        pd[threadIdx.x][2] = dz;
-    }
-    __syncthreads();
     const int tpr = d >> 2;                               // threads per row
     const int rpp = 256 / tpr;                            // rows per pass
     const int rsub = threadIdx.x / tpr;
     const int c = (threadIdx.x - rsub * tpr) * 4;
+    // this thread's 4 channels: weights, bias and neuron parameters stay in registers for ALL strips of the workgroup
+    // (a strip of 32 rows is only 4-16 elements per thread: reloading ~40 parameters per strip cost as much as the work)
     float wx[4], wy[4], wz[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -333,29 +317,51 @@ __global__ __launch_bounds__(256) void fn_pe1_vec4_kernel(const float* __restric
     np[1].theta0 = f32x2{pth.z, pth.w};
     const NeuronP2 np4[4] = {np[0], np[1], np[0], np[1]};
     const float bs[4] = {bb.x, bb.y, bb.z, bb.w};
-    const int nrow = (int)((rows - row0) < PE_ROWS ? (rows - row0) : PE_ROWS);
-    for (int r = rsub; r < nrow; r += 2 * rpp) {
-        const int rb = r + rpp < PE_ROWS ? r + rpp : r;    // second row of the pair (may be past nrow: computed, not stored)
-        float va[4], vb[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float a = __fmul_rn(wx[u], pd[r][0]);
-            a = __fmaf_rn(wy[u], pd[r][1], a);
-            a = __fmaf_rn(wz[u], pd[r][2], a);
-            va[u] = __fadd_rn(a, bs[u]);
-            float b2 = __fmul_rn(wx[u], pd[rb][0]);
-            b2 = __fmaf_rn(wy[u], pd[rb][1], b2);
-            b2 = __fmaf_rn(wz[u], pd[rb][2], b2);
-            vb[u] = __fadd_rn(b2, bs[u]);
+    const int64_t nstrips = (rows + PE_ROWS - 1) / PE_ROWS;
+    for (int64_t strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+        const int64_t row0 = strip * PE_ROWS;
+        __syncthreads();                                  // the previous strip's differences are no longer read
+        if (threadIdx.x < PE_ROWS) {
+            const int64_t r = row0 + threadIdx.x;
+            float dx = 0.f, dy = 0.f, dz = 0.f;
+            if (r < rows) {
+                const int64_t pt = r / kk;
+                const int64_t patch_i = pt / m;
+                const float* pi = patch + pt * 3;
+                const float* pj = patch + (patch_i * m + idx[r]) * 3;
+                dx = __fsub_rn(pi[0], pj[0]);
+                dy = __fsub_rn(pi[1], pj[1]);
+                dz = __fsub_rn(pi[2], pj[2]);
+            }
+            pd[threadIdx.x][0] = dx;
+            pd[threadIdx.x][1] = dy;
+            pd[threadIdx.x][2] = dz;
         }
-        f32x2 pv[4] = {f32x2{va[0], va[1]}, f32x2{va[2], va[3]}, f32x2{vb[0], vb[1]}, f32x2{vb[2], vb[3]}};
-        lif_selfloop_pairs<4>(pv, np4, T);
-        const float oa[4] = {pv[0].x, pv[0].y, pv[1].x, pv[1].y}, ob[4] = {pv[2].x, pv[2].y, pv[3].x, pv[3].y};
-        if (split) store_split4<true>(out, row0 + r, d, c, d, oa);     // operand of the pos-enc ring GEMM
-        else store_f32x4<true>(out, row0 + r, d, c, d, oa);
-        if (rb != r && rb < nrow) {
-            if (split) store_split4<true>(out, row0 + rb, d, c, d, ob);
-            else store_f32x4<true>(out, row0 + rb, d, c, d, ob);
+        __syncthreads();
+        const int nrow = (int)((rows - row0) < PE_ROWS ? (rows - row0) : PE_ROWS);
+        for (int r = rsub; r < nrow; r += 2 * rpp) {
+            const int rb = r + rpp < PE_ROWS ? r + rpp : r;    // second row of the pair (may be past nrow: computed, not stored)
+            float va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float a = __fmul_rn(wx[u], pd[r][0]);
+                a = __fmaf_rn(wy[u], pd[r][1], a);
+                a = __fmaf_rn(wz[u], pd[r][2], a);
+                va[u] = __fadd_rn(a, bs[u]);
+                float b2 = __fmul_rn(wx[u], pd[rb][0]);
+                b2 = __fmaf_rn(wy[u], pd[rb][1], b2);
+                b2 = __fmaf_rn(wz[u], pd[rb][2], b2);
+                vb[u] = __fadd_rn(b2, bs[u]);
+            }
+            f32x2 pv[4] = {f32x2{va[0], va[1]}, f32x2{va[2], va[3]}, f32x2{vb[0], vb[1]}, f32x2{vb[2], vb[3]}};
+            lif_selfloop_pairs<4>(pv, np4, T);
+            const float oa[4] = {pv[0].x, pv[0].y, pv[1].x, pv[1].y}, ob[4] = {pv[2].x, pv[2].y, pv[3].x, pv[3].y};
+            if (split) store_split4<true>(out, row0 + r, d, c, d, oa);     // operand of the pos-enc ring GEMM
+            else store_f32x4<true>(out, row0 + r, d, c, d, oa);
+            if (rb != r && rb < nrow) {
+                if (split) store_split4<true>(out, row0 + rb, d, c, d, ob);
+                else store_f32x4<true>(out, row0 + rb, d, c, d, ob);
+            }
         }
     }
 }
@@ -368,7 +374,8 @@ int launch_fn_pe1(const float* patch, const int32_t* idx, int64_t rows, int m, i
     const int tpr = d / 4;
     const bool al16 = (((uintptr_t)bias | (uintptr_t)lif | (uintptr_t)out) & 15) == 0;
     if (d % 4 == 0 && tpr >= 1 && tpr <= 256 && (tpr & (tpr - 1)) == 0 && al16) {
-        hipLaunchKernelGGL(fn_pe1_vec4_kernel, dim3((unsigned)strips), dim3(256), 0, st, patch, idx, rows, m, kk, d, w, bias, lif,
+        const int64_t grid = strips < 256 * 40 ? strips : 256 * 40;     // ~40 resident-or-queued workgroups per CU, each walking strips
+        hipLaunchKernelGGL(fn_pe1_vec4_kernel, dim3((unsigned)grid), dim3(256), 0, st, patch, idx, rows, m, kk, d, w, bias, lif,
                            T, out, split);
         SAPCU_CHECK_LAUNCH();
         return SAPCU_OK;
