@@ -150,9 +150,11 @@ def knn_leg(dev, cloud, seeds, reps=20):
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) * 1e-3 / reps
     streamed = float(seeds.shape[0]) * cloud.shape[0] * 24.0
-    return {"kernel": "knn_outer_kernel", "us": round(t * 1e6, 1), "model": "B*N*24 bytes streamed per launch",
+    return {"kernel": "knn_outer_kernel", "us": round(t * 1e6, 1),
+            "model": "B*N*24 bytes streamed per launch (the f64 coordinates the kernel reads; SURVEY.md 8d also names an "
+                     "fp32-equivalent B*N*12 model: frac_12B)",
             "achieved": round(streamed / t / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(streamed / t / 1e9 / PEAK_HBM_GBS, 4)}
+            "frac": round(streamed / t / 1e9 / PEAK_HBM_GBS, 4), "frac_12B": round(streamed / 2 / t / 1e9 / PEAK_HBM_GBS, 4)}
 
 
 def cpu_baseline(sdn, sdd, sample=64):
