@@ -33,6 +33,10 @@ _SIGNATURES = {
     "sapcu_fps_workspace_bytes": (c_int64, [c_int64]),
     "sapcu_fps_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     "sapcu_dense_seeds_host": (c_int, [c_void_p, c_int64, c_double, c_void_p, c_int64, POINTER(c_int64)]),
+    "sapcu_lif_train_forward": (c_int, [c_void_p, c_int64, c_int, c_int] + [c_void_p] * 4 + [c_void_p, c_void_p]),
+    "sapcu_lif_train_workspace_bytes": (c_int64, [c_int64, c_int]),
+    "sapcu_lif_train_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int] + [c_void_p] * 4 + [c_void_p] * 5 +
+                                 [c_void_p, c_int64, c_void_p]),
     "sapcu_neuron_selfloop": (c_int, [c_void_p, c_int64, c_int, c_int] + [c_void_p] * 6 + [c_void_p] * 4 + [c_void_p]),
     "sapcu_patch_knn": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sapcu_model_create": (c_int, [c_int, POINTER(c_int32), c_int, c_void_p, c_int64, POINTER(c_int64), c_int,

@@ -1,0 +1,210 @@
+// Training-mode neuron loop, forward and backward: the first piece of SURVEY.md §8 row f-4 (training backward).
+//
+// /root/reference/fn/snn_coder.py:87-151 in `self.training` mode, driven as fn drives it (`for t: x, *st = snn(x, *st)`,
+// :318-320): the forward value of a spike is the HARD threshold (m - theta > 0), its derivative the soft surrogate
+// 0.5*N'(u) + 0.5*10*sigma'(10u) on clamp(u, +-10) (straight-through estimator, :148-151); the refractory gate
+// `x * (r <= 0)` is a constant mask for the gradient.  Unlike the eval path nothing here is peeled: in training the spikes
+// are 0/1 and the gate re-opens, so every step is evaluated as written.
+//
+// One thread = one (row, channel) element: the T-step forward keeps the per-step quantities the reverse sweep needs in
+// registers (T <= 8), the reverse sweep runs in the same thread — no activations are saved between forward and backward,
+// the backward kernel recomputes the T steps from x.  Parameter gradients are summed over rows deterministically:
+// per-workgroup partial sums (fixed order inside a thread column, then across the workgroup's row slabs in LDS) go to a
+// workspace, a second kernel adds the partials in ascending workgroup order.
+#include "common.h"
+#include "../../include/sapcu.h"
+
+namespace sapcu {
+
+constexpr int LT_MAX_T = 8;
+constexpr int LT_ROWS_PER_WG = 64;    // 4 row slabs of 16 rows x 64 channels per 256-thread workgroup
+
+struct TrainP {
+    float decay, adapt, rdecay, theta0;
+};
+
+__device__ __forceinline__ TrainP load_train_params(const float* md, const float* ta, const float* rd, const float* tb, int c) {
+    return TrainP{fminf(fmaxf(md[c], 0.1f), 0.99f), fminf(fmaxf(ta[c], 0.001f), 0.1f), fminf(fmaxf(rd[c], 0.1f), 0.95f), tb[c]};
+}
+
+// soft surrogate value is not needed in training (the forward value is the hard spike); its derivative is
+__device__ __forceinline__ float surrogate_grad(float u) {
+    if (!(u >= -10.0f && u <= 10.0f)) return 0.f;              // torch.clamp passes the gradient on [min, max] only
+    const float gauss = expf(-0.5f * u * u) * 0.3989422804014327f;
+    const float sg = 1.0f / (1.0f + expf(-10.0f * u));
+    return 0.5f * (-u * gauss) + 0.5f * (10.0f * sg * (1.0f - sg));
+}
+
+struct StepRec {      // what the reverse sweep needs from one forward step
+    float m, r, th;   // state BEFORE the step
+    float mm, u, sp;  // membrane after integration, threshold distance, (hard) spike
+    float gate;       // (r <= 0)
+};
+
+__device__ __forceinline__ float train_forward(float x, const TrainP& p, int T, StepRec (&rec)[LT_MAX_T]) {
+    float m = 0.f, r = 0.f, th = p.theta0, in = x, sp = 0.f;
+    for (int t = 0; t < T; ++t) {
+        StepRec& q = rec[t];
+        q.m = m; q.r = r; q.th = th;
+        q.gate = r <= 0.f ? 1.f : 0.f;
+        const float xin = in * q.gate;
+        q.mm = m * p.decay * (1.0f - r) + xin;
+        q.u = q.mm - th;
+        sp = q.u > 0.f ? 1.f : 0.f;
+        q.sp = sp;
+        m = q.mm * (1.0f - sp);
+        r = r * p.rdecay + sp;
+        th = p.theta0 + ((th + p.adapt * sp) - p.theta0) * 0.95f;
+        in = sp;
+    }
+    return sp;
+}
+
+__global__ __launch_bounds__(256) void lif_train_fwd_kernel(const float* __restrict__ x, int64_t rows, int ch, int T,
+                                                            const float* md, const float* ta, const float* rd, const float* tb,
+                                                            float* __restrict__ spikes) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * ch) return;
+    const TrainP p = load_train_params(md, ta, rd, tb, (int)(t % ch));
+    StepRec rec[LT_MAX_T];
+    spikes[t] = train_forward(x[t], p, T, rec);
+}
+
+// grid: (ceil(rows / 64), ceil(ch / 64)); thread (slab = tid >> 6, lane = tid & 63) walks rows slab*16 .. +16 of its column
+__global__ __launch_bounds__(256) void lif_train_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gout,
+                                                            int64_t rows, int ch, int T, const float* md, const float* ta,
+                                                            const float* rd, const float* tb, float* __restrict__ gx,
+                                                            float* __restrict__ partial /*[gridDim.x][4][ch]*/) {
+    __shared__ float red[4][4][64];
+    const int lane = threadIdx.x & 63, slab = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    const bool live = c < ch;
+    float g_decay = 0.f, g_adapt = 0.f, g_rdecay = 0.f, g_theta = 0.f;
+    if (live) {
+        const TrainP p = load_train_params(md, ta, rd, tb, c);
+        const int64_t row0 = (int64_t)blockIdx.x * LT_ROWS_PER_WG + slab * 16;
+        for (int i = 0; i < 16; ++i) {
+            const int64_t row = row0 + i;
+            if (row >= rows) break;
+            StepRec rec[LT_MAX_T];
+            train_forward(x[row * ch + c], p, T, rec);
+            // reverse sweep; adjoints of the state AFTER step t
+            float a_sp = gout[row * ch + c], a_m = 0.f, a_r = 0.f, a_th = 0.f;
+            for (int t = T - 1; t >= 0; --t) {
+                const StepRec& q = rec[t];
+                // th' = theta0 + ((th + adapt*sp) - theta0) * 0.95
+                const float a_tht = 0.95f * a_th;
+                g_theta += a_th * 0.05f;
+                float b_th = a_tht;                       // adjoint of th (before the step)
+                g_adapt += a_tht * q.sp;
+                a_sp += a_tht * p.adapt;
+                // r' = r*rdecay + sp
+                float b_r = a_r * p.rdecay;
+                g_rdecay += a_r * q.r;
+                a_sp += a_r;
+                // m' = mm * (1 - sp)
+                float a_mm = a_m * (1.0f - q.sp);
+                a_sp += -a_m * q.mm;
+                // sp = H(u) with the surrogate derivative; u = mm - th
+                const float a_u = a_sp * surrogate_grad(q.u);
+                a_mm += a_u;
+                b_th += -a_u;
+                // mm = m*decay*(1-r) + x*gate
+                const float b_m = a_mm * p.decay * (1.0f - q.r);
+                g_decay += a_mm * q.m * (1.0f - q.r);
+                b_r += -a_mm * q.m * p.decay;
+                const float a_x = a_mm * q.gate;
+                a_m = b_m; a_r = b_r; a_th = b_th;
+                a_sp = a_x;                               // x_t = sp_{t-1}  (t >= 1);  for t = 0 it is dL/dx
+            }
+            g_theta += a_th;                              // the initial threshold IS theta0
+            gx[row * ch + c] = a_sp;
+        }
+    }
+    red[slab][0][lane] = g_decay;
+    red[slab][1][lane] = g_adapt;
+    red[slab][2][lane] = g_rdecay;
+    red[slab][3][lane] = g_theta;
+    __syncthreads();
+    if (slab == 0 && live) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float s = ((red[0][q][lane] + red[1][q][lane]) + red[2][q][lane]) + red[3][q][lane];
+            partial[((int64_t)blockIdx.x * 4 + q) * ch + c] = s;
+        }
+    }
+}
+
+// sums the per-workgroup partials in ascending order and applies the clamp masks of the raw parameters
+__global__ __launch_bounds__(256) void lif_train_param_reduce_kernel(const float* __restrict__ partial, int64_t nblocks, int ch,
+                                                                     const float* md, const float* ta, const float* rd,
+                                                                     float* __restrict__ g_md, float* __restrict__ g_ta,
+                                                                     float* __restrict__ g_rd, float* __restrict__ g_tb) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ch) return;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t b = 0; b < nblocks; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] += partial[(b * 4 + q) * ch + c];
+    g_md[c] = (md[c] >= 0.1f && md[c] <= 0.99f) ? s[0] : 0.f;
+    g_ta[c] = (ta[c] >= 0.001f && ta[c] <= 0.1f) ? s[1] : 0.f;
+    g_rd[c] = (rd[c] >= 0.1f && rd[c] <= 0.95f) ? s[2] : 0.f;
+    g_tb[c] = s[3];
+}
+
+}  // namespace sapcu
+
+using namespace sapcu;
+
+extern "C" {
+
+int sapcu_lif_train_forward(const float* x, int64_t rows, int channels, int steps, const float* membrane_decay,
+                            const float* threshold_adapt, const float* refractory_decay, const float* threshold_base,
+                            float* spikes_out, void* stream) {
+    SAPCU_CHECK_ARG(x && membrane_decay && threshold_adapt && refractory_decay && threshold_base && spikes_out,
+                    "lif_train_forward: null pointer");
+    SAPCU_CHECK_ARG(rows >= 0 && channels >= 1 && steps >= 1 && steps <= LT_MAX_T, "lif_train_forward: need 1 <= steps <= %d", LT_MAX_T);
+    const int64_t total = rows * channels;
+    if (total == 0) return SAPCU_OK;
+    hipLaunchKernelGGL(lif_train_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, rows,
+                       channels, steps, membrane_decay, threshold_adapt, refractory_decay, threshold_base, spikes_out);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+int64_t sapcu_lif_train_workspace_bytes(int64_t rows, int channels) {
+    if (rows < 0 || channels < 1) return -1;
+    const int64_t nb = (rows + LT_ROWS_PER_WG - 1) / LT_ROWS_PER_WG;
+    return (nb > 0 ? nb : 1) * 4 * (int64_t)channels * (int64_t)sizeof(float);
+}
+
+int sapcu_lif_train_backward(const float* x, const float* grad_spikes, int64_t rows, int channels, int steps,
+                             const float* membrane_decay, const float* threshold_adapt, const float* refractory_decay,
+                             const float* threshold_base, float* grad_x, float* grad_membrane_decay,
+                             float* grad_threshold_adapt, float* grad_refractory_decay, float* grad_threshold_base,
+                             void* workspace, int64_t workspace_bytes, void* stream) {
+    SAPCU_CHECK_ARG(x && grad_spikes && membrane_decay && threshold_adapt && refractory_decay && threshold_base && grad_x &&
+                        grad_membrane_decay && grad_threshold_adapt && grad_refractory_decay && grad_threshold_base && workspace,
+                    "lif_train_backward: null pointer");
+    SAPCU_CHECK_ARG(rows >= 0 && channels >= 1 && steps >= 1 && steps <= LT_MAX_T, "lif_train_backward: need 1 <= steps <= %d", LT_MAX_T);
+    if (workspace_bytes < sapcu_lif_train_workspace_bytes(rows, channels)) {
+        set_error("lif_train_backward: workspace of %lld bytes, need %lld", (long long)workspace_bytes,
+                  (long long)sapcu_lif_train_workspace_bytes(rows, channels));
+        return SAPCU_ERR_WORKSPACE;
+    }
+    const int64_t nb = (rows + LT_ROWS_PER_WG - 1) / LT_ROWS_PER_WG;
+    if (nb > 0) {
+        SAPCU_CHECK_ARG(nb < 0x7fffffffLL, "lif_train_backward: too many rows");
+        hipLaunchKernelGGL(lif_train_bwd_kernel, dim3((unsigned)nb, (unsigned)((channels + 63) / 64)), dim3(256), 0,
+                           (hipStream_t)stream, x, grad_spikes, rows, channels, steps, membrane_decay, threshold_adapt,
+                           refractory_decay, threshold_base, grad_x, (float*)workspace);
+        SAPCU_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(lif_train_param_reduce_kernel, dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, nb, channels, membrane_decay, threshold_adapt, refractory_decay,
+                       grad_membrane_decay, grad_threshold_adapt, grad_refractory_decay, grad_threshold_base);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+}  // extern "C"

@@ -96,6 +96,24 @@ int sapcu_neuron_selfloop(const float* x, int64_t rows, int channels, int steps,
                           float* spikes_out, float* membrane_out, float* threshold_out,
                           float* refractory_out, void* stream);
 
+/* Training-mode neuron loop (first piece) — fn/snn_coder.py:87-151 with `self.training`, driven
+ * as `for t: x, *st = snn(x, *st)` (:318-320): forward value = hard spikes (m - theta > 0), derivative = the soft
+ * surrogate's (straight-through estimator, :148-151), the refractory gate is a constant mask.
+ * x, spikes_out, grad_spikes, grad_x: [rows, channels] f32; parameters and their gradients: RAW per-channel values
+ * (clamped inside; a parameter outside its clamp range gets zero gradient, as torch.clamp gives it).  1 <= steps <= 8.
+ * The backward recomputes the forward from x (nothing is saved between the two calls); parameter gradients are summed
+ * over rows in a fixed order (deterministic) through a workspace of sapcu_lif_train_workspace_bytes(rows, channels). */
+int sapcu_lif_train_forward(const float* x, int64_t rows, int channels, int steps, const float* membrane_decay,
+                            const float* threshold_adapt, const float* refractory_decay,
+                            const float* threshold_base, float* spikes_out, void* stream);
+int64_t sapcu_lif_train_workspace_bytes(int64_t rows, int channels);
+int sapcu_lif_train_backward(const float* x, const float* grad_spikes, int64_t rows, int channels, int steps,
+                             const float* membrane_decay, const float* threshold_adapt,
+                             const float* refractory_decay, const float* threshold_base, float* grad_x,
+                             float* grad_membrane_decay, float* grad_threshold_adapt,
+                             float* grad_refractory_decay, float* grad_threshold_base, void* workspace,
+                             int64_t workspace_bytes, void* stream);
+
 /* In-patch kNN `topk(-|xi|^2 + 2 xi.xj - |xj|^2)` — fn/snn_coder.py:31-39, fd/snn_coder.py:25-32.
  * feat [b, m, ld] f32 (point-major, first c columns used), 1 <= m <= 128, k <= m.
  * idx_out [b,m,k] int32, descending score, equal scores by ascending index. */

@@ -1,0 +1,39 @@
+"""CPU ORACLE (test infrastructure, NOT product code) — training-mode neuron loop.
+
+torch restatement of /root/reference/fn/snn_coder.py:87-151 with ``self.training`` (hard spikes forward, soft-surrogate
+derivative backward through autograd's straight-through construction, constant gate mask), driven as at :318-320.
+Gradients come from torch autograd on this restatement.  Only ``tests/`` may import it.  Pinned by
+tests/golden/neuron_train.npz (the reference's own module in train mode, forward and backward).
+"""
+import math
+
+import torch
+
+
+def _expand(p, x):
+    return p.view([1, -1] + [1] * (x.dim() - 2)).expand_as(x)
+
+
+def spike_train(u, grad_width=10.0):
+    uc = torch.clamp(u, -10.0, 10.0)
+    soft = 0.5 * torch.exp(-(uc ** 2) / 2) / math.sqrt(2 * math.pi) + 0.5 * torch.sigmoid(grad_width * uc)
+    hard = (u > 0).float()
+    return soft + (hard - soft).detach()
+
+
+def lif_selfloop_train(x, membrane_decay, threshold_adapt, refractory_decay, threshold_base, steps=4):
+    decay = _expand(torch.clamp(membrane_decay, 0.1, 0.99), x)
+    adapt = _expand(torch.clamp(threshold_adapt, 0.001, 0.1), x)
+    rdecay = _expand(torch.clamp(refractory_decay, 0.1, 0.95), x)
+    theta0 = _expand(threshold_base, x)
+    m, th, r = torch.zeros_like(x), theta0, torch.zeros_like(x)
+    for _ in range(steps):
+        x = x * (r <= 0).float()
+        m = m * decay * (1 - r) + x
+        sp = spike_train(m - th)
+        m = m * (1 - sp)
+        r = r * rdecay + sp
+        th = th + adapt * sp
+        th = theta0 + (th - theta0) * 0.95
+        x = sp
+    return x

@@ -176,10 +176,45 @@ def fps_fixture():
     save("fps.npz", **out)
 
 
+def neuron_train_fixture():
+    """The reference's own LIF neuron IN TRAINING MODE (hard spikes + straight-through surrogate gradient), self-feeding for
+    T steps as fn drives it (fn/snn_coder.py:318-320): forward spikes and the gradients of sum(spikes * g) w.r.t. the input
+    and the four raw per-channel parameters, for 2-D, 3-D and 4-D inputs; parameters partly outside their clamp ranges."""
+    rng = np.random.default_rng(11)
+    out = {}
+    for tag, shape, T in (("2d", (96, 40), 4), ("3d", (5, 24, 17), 4), ("4d", (3, 16, 7, 5), 6), ("t1", (33, 8), 1)):
+        C = shape[1]
+        x = torch.tensor(rng.normal(0.6, 1.0, shape).astype(np.float32), requires_grad=True)
+        g = torch.tensor(rng.normal(0.0, 1.0, shape).astype(np.float32))
+        raw = np.stack([rng.uniform(0.05, 1.1, C), rng.uniform(-0.02, 0.15, C), rng.uniform(0.05, 1.0, C),
+                        rng.normal(0.7, 0.4, C)]).astype(np.float32)
+        neuron = ref_fn.MultiTimeConstantLIFNeuron(C)
+        with torch.no_grad():
+            neuron.membrane_decay.copy_(torch.from_numpy(raw[0]))
+            neuron.threshold_adapt.copy_(torch.from_numpy(raw[1]))
+            neuron.refractory_decay.copy_(torch.from_numpy(raw[2]))
+            neuron.threshold_base.copy_(torch.from_numpy(raw[3]))
+        neuron.train()
+        v, st = x, [None, None, None]
+        for _ in range(T):
+            v, *st = neuron(v, *st)
+        (v * g).sum().backward()
+        def gnp(p):                      # a parameter the loss does not depend on (T = 1) has no gradient: zeros
+            return npy(p.grad) if p.grad is not None else np.zeros(C, np.float32)
+        out.update({tag + "_x": npy(x), tag + "_g": npy(g), tag + "_raw": raw, tag + "_T": np.int64(T), tag + "_spikes": npy(v),
+                    tag + "_gx": npy(x.grad), tag + "_gmd": gnp(neuron.membrane_decay),
+                    tag + "_gta": gnp(neuron.threshold_adapt), tag + "_grd": gnp(neuron.refractory_decay),
+                    tag + "_gtb": gnp(neuron.threshold_base)})
+        print("neuron_train", tag, shape, "spike rate %.3f" % float(v.mean()), "|gx| %.3g" % float(x.grad.abs().mean()))
+    out["tags"] = np.array(["2d", "3d", "4d", "t1"])
+    save("neuron_train.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-e2e", action="store_true")
     ap.add_argument("--only-fps", action="store_true", help="only (re)generate fps.npz")
+    ap.add_argument("--only-train", action="store_true", help="only (re)generate neuron_train.npz")
     ap.add_argument("--only-seeds", action="store_true", help="only (re)generate dense_seeds.npz")
     args = ap.parse_args()
     if args.only_seeds:
@@ -187,6 +222,9 @@ def main():
         return
     if args.only_fps:
         fps_fixture()
+        return
+    if args.only_train:
+        neuron_train_fixture()
         return
     torch.manual_seed(0)
     torch.set_num_threads(8)

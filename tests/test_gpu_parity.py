@@ -685,3 +685,55 @@ def test_fused_batches_equal_batch_by_batch(weights):
         for other in outs[1:]:
             for a, b in zip(outs[0], other):
                 assert torch.equal(a, b), mode
+
+
+# ---------------------------------------------------------------------------------------------
+# row f-4, first piece: training-mode neuron loop (hard spikes forward, surrogate gradient backward)
+# ---------------------------------------------------------------------------------------------
+def test_training_neuron_loop_forward_backward_against_reference_run():
+    from sapcu_amd import train
+    g = golden("neuron_train.npz")
+    for tag in g["tags"]:
+        tag = str(tag)
+        x = _dev(g[tag + "_x"]).requires_grad_(True)
+        raw = [_dev(g[tag + "_raw"][i]).requires_grad_(True) for i in range(4)]
+        out = train.lif_selfloop_train(x, *raw, steps=int(g[tag + "_T"]))
+        assert torch.equal(out.detach().cpu(), torch.from_numpy(g[tag + "_spikes"])), tag       # 0/1 spikes: exact
+        (out * _dev(g[tag + "_g"])).sum().backward()
+        np.testing.assert_allclose(x.grad.cpu().numpy(), g[tag + "_gx"], rtol=2e-5, atol=1e-6, err_msg=tag)
+        for p, key in zip(raw, ("_gmd", "_gta", "_grd", "_gtb")):
+            np.testing.assert_allclose(p.grad.cpu().numpy(), g[tag + key], rtol=1e-4, atol=2e-5, err_msg=tag + key)
+
+
+def test_training_neuron_loop_against_oracle_autograd_at_size():
+    """[4096, 512] elements (2.1 M), T = 4: forward exact, gradients against torch autograd on the oracle; the parameter
+    gradients are sums over 4096 rows — compared relative to the sum of absolute contributions; run twice: bit-identical
+    (deterministic reduction)."""
+    from oracle import train_path as TP
+    from sapcu_amd import train
+    rng = np.random.default_rng(3)
+    rows, C = 4096, 512
+    xh = rng.normal(0.6, 1.0, (rows, C)).astype(np.float32)
+    gh = rng.normal(0.0, 1.0, (rows, C)).astype(np.float32)
+    rawh = np.stack([rng.uniform(0.05, 1.1, C), rng.uniform(-0.02, 0.15, C), rng.uniform(0.05, 1.0, C), rng.normal(0.7, 0.4, C)]).astype(np.float32)
+    xo = torch.from_numpy(xh).requires_grad_(True)
+    ro = [torch.from_numpy(rawh[i]).requires_grad_(True) for i in range(4)]
+    oo = TP.lif_selfloop_train(xo, *ro, steps=4)
+    (oo * torch.from_numpy(gh)).sum().backward()
+    runs = []
+    for _ in range(2):
+        x = _dev(xh).requires_grad_(True)
+        raw = [_dev(rawh[i]).requires_grad_(True) for i in range(4)]
+        out = train.lif_selfloop_train(x, *raw, steps=4)
+        (out * _dev(gh)).sum().backward()
+        runs.append([out.detach().cpu(), x.grad.cpu()] + [p.grad.cpu() for p in raw])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    out, gx, gp = runs[0][0], runs[0][1], runs[0][2:]
+    assert torch.equal(out, oo.detach())
+    np.testing.assert_allclose(gx.numpy(), xo.grad.numpy(), rtol=2e-5, atol=1e-6)
+    for got, want in zip(gp, ro):
+        scale = float(want.grad.abs().max()) + 1e-6
+        assert float((got - want.grad).abs().max()) <= 2e-4 * scale + 1e-4, float((got - want.grad).abs().max())
+    with pytest.raises(ValueError):
+        train.lif_selfloop_train(torch.zeros(4, 4), *[torch.zeros(4)] * 4)      # CPU tensor: no CPU path

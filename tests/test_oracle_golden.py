@@ -197,3 +197,21 @@ def test_fps_and_normalisation_against_reference_run():
     c, loc, scale = F.normalize_pointcloud(g["flat_in"])
     np.testing.assert_array_equal(c, g["flat_cloud"])
     assert scale == 0.0 == float(g["flat_scale"])
+
+
+def test_training_mode_neuron_loop_against_reference_run():
+    """Row f-4, first piece: the oracle's training-mode neuron loop (hard spikes, surrogate gradient) reproduces the
+    reference module's forward AND its autograd gradients (input + four raw parameters, clamp masks included)."""
+    from oracle import train_path as TP
+    g = golden("neuron_train.npz")
+    for tag in g["tags"]:
+        tag = str(tag)
+        x = t(g[tag + "_x"]).requires_grad_(True)
+        raw = [t(g[tag + "_raw"][i]).requires_grad_(True) for i in range(4)]
+        out = TP.lif_selfloop_train(x, *raw, steps=int(g[tag + "_T"]))
+        np.testing.assert_array_equal(out.detach().numpy(), g[tag + "_spikes"], err_msg=tag)
+        (out * t(g[tag + "_g"])).sum().backward()
+        np.testing.assert_allclose(x.grad.numpy(), g[tag + "_gx"], rtol=1e-5, atol=1e-7, err_msg=tag)
+        for p, key in zip(raw, ("_gmd", "_gta", "_grd", "_gtb")):
+            got = p.grad.numpy() if p.grad is not None else np.zeros_like(g[tag + key])
+            np.testing.assert_allclose(got, g[tag + key], rtol=1e-5, atol=1e-6, err_msg=tag + key)
