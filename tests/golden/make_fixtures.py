@@ -393,8 +393,10 @@ def main():
     rot = np.stack([np.matmul(mats[j], pat[j].T).T for j in range(64)], 0)
     save("rotation.npz", normals=nr, matrices=mats, rotated_f32=rot.astype(np.float32))
 
-    # ---- 9b. seed generator outputs
+    # ---- 9b. seed generator outputs, FPS / normalisation (generate.py), training-mode neuron (row f-4)
     seed_fixture()
+    fps_fixture()
+    neuron_train_fixture()
 
     # ---- 10. end-to-end Generator3D6.upsample on sphere N=2048, dense_spacing 0.03 (~900 seeds)
     if not args.skip_e2e:
