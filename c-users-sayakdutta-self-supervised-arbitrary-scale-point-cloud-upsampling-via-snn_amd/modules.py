@@ -98,10 +98,13 @@ class _HipModel(nn.Module):
                 _lib.load().sapcu_model_destroy(self._handle)
             except Exception:
                 pass
-            self._handle = None
+            object.__setattr__(self, "_handle", None)     # (plain attribute: nn.Module.__setattr__ is not usable at interpreter exit)
 
     def __del__(self):
-        self._release()
+        try:
+            self._release()
+        except Exception:       # interpreter shutdown: modules this needs may already be gone; the process is ending anyway
+            pass
 
     def _workspace(self, handle, b, m, dev):
         need = _lib.load().sapcu_workspace_bytes(handle, b, m)
