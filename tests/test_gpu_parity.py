@@ -737,3 +737,26 @@ def test_training_neuron_loop_against_oracle_autograd_at_size():
         assert float((got - want.grad).abs().max()) <= 2e-4 * scale + 1e-4, float((got - want.grad).abs().max())
     with pytest.raises(ValueError):
         train.lif_selfloop_train(torch.zeros(4, 4), *[torch.zeros(4)] * 4)      # CPU tensor: no CPU path
+
+
+def test_weights_are_repacked_after_a_checkpoint_load(weights):
+    """The packed device blob follows the module's parameters: after load_state_dict of other weights (CheckpointIO.load
+    does exactly that) or an in-place edit, the next forward uses the new values; .eval()/.reset_states() keep it."""
+    fn, fd, sdn, sdd = U.build_gpu_models(weights)
+    fn.knn_cache_mode = "fresh"
+    patch = U.sphere_patches(6, 48, skip=100).to(U.dev())
+    n0, d0 = fn(patch).clone(), fd(patch).clone()
+    h0 = fn._handle.value
+    fn.eval(); fn.reset_states()
+    assert torch.equal(fn(patch), n0) and fn._handle.value == h0            # nothing changed: same engine
+    sd2 = {k: (v * 1.03 if v.dtype.is_floating_point and "running_var" not in k and "num_batches" not in k else v) for k, v in sdn.items()}
+    fn.load_state_dict(sd2, strict=True)
+    n1 = fn(patch)
+    assert not torch.equal(n1, n0)
+    fresh, _, _, _ = U.build_gpu_models(weights)
+    fresh.load_state_dict(sd2, strict=True)
+    fresh.knn_cache_mode = "fresh"
+    assert torch.equal(fresh(patch), n1)
+    with torch.no_grad():
+        fd.distance_decoder.fc_distance.bias.add_(0.25)                         # in-place edit bumps the tensor version
+    assert not torch.equal(fd(patch), d0)
