@@ -265,7 +265,9 @@ def main():
             "metric": "upsampled query-points/sec (kNN + fn fwd + rotate + fd fwd + displace), 4x scale, M=48 T=4",
             "value": round(total / dt, 2), "unit": "query-points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (GEMMs as 3 x f16 MFMA with f32 accumulation; outer kNN f64)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32 (GEMMs on the exact-f32 MFMA kernels, SAPCU_GEMM=f32; outer kNN f64)" if os.environ.get("SAPCU_GEMM") == "f32"
+                      else "f32 (GEMMs as 3 x f16 MFMA with f32 accumulation; outer kNN f64)"), "data": "synthetic",
             "config": {"workload": "synthetic sphere N=%d (seed 0), B=%d grid queries per GPU per step, M=%d, T=%d, "
                                    "fn k=[24,18,12] emb 640, fd k=32 scales [8,16,32,48] emb 768, conditioned-random "
                                    "weights seed 0, in-patch kNN recomputed every batch" % (N_CLOUD, B_PER_GPU, M_PTS, T_STEPS),
