@@ -152,6 +152,146 @@ __global__ __launch_bounds__(256) void lif_train_param_reduce_kernel(const float
     g_tb[c] = s[3];
 }
 
+// =============================================================================================
+// Layer pieces of the training step: BatchNorm in training mode (batch statistics over the rows of a [rows, C] tensor —
+// what nn.BatchNorm1d/2d do to a 1x1 convolution's output, fn/snn_coder.py:225-252), its backward, and the weight /
+// bias gradients of the 1x1 convolution.  All column reductions are deterministic: fixed-order partial sums per
+// workgroup (f64), then a fixed-order sum of the partials.
+// =============================================================================================
+constexpr int CR_ROWS = 256;     // rows per workgroup of the column reductions
+
+// partial[b][q][c] (f64), q = 0: sum of u(row,c), q = 1: sum of u*v.   MODE 0: u = a, v = a (sum, sum of squares)
+//                                                                    MODE 1: u = a (= dz), v = (b - mean) * invstd (= y_hat)
+template <int MODE>
+__global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t rows,
+                                                          int ch, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          double* __restrict__ partial) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= ch) return;
+    const int64_t r0 = (int64_t)blockIdx.x * CR_ROWS;
+    const int64_t r1 = r0 + CR_ROWS < rows ? r0 + CR_ROWS : rows;
+    const float mu = MODE == 1 ? mean[c] : 0.f, is = MODE == 1 ? invstd[c] : 0.f;
+    double s0 = 0.0, s1 = 0.0;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float u = a[r * ch + c];
+        const float v = MODE == 0 ? u : (b[r * ch + c] - mu) * is;
+        s0 += (double)u;
+        s1 += (double)u * (double)v;
+    }
+    partial[((int64_t)blockIdx.x * 2 + 0) * ch + c] = s0;
+    partial[((int64_t)blockIdx.x * 2 + 1) * ch + c] = s1;
+}
+
+__global__ __launch_bounds__(256) void col_final_kernel(const double* __restrict__ partial, int64_t nb, int ch,
+                                                        double* __restrict__ sums /*[2][ch]*/) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ch) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int64_t b = 0; b < nb; ++b) {
+        s0 += partial[(b * 2 + 0) * ch + c];
+        s1 += partial[(b * 2 + 1) * ch + c];
+    }
+    sums[c] = s0;
+    sums[ch + c] = s1;
+}
+
+__global__ __launch_bounds__(256) void bn_train_apply_kernel(const float* __restrict__ y, int64_t rows, int ch,
+                                                             const double* __restrict__ sums, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, float* __restrict__ z,
+                                                             float* __restrict__ mean_out, float* __restrict__ var_out,
+                                                             float* __restrict__ invstd_out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * ch) return;
+    const int c = (int)(t % ch);
+    const double mu = sums[c] / (double)rows;
+    double var = sums[ch + c] / (double)rows - mu * mu;       // biased variance: what training-mode normalisation uses
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    if (t < ch) {
+        mean_out[c] = (float)mu;
+        var_out[c] = (float)var;
+        invstd_out[c] = is;
+    }
+    z[t] = (y[t] - (float)mu) * is * gamma[c] + beta[c];
+}
+
+// dy = gamma * invstd * (dz - sum(dz)/R - y_hat * sum(dz*y_hat)/R);  dgamma = sum(dz*y_hat), dbeta = sum(dz)
+__global__ __launch_bounds__(256) void bn_train_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ dz,
+                                                                 int64_t rows, int ch, const double* __restrict__ sums,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, float* __restrict__ dy,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * ch) return;
+    const int c = (int)(t % ch);
+    const float sdz = (float)(sums[c] / (double)rows), sdzy = (float)(sums[ch + c] / (double)rows);
+    if (t < ch) {
+        dbeta[c] = (float)sums[c];
+        dgamma[c] = (float)sums[ch + c];
+    }
+    const float yh = (y[t] - mean[c]) * invstd[c];
+    dy[t] = gamma[c] * invstd[c] * (dz[t] - sdz - yh * sdzy);
+}
+
+// ---- weight gradient of a 1x1 convolution: dW[n,k] = sum_r dY[r,n] * X[r,k]  (exact-f32 MFMA, 2 rows per instruction).
+// Workgroup = 4 waves = one 64x64 tile of dW over one slab of rows; wave (wn, wk) owns a 32x32 block: lane l supplies
+// dY[r + (l>>5)][n0 + wn*32 + (l&31)] and X[r + (l>>5)][k0 + wk*32 + (l&31)] — row-major tensors are already in the
+// operand layout of v_mfma_f32_32x32x2_f32 for this product, no transposition.  Partials [slab][n][k] are summed in slab
+// order by wgrad_reduce_kernel (deterministic).  First version: operands come straight from global memory (L2 absorbs the
+// n/64-fold and k/64-fold re-reads); an LDS-staged / larger-tile version is future work.
+typedef float f32x16t __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void wgrad_partial_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x,
+                                                            int ldx, int64_t rows, int n, int k, int64_t rows_per_slab,
+                                                            float* __restrict__ partial /*[slabs][n][k]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int nn = blockIdx.x * 64 + wn * 32 + (lane & 31);
+    const int kc = blockIdx.y * 64 + wk * 32 + (lane & 31);
+    const int par = lane >> 5;
+    const int64_t r0 = (int64_t)blockIdx.z * rows_per_slab;
+    const int64_t r1 = r0 + rows_per_slab < rows ? r0 + rows_per_slab : rows;
+    f32x16t acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const bool nok = nn < n, kok = kc < k;
+    for (int64_t r = r0; r < r1; r += 2) {
+        const int64_t rr = r + par;
+        const bool rok = rr < r1;
+        const float av = (rok && nok) ? dy[rr * ldy + nn] : 0.f;
+        const float bv = (rok && kok) ? x[rr * ldx + kc] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    // accumulator layout: lane = column (k index within the block) + 32 * h, register e = row (e&3) + 8*(e>>2) + 4h (n index)
+    float* out = partial + (int64_t)blockIdx.z * n * k;
+    const int col = blockIdx.y * 64 + wk * 32 + (lane & 31);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = blockIdx.x * 64 + wn * 32 + (e & 3) + 8 * (e >> 2) + 4 * par;
+        if (row < n && col < k) out[(int64_t)row * k + col] = acc[e];
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int slabs, int64_t count,
+                                                           float* __restrict__ dw) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    float s = 0.f;
+    for (int b = 0; b < slabs; ++b) s += partial[(int64_t)b * count + t];
+    dw[t] = s;
+}
+
+__global__ __launch_bounds__(256) void colsum_to_float_kernel(const double* __restrict__ sums, int ch, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < ch) out[c] = (float)sums[c];
+}
+
+static int64_t col_blocks(int64_t rows) { return rows > 0 ? (rows + CR_ROWS - 1) / CR_ROWS : 0; }
+static int wgrad_slabs(int64_t rows) {
+    int64_t s = (rows + 8191) / 8192;
+    return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
+}
+
 }  // namespace sapcu
 
 using namespace sapcu;
@@ -203,6 +343,89 @@ int sapcu_lif_train_backward(const float* x, const float* grad_spikes, int64_t r
     hipLaunchKernelGGL(lif_train_param_reduce_kernel, dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, nb, channels, membrane_decay, threshold_adapt, refractory_decay,
                        grad_membrane_decay, grad_threshold_adapt, grad_refractory_decay, grad_threshold_base);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+
+int64_t sapcu_train_workspace_bytes(int64_t rows, int channels, int k) {
+    if (rows < 0 || channels < 1 || k < 0) return -1;
+    const int64_t col = (col_blocks(rows) * 2 + 2) * (int64_t)channels * (int64_t)sizeof(double);
+    const int64_t wg = (int64_t)wgrad_slabs(rows) * channels * (int64_t)(k > 0 ? k : 1) * (int64_t)sizeof(float);
+    return (col > wg ? col : wg) + 256;
+}
+
+static int column_sums(int mode, const float* a, const float* b, int64_t rows, int ch, const float* mean, const float* invstd,
+                       double* ws, double** sums_out, hipStream_t st) {
+    const int64_t nb = col_blocks(rows);
+    double* partial = ws;
+    double* sums = ws + nb * 2 * (int64_t)ch;
+    const dim3 grid((unsigned)(nb > 0 ? nb : 1), (unsigned)((ch + 255) / 256));
+    if (nb > 0) {
+        if (mode == 0) hipLaunchKernelGGL(col_partial_kernel<0>, grid, dim3(256), 0, st, a, b, rows, ch, mean, invstd, partial);
+        else hipLaunchKernelGGL(col_partial_kernel<1>, grid, dim3(256), 0, st, a, b, rows, ch, mean, invstd, partial);
+        SAPCU_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(col_final_kernel, dim3((unsigned)((ch + 255) / 256)), dim3(256), 0, st, partial, nb, ch, sums);
+    SAPCU_CHECK_LAUNCH();
+    *sums_out = sums;
+    return SAPCU_OK;
+}
+
+int sapcu_bn_train_forward(const float* y, int64_t rows, int channels, const float* gamma, const float* beta, float eps,
+                           float* z_out, float* mean_out, float* var_out, float* invstd_out, void* workspace,
+                           int64_t workspace_bytes, void* stream) {
+    SAPCU_CHECK_ARG(y && gamma && beta && z_out && mean_out && var_out && invstd_out && workspace && rows >= 1 && channels >= 1,
+                    "bn_train_forward: bad argument");
+    SAPCU_CHECK_ARG(workspace_bytes >= sapcu_train_workspace_bytes(rows, channels, 0), "bn_train_forward: workspace too small");
+    double* sums = nullptr;
+    int rc = column_sums(0, y, nullptr, rows, channels, nullptr, nullptr, (double*)workspace, &sums, (hipStream_t)stream);
+    if (rc != SAPCU_OK) return rc;
+    const int64_t total = rows * channels;
+    hipLaunchKernelGGL(bn_train_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, rows,
+                       channels, sums, gamma, beta, eps, z_out, mean_out, var_out, invstd_out);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+int sapcu_bn_train_backward(const float* y, const float* grad_z, int64_t rows, int channels, const float* gamma,
+                            const float* mean, const float* invstd, float* grad_y, float* grad_gamma, float* grad_beta,
+                            void* workspace, int64_t workspace_bytes, void* stream) {
+    SAPCU_CHECK_ARG(y && grad_z && gamma && mean && invstd && grad_y && grad_gamma && grad_beta && workspace && rows >= 1 &&
+                        channels >= 1, "bn_train_backward: bad argument");
+    SAPCU_CHECK_ARG(workspace_bytes >= sapcu_train_workspace_bytes(rows, channels, 0), "bn_train_backward: workspace too small");
+    double* sums = nullptr;
+    int rc = column_sums(1, grad_z, y, rows, channels, mean, invstd, (double*)workspace, &sums, (hipStream_t)stream);
+    if (rc != SAPCU_OK) return rc;
+    const int64_t total = rows * channels;
+    hipLaunchKernelGGL(bn_train_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, grad_z,
+                       rows, channels, sums, gamma, mean, invstd, grad_y, grad_gamma, grad_beta);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+int sapcu_conv1x1_wgrad_f32(const float* grad_y, int ldy, const float* x, int ldx, int64_t rows, int n, int k, float* grad_w,
+                            float* grad_bias, void* workspace, int64_t workspace_bytes, void* stream) {
+    SAPCU_CHECK_ARG(grad_y && x && grad_w && workspace && rows >= 1 && n >= 1 && k >= 1 && ldy >= n && ldx >= k,
+                    "conv1x1_wgrad: bad argument");
+    SAPCU_CHECK_ARG(workspace_bytes >= sapcu_train_workspace_bytes(rows, n, k), "conv1x1_wgrad: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (grad_bias) {                                   // db = column sums of dY (needs a dense dY for the shared reduction)
+        SAPCU_CHECK_ARG(ldy == n, "conv1x1_wgrad: the bias gradient needs ldy == n");
+        double* sums = nullptr;
+        int rc = column_sums(0, grad_y, nullptr, rows, n, nullptr, nullptr, (double*)workspace, &sums, st);
+        if (rc != SAPCU_OK) return rc;
+        hipLaunchKernelGGL(colsum_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sums, n, grad_bias);
+        SAPCU_CHECK_LAUNCH();
+    }
+    const int slabs = wgrad_slabs(rows);
+    const int64_t rps = (((rows + slabs - 1) / slabs) + 1) & ~(int64_t)1;      // even: a slab's row pairs stay inside it
+    hipLaunchKernelGGL(wgrad_partial_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)((k + 63) / 64), (unsigned)slabs), dim3(256), 0,
+                       st, grad_y, ldy, x, ldx, rows, n, k, rps, (float*)workspace);
+    SAPCU_CHECK_LAUNCH();
+    const int64_t count = (int64_t)n * k;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, (const float*)workspace, slabs,
+                       count, grad_w);
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
 }

@@ -1,9 +1,11 @@
-"""Training-side ops: so far the surrogate-gradient neuron loop.
+"""Training-side ops: the surrogate-gradient neuron loop and one trainable layer.
 
 ``lif_selfloop_train`` is the T-step self-feeding loop of ``MultiTimeConstantLIFNeuron`` in training mode
 (/root/reference/fn/snn_coder.py:87-151, driven as at :318-320) as one differentiable op: hard spikes forward, the soft
-surrogate's derivative backward, both as HIP kernels (csrc/train_ops.hip).  The rest of the training step (the blocks'
-backward, BatchNorm in training mode, losses, optimiser) is not built yet.
+surrogate's derivative backward.  ``conv_bn_lif_train`` is fn's basic building block in training mode — 1x1 convolution +
+BatchNorm (batch statistics) + that neuron loop (fn/snn_coder.py:225-229,317-320) — forward and backward on HIP kernels
+(csrc/train_ops.hip; the convolution's forward and data gradient are the library's exact-f32 GEMM).  The rest of the
+training step (attention/softmax/gather backward, pooling, decoder, losses, optimiser, bf16) is not built yet.
 """
 import torch
 
@@ -51,3 +53,86 @@ def lif_selfloop_train(x, membrane_decay, threshold_adapt, refractory_decay, thr
     """x [B, C] | [B, C, N] | [B, C, N, k] (channel axis 1, as the reference's neuron takes it) -> hard spikes of the last of
     `steps` self-feeding neuron steps; differentiable w.r.t. x and the four raw per-channel parameters."""
     return _LifSelfLoopTrain.apply(x, membrane_decay, threshold_adapt, refractory_decay, threshold_base, steps)
+
+
+def _ws(lib, rows, ch, k, dev):
+    nbytes = int(lib.sapcu_train_workspace_bytes(rows, ch, k))
+    return torch.empty((nbytes,), dtype=torch.uint8, device=dev), nbytes
+
+
+def _gemm(lib, a, w, bias, out):
+    """out[r, n] = a[r, k] . w[n, k]^T (+ bias): the exact-f32 MFMA kernel (k % 32 == 0)."""
+    r, k = a.shape
+    n = w.shape[0]
+    _lib.check(lib.sapcu_gemm_f32(_lib.ptr(a), r, k, k, _lib.ptr(w), n, _lib.ptr(bias), None, 0, _lib.ptr(out), n, None, 0, 0,
+                                  _lib.current_stream()))
+    return out
+
+
+class _ConvBnLifTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, membrane_decay, threshold_adapt, refractory_decay, threshold_base, steps, eps):
+        lib = _lib.load()
+        rows, cin = x.shape
+        cout = weight.shape[0]
+        if cin % 32 or cout % 32:
+            raise ValueError("conv_bn_lif_train: channel counts must be multiples of 32 (got %d -> %d)" % (cin, cout))
+        dev = x.device
+        x = x.contiguous()
+        w = weight.detach().contiguous()
+        prm = [p.detach().contiguous() for p in (membrane_decay, threshold_adapt, refractory_decay, threshold_base)]
+        y = torch.empty((rows, cout), dtype=torch.float32, device=dev)
+        z = torch.empty_like(y)
+        mean, var, invstd = (torch.empty((cout,), dtype=torch.float32, device=dev) for _ in range(3))
+        spikes = torch.empty_like(y)
+        ws, nbytes = _ws(lib, rows, cout, 0, dev)
+        with torch.cuda.device(dev):
+            _gemm(lib, x, w, bias.detach().contiguous(), y)
+            _lib.check(lib.sapcu_bn_train_forward(_lib.ptr(y), rows, cout, _lib.ptr(gamma.detach().contiguous()),
+                                                  _lib.ptr(beta.detach().contiguous()), float(eps), _lib.ptr(z), _lib.ptr(mean),
+                                                  _lib.ptr(var), _lib.ptr(invstd), _lib.ptr(ws), nbytes, _lib.current_stream()))
+            _lib.check(lib.sapcu_lif_train_forward(_lib.ptr(z), rows, cout, int(steps), *[_lib.ptr(p) for p in prm],
+                                                   _lib.ptr(spikes), _lib.current_stream()))
+        ctx.save_for_backward(x, w, gamma.detach().contiguous(), y, z, mean, invstd, *prm)
+        ctx.steps = int(steps)
+        ctx.batch_stats = (mean, var)
+        return spikes
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        x, w, gamma, y, z, mean, invstd, md, ta, rd, tb = ctx.saved_tensors
+        rows, cin = x.shape
+        cout = w.shape[0]
+        dev = x.device
+        g = grad_out.contiguous()
+        dz, dy, dx = torch.empty_like(y), torch.empty_like(y), torch.empty_like(x)
+        gp = [torch.empty_like(md) for _ in range(4)]
+        dgamma, dbeta, dbias = (torch.empty((cout,), dtype=torch.float32, device=dev) for _ in range(3))
+        dw = torch.empty_like(w)
+        ws, nbytes = _ws(lib, rows, cout, cin, dev)
+        lws_bytes = int(lib.sapcu_lif_train_workspace_bytes(rows, cout))
+        lws = torch.empty((lws_bytes,), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            st = _lib.current_stream()
+            _lib.check(lib.sapcu_lif_train_backward(_lib.ptr(z), _lib.ptr(g), rows, cout, ctx.steps, _lib.ptr(md), _lib.ptr(ta),
+                                                    _lib.ptr(rd), _lib.ptr(tb), _lib.ptr(dz), *[_lib.ptr(t) for t in gp],
+                                                    _lib.ptr(lws), lws_bytes, st))
+            _lib.check(lib.sapcu_bn_train_backward(_lib.ptr(y), _lib.ptr(dz), rows, cout, _lib.ptr(gamma), _lib.ptr(mean),
+                                                   _lib.ptr(invstd), _lib.ptr(dy), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws),
+                                                   nbytes, st))
+            _lib.check(lib.sapcu_conv1x1_wgrad_f32(_lib.ptr(dy), cout, _lib.ptr(x), cin, rows, cout, cin, _lib.ptr(dw),
+                                                   _lib.ptr(dbias), _lib.ptr(ws), nbytes, st))
+            _gemm(lib, dy, w.t().contiguous(), None, dx)            # dx[r, cin] = dy[r, cout] . (W^T)[cin, cout]^T
+        return (dx, dw, dbias, dgamma, dbeta, gp[0], gp[1], gp[2], gp[3], None, None)
+
+
+def conv_bn_lif_train(x, weight, bias, gamma, beta, membrane_decay, threshold_adapt, refractory_decay, threshold_base,
+                      steps=4, eps=1e-5):
+    """fn's basic layer in TRAINING mode (fn/snn_coder.py:225-229 + 317-320): x [rows, c_in] (channels last) ->
+    hard spikes [rows, c_out] of `steps` neuron steps on BatchNorm_train(x . W^T + b).  Differentiable w.r.t. x and all nine
+    parameter tensors.  (The BatchNorm running statistics are not touched: `batch_stats(out)` returns the batch mean and
+    biased variance for the caller's momentum update.)"""
+    w2 = weight.reshape(weight.shape[0], -1)                      # Conv1d/Conv2d 1x1 weights [c_out, c_in, 1(,1)]
+    return _ConvBnLifTrain.apply(x, w2, bias, gamma, beta, membrane_decay, threshold_adapt, refractory_decay, threshold_base,
+                                 steps, eps)

@@ -114,6 +114,25 @@ int sapcu_lif_train_backward(const float* x, const float* grad_spikes, int64_t r
                              float* grad_refractory_decay, float* grad_threshold_base, void* workspace,
                              int64_t workspace_bytes, void* stream);
 
+/* Layer pieces of the training step (row f-4): BatchNorm in TRAINING mode over the rows of a [rows, channels] tensor (what
+ * nn.BatchNorm1d/2d do to a 1x1 convolution's output, fn/snn_coder.py:225-252: batch mean and biased variance), its
+ * backward, and the weight / bias gradient of the 1x1 convolution.  Deterministic reductions (fixed-order f64 partial
+ * sums).  workspace: sapcu_train_workspace_bytes(rows, channels, k) bytes (k = 0 for the BatchNorm calls).
+ *   forward : z = (y - mean) * invstd * gamma + beta;   mean/var (biased)/invstd [channels] are outputs (the running
+ *             statistics update is the caller's: momentum, unbiased variance)
+ *   backward: grad_y = gamma*invstd*(grad_z - mean_r(grad_z) - y_hat*mean_r(grad_z*y_hat)); grad_gamma, grad_beta
+ *   wgrad   : grad_w[n,k] = sum_r grad_y[r,n] * x[r,k]  (exact-f32 MFMA);  grad_bias[n] = sum_r grad_y[r,n] (optional)
+ * The data gradient of the convolution is a plain GEMM: sapcu_gemm_f32(grad_y, rows, n, ldy, W^T [k,n], k, ...). */
+int64_t sapcu_train_workspace_bytes(int64_t rows, int channels, int k);
+int sapcu_bn_train_forward(const float* y, int64_t rows, int channels, const float* gamma, const float* beta, float eps,
+                           float* z_out, float* mean_out, float* var_out, float* invstd_out, void* workspace,
+                           int64_t workspace_bytes, void* stream);
+int sapcu_bn_train_backward(const float* y, const float* grad_z, int64_t rows, int channels, const float* gamma,
+                            const float* mean, const float* invstd, float* grad_y, float* grad_gamma,
+                            float* grad_beta, void* workspace, int64_t workspace_bytes, void* stream);
+int sapcu_conv1x1_wgrad_f32(const float* grad_y, int ldy, const float* x, int ldx, int64_t rows, int n, int k,
+                            float* grad_w, float* grad_bias, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* In-patch kNN `topk(-|xi|^2 + 2 xi.xj - |xj|^2)` — fn/snn_coder.py:31-39, fd/snn_coder.py:25-32.
  * feat [b, m, ld] f32 (point-major, first c columns used), 1 <= m <= 128, k <= m.
  * idx_out [b,m,k] int32, descending score, equal scores by ascending index. */

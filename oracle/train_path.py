@@ -37,3 +37,13 @@ def lif_selfloop_train(x, membrane_decay, threshold_adapt, refractory_decay, thr
         th = theta0 + (th - theta0) * 0.95
         x = sp
     return x
+
+
+def conv_bn_lif_train(x, weight, bias, gamma, beta, membrane_decay, threshold_adapt, refractory_decay, threshold_base,
+                      steps=4, eps=1e-5):
+    """fn/snn_coder.py:225-229 + 317-320 in training mode on channels-last rows: x [rows, c_in] -> spikes [rows, c_out]."""
+    y = x @ weight.reshape(weight.shape[0], -1).t() + bias
+    mean = y.mean(0)
+    var = y.var(0, unbiased=False)
+    z = (y - mean) / torch.sqrt(var + eps) * gamma + beta
+    return lif_selfloop_train(z, membrane_decay, threshold_adapt, refractory_decay, threshold_base, steps)

@@ -207,6 +207,34 @@ def neuron_train_fixture():
                     tag + "_gtb": gnp(neuron.threshold_base)})
         print("neuron_train", tag, shape, "spike rate %.3f" % float(v.mean()), "|gx| %.3g" % float(x.grad.abs().mean()))
     out["tags"] = np.array(["2d", "3d", "4d", "t1"])
+    # the reference's layer in training mode: Conv1d(64, 128, 1) + BatchNorm1d(128) + LIF x 4 (fn/snn_coder.py:225-229, 317-320)
+    B, N, cin, cout = 6, 40, 64, 128
+    conv, bn, neuron = nn.Conv1d(cin, cout, 1), nn.BatchNorm1d(cout), ref_fn.MultiTimeConstantLIFNeuron(cout)
+    with torch.no_grad():
+        bn.weight.copy_(torch.tensor(rng.uniform(0.5, 1.5, cout).astype(np.float32)))
+        bn.bias.copy_(torch.tensor(rng.normal(0.4, 0.5, cout).astype(np.float32)))
+        neuron.membrane_decay.copy_(torch.tensor(rng.uniform(0.05, 1.1, cout).astype(np.float32)))
+        neuron.threshold_adapt.copy_(torch.tensor(rng.uniform(-0.02, 0.15, cout).astype(np.float32)))
+        neuron.refractory_decay.copy_(torch.tensor(rng.uniform(0.05, 1.0, cout).astype(np.float32)))
+        neuron.threshold_base.copy_(torch.tensor(rng.normal(0.7, 0.4, cout).astype(np.float32)))
+    for mod in (conv, bn, neuron):
+        mod.train()
+    x = torch.tensor(rng.normal(0.0, 1.0, (B, cin, N)).astype(np.float32), requires_grad=True)
+    g = torch.tensor(rng.normal(0.0, 1.0, (B, cout, N)).astype(np.float32))
+    v, st = bn(conv(x)), [None, None, None]
+    for _ in range(4):
+        v, *st = neuron(v, *st)
+    (v * g).sum().backward()
+    out.update({"layer_x": npy(x), "layer_g": npy(g), "layer_spikes": npy(v), "layer_gx": npy(x.grad),
+                "layer_w": npy(conv.weight), "layer_b": npy(conv.bias), "layer_gamma": npy(bn.weight), "layer_beta": npy(bn.bias),
+                "layer_raw": np.stack([npy(neuron.membrane_decay), npy(neuron.threshold_adapt), npy(neuron.refractory_decay),
+                                       npy(neuron.threshold_base)]),
+                "layer_gw": npy(conv.weight.grad), "layer_gb": npy(conv.bias.grad), "layer_ggamma": npy(bn.weight.grad),
+                "layer_gbeta": npy(bn.bias.grad),
+                "layer_graw": np.stack([npy(neuron.membrane_decay.grad), npy(neuron.threshold_adapt.grad),
+                                        npy(neuron.refractory_decay.grad), npy(neuron.threshold_base.grad)]),
+                "layer_running_mean": npy(bn.running_mean), "layer_running_var": npy(bn.running_var)})
+    print("layer", tuple(x.shape), "->", tuple(v.shape), "spike rate %.3f" % float(v.mean()))
     save("neuron_train.npz", **out)
 
 

@@ -760,3 +760,56 @@ def test_weights_are_repacked_after_a_checkpoint_load(weights):
     with torch.no_grad():
         fd.distance_decoder.fc_distance.bias.add_(0.25)                         # in-place edit bumps the tensor version
     assert not torch.equal(fd(patch), d0)
+
+
+def _rel_l2(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def test_training_layer_conv_bn_neuron_forward_backward():
+    """fn's basic layer in training mode on the HIP ops (exact-f32 GEMM, BatchNorm batch statistics, neuron loop; wgrad,
+    BatchNorm backward, data-gradient GEMM) against the reference run (fixture) and, at 24 576 rows x 128 -> 256
+    channels, against torch autograd on the oracle.  A pre-activation within rounding of its threshold may flip a hard
+    spike: the flip rate is bounded and the gradients are compared in relative L2."""
+    from oracle import train_path as TP
+    from sapcu_amd import train
+    g = golden("neuron_train.npz")
+    B, cin, N = g["layer_x"].shape
+    cout = g["layer_w"].shape[0]
+    x = _dev(g["layer_x"]).permute(0, 2, 1).reshape(B * N, cin).clone().requires_grad_(True)
+    prm = [_dev(g[k]).clone().requires_grad_(True) for k in ("layer_w", "layer_b", "layer_gamma", "layer_beta")]
+    raw = [_dev(g["layer_raw"][i]).clone().requires_grad_(True) for i in range(4)]
+    out = train.conv_bn_lif_train(x, *prm, *raw, steps=4)
+    want = torch.from_numpy(g["layer_spikes"]).permute(0, 2, 1).reshape(B * N, cout)
+    assert torch.equal(out.detach().cpu(), want)
+    (out * _dev(g["layer_g"]).permute(0, 2, 1).reshape(B * N, cout)).sum().backward()
+    gx = torch.from_numpy(g["layer_gx"]).permute(0, 2, 1).reshape(B * N, cin)
+    assert _rel_l2(x.grad.cpu(), gx) <= 2e-4
+    for p, key in zip(prm, ("layer_gw", "layer_gb", "layer_ggamma", "layer_gbeta")):
+        ref = torch.from_numpy(g[key]).reshape(p.shape)
+        assert (p.grad.cpu() - ref).abs().max() <= 2e-4 * max(1.0, float(ref.abs().max())), key
+    for i, p in enumerate(raw):
+        ref = torch.from_numpy(g["layer_graw"][i])
+        assert (p.grad.cpu() - ref).abs().max() <= 2e-4 * max(1.0, float(ref.abs().max()))
+    # larger, against the oracle's autograd
+    rng = np.random.default_rng(9)
+    rows, cin, cout = 24576, 128, 256
+    xh = rng.normal(0, 1, (rows, cin)).astype(np.float32)
+    wh = (rng.normal(0, 1, (cout, cin)) / np.sqrt(cin)).astype(np.float32)
+    bh, gah, beh = rng.normal(0, 0.1, cout).astype(np.float32), rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0.4, 0.5, cout).astype(np.float32)
+    rawh = np.stack([rng.uniform(0.05, 1.1, cout), rng.uniform(-0.02, 0.15, cout), rng.uniform(0.05, 1.0, cout), rng.normal(0.7, 0.4, cout)]).astype(np.float32)
+    gh = rng.normal(0, 1, (rows, cout)).astype(np.float32)
+    host = [torch.from_numpy(a).clone().requires_grad_(True) for a in (xh, wh, bh, gah, beh, rawh[0], rawh[1], rawh[2], rawh[3])]
+    oo = TP.conv_bn_lif_train(*host, steps=4)
+    (oo * torch.from_numpy(gh)).sum().backward()
+    devt = [_dev(a).clone().requires_grad_(True) for a in (xh, wh, bh, gah, beh, rawh[0], rawh[1], rawh[2], rawh[3])]
+    od = train.conv_bn_lif_train(*devt, steps=4)
+    (od * _dev(gh)).sum().backward()
+    flips = float((od.detach().cpu() != oo.detach()).float().mean())
+    assert flips <= 2e-5, flips
+    names = ["x", "w", "b", "gamma", "beta", "decay", "adapt", "rdecay", "theta0"]
+    for nme, hd, dd in zip(names, host, devt):
+        if nme == "b":                                    # the conv bias cancels in BatchNorm: its gradient is rounding noise
+            assert float(dd.grad.abs().max()) <= 1e-2
+            continue
+        assert _rel_l2(dd.grad.cpu(), hd.grad) <= 5e-3 + 50 * flips, (nme, _rel_l2(dd.grad.cpu(), hd.grad))

@@ -215,3 +215,26 @@ def test_training_mode_neuron_loop_against_reference_run():
         for p, key in zip(raw, ("_gmd", "_gta", "_grd", "_gtb")):
             got = p.grad.numpy() if p.grad is not None else np.zeros_like(g[tag + key])
             np.testing.assert_allclose(got, g[tag + key], rtol=1e-5, atol=1e-6, err_msg=tag + key)
+
+
+def test_training_layer_conv_bn_neuron_against_reference_run():
+    """Row f-4: the oracle's layer restatement (1x1 conv + BatchNorm batch statistics + neuron loop, channels-last rows)
+    reproduces the reference modules in train mode: spikes exact, all ten gradients."""
+    from oracle import train_path as TP
+    g = golden("neuron_train.npz")
+    B, cin, N = g["layer_x"].shape
+    cout = g["layer_w"].shape[0]
+    x = t(g["layer_x"]).permute(0, 2, 1).reshape(B * N, cin).clone().requires_grad_(True)
+    prm = [t(g[k]).clone().requires_grad_(True) for k in ("layer_w", "layer_b", "layer_gamma", "layer_beta")]
+    raw = [t(g["layer_raw"][i]).clone().requires_grad_(True) for i in range(4)]
+    out = TP.conv_bn_lif_train(x, *prm, *raw, steps=4)
+    want = t(g["layer_spikes"]).permute(0, 2, 1).reshape(B * N, cout)
+    assert (out.detach() != want).float().mean() <= 1e-4          # a pre-activation within 1e-6 of the threshold may flip
+    (out * t(g["layer_g"]).permute(0, 2, 1).reshape(B * N, cout)).sum().backward()
+    if torch.equal(out.detach(), want):
+        gx = t(g["layer_gx"]).permute(0, 2, 1).reshape(B * N, cin)
+        np.testing.assert_allclose(x.grad.numpy(), gx.numpy(), rtol=1e-3, atol=2e-5)
+        for p, key in zip(prm, ("layer_gw", "layer_gb", "layer_ggamma", "layer_gbeta")):
+            np.testing.assert_allclose(p.grad.numpy(), g[key].reshape(p.shape), rtol=1e-3, atol=5e-4, err_msg=key)
+        for i, p in enumerate(raw):
+            np.testing.assert_allclose(p.grad.numpy(), g["layer_graw"][i], rtol=1e-3, atol=5e-4)
