@@ -12,6 +12,7 @@
 // per-workgroup partial sums (fixed order inside a thread column, then across the workgroup's row slabs in LDS) go to a
 // workspace, a second kernel adds the partials in ascending workgroup order.
 #include "common.h"
+#include "ops.h"
 #include "../../include/sapcu.h"
 
 namespace sapcu {
@@ -292,6 +293,48 @@ static int wgrad_slabs(int64_t rows) {
     return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
 }
 
+// ---- backward of the per-channel softmax over the k neighbours + weighted aggregation (fn/snn_coder.py:379-389):
+//   forward (fn_softmax_agg_kernel): w = softmax_j(a_j / sqrt(hd)), u_j = v[nbr_j] + pe_j, res = sum_j w_j u_j
+//   backward, g = d res:  d pe_j = w_j g;  d v[nbr_j] += w_j g (scatter-add);  d a_j = w_j g (u_j - res) / sqrt(hd)
+// thread per (point, channel); the softmax is recomputed from `a` with the forward kernel's arithmetic.  grad_v is
+// accumulated with float atomics (a neighbour row receives contributions from several points: summation order, and so
+// the last bits of grad_v, may differ between runs).
+__global__ __launch_bounds__(256) void softmax_agg_bwd_kernel(const float* __restrict__ a, const float* __restrict__ pe,
+                                                              const float* __restrict__ v, int ldv, const int32_t* __restrict__ idx,
+                                                              const float* __restrict__ gres, int64_t pts, int m, int kk, int d,
+                                                              float sqrt_hd, float* __restrict__ ga, float* __restrict__ gpe,
+                                                              float* __restrict__ gv, int ldgv) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pts * d) return;
+    const int c = (int)(t % d);
+    const int64_t pt = t / d;
+    const int64_t patch_i = pt / m;
+    const float* ar = a + pt * kk * d + c;
+    const float* pr = pe + pt * kk * d + c;
+    const int32_t* ir = idx + pt * kk;
+    const float inv_sqrt_hd = __fdiv_rn(1.0f, sqrt_hd);
+    float mx = -__builtin_huge_valf();
+    for (int j = 0; j < kk; ++j) mx = fmaxf(mx, __fmul_rn(ar[(int64_t)j * d], inv_sqrt_hd));
+    float den = 0.f;
+    for (int j = 0; j < kk; ++j) den = __fadd_rn(den, fast_exp(__fsub_rn(__fmul_rn(ar[(int64_t)j * d], inv_sqrt_hd), mx)));
+    const float inv_den = __fdiv_rn(1.0f, den);
+    float res = 0.f;
+    for (int j = 0; j < kk; ++j) {
+        const float wj = __fmul_rn(fast_exp(__fsub_rn(__fmul_rn(ar[(int64_t)j * d], inv_sqrt_hd), mx)), inv_den);
+        res = __fmaf_rn(wj, __fadd_rn(v[(patch_i * m + ir[j]) * ldv + c], pr[(int64_t)j * d]), res);
+    }
+    const float g = gres[t];
+    for (int j = 0; j < kk; ++j) {
+        const float wj = __fmul_rn(fast_exp(__fsub_rn(__fmul_rn(ar[(int64_t)j * d], inv_sqrt_hd), mx)), inv_den);
+        const int64_t nb = patch_i * m + ir[j];
+        const float u = __fadd_rn(v[nb * ldv + c], pr[(int64_t)j * d]);
+        const float wg = wj * g;
+        gpe[(pt * kk + j) * d + c] = wg;
+        atomicAdd(gv + nb * ldgv + c, wg);
+        ga[(pt * kk + j) * d + c] = wg * (u - res) * inv_sqrt_hd;
+    }
+}
+
 }  // namespace sapcu
 
 using namespace sapcu;
@@ -426,6 +469,29 @@ int sapcu_conv1x1_wgrad_f32(const float* grad_y, int ldy, const float* x, int ld
     const int64_t count = (int64_t)n * k;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, (const float*)workspace, slabs,
                        count, grad_w);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+
+int sapcu_softmax_agg_forward(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx, int64_t pts, int m,
+                              int kk, int d, float sqrt_hd, float* res, void* stream) {
+    SAPCU_CHECK_ARG(a && pe && v && idx && res && pts >= 0 && m >= 1 && kk >= 1 && d >= 1 && ldv >= d && sqrt_hd > 0.f,
+                    "softmax_agg_forward: bad argument");
+    return launch_fn_softmax_agg(a, pe, v, ldv, idx, pts, m, kk, d, sqrt_hd, res, 0, (hipStream_t)stream);
+}
+
+int sapcu_softmax_agg_backward(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx,
+                               const float* grad_res, int64_t pts, int m, int kk, int d, float sqrt_hd, float* grad_a,
+                               float* grad_pe, float* grad_v, int ldgv, void* stream) {
+    SAPCU_CHECK_ARG(a && pe && v && idx && grad_res && grad_a && grad_pe && grad_v && pts >= 0 && m >= 1 && kk >= 1 && d >= 1 &&
+                        ldv >= d && ldgv >= d && sqrt_hd > 0.f, "softmax_agg_backward: bad argument");
+    if (pts == 0) return SAPCU_OK;
+    SAPCU_CHECK_ARG(pts % m == 0, "softmax_agg_backward: points must come in whole patches of m");
+    hipStream_t st = (hipStream_t)stream;
+    SAPCU_CHECK_HIP(hipMemset2DAsync(grad_v, (size_t)ldgv * 4, 0, (size_t)d * 4, (size_t)pts, st));
+    hipLaunchKernelGGL(softmax_agg_bwd_kernel, dim3((unsigned)((pts * d + 255) / 256)), dim3(256), 0, st, a, pe, v, ldv, idx, grad_res,
+                       pts, m, kk, d, sqrt_hd, grad_a, grad_pe, grad_v, ldgv);
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
 }

@@ -136,3 +136,39 @@ def conv_bn_lif_train(x, weight, bias, gamma, beta, membrane_decay, threshold_ad
     w2 = weight.reshape(weight.shape[0], -1)                      # Conv1d/Conv2d 1x1 weights [c_out, c_in, 1(,1)]
     return _ConvBnLifTrain.apply(x, w2, bias, gamma, beta, membrane_decay, threshold_adapt, refractory_decay, threshold_base,
                                  steps, eps)
+
+
+class _SoftmaxAgg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, pe, v, idx, m, sqrt_hd):
+        lib = _lib.load()
+        pts, d = v.shape
+        kk = a.shape[0] // pts
+        a, pe, v = a.contiguous(), pe.contiguous(), v.contiguous()
+        idx = idx.contiguous().to(torch.int32)
+        res = torch.empty((pts, d), dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            _lib.check(lib.sapcu_softmax_agg_forward(_lib.ptr(a), _lib.ptr(pe), _lib.ptr(v), d, _lib.ptr(idx), pts, int(m), kk, d,
+                                                     float(sqrt_hd), _lib.ptr(res), _lib.current_stream()))
+        ctx.save_for_backward(a, pe, v, idx)
+        ctx.m, ctx.sqrt_hd = int(m), float(sqrt_hd)
+        return res
+
+    @staticmethod
+    def backward(ctx, grad_res):
+        lib = _lib.load()
+        a, pe, v, idx = ctx.saved_tensors
+        pts, d = v.shape
+        kk = a.shape[0] // pts
+        ga, gpe, gv = torch.empty_like(a), torch.empty_like(pe), torch.empty_like(v)
+        with torch.cuda.device(a.device):
+            _lib.check(lib.sapcu_softmax_agg_backward(_lib.ptr(a), _lib.ptr(pe), _lib.ptr(v), d, _lib.ptr(idx),
+                                                      _lib.ptr(grad_res.contiguous()), pts, ctx.m, kk, d, ctx.sqrt_hd, _lib.ptr(ga),
+                                                      _lib.ptr(gpe), _lib.ptr(gv), d, _lib.current_stream()))
+        return ga, gpe, gv, None, None, None
+
+
+def softmax_agg(a, pe, v, idx, m, sqrt_hd):
+    """fn/snn_coder.py:379-389 on edge rows: a, pe [P*k, d]; v [P, d]; idx [P*k] in-patch neighbour indices (m points per
+    patch) -> res [P, d] = sum_j softmax_j(a / sqrt_hd) * (v[nbr_j] + pe_j).  Differentiable w.r.t. a, pe and v."""
+    return _SoftmaxAgg.apply(a, pe, v, idx, m, sqrt_hd)

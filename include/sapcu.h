@@ -133,6 +133,16 @@ int sapcu_bn_train_backward(const float* y, const float* grad_z, int64_t rows, i
 int sapcu_conv1x1_wgrad_f32(const float* grad_y, int ldy, const float* x, int ldx, int64_t rows, int n, int k,
                             float* grad_w, float* grad_bias, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Per-channel softmax over the k neighbours + weighted aggregation (fn/snn_coder.py:379-389), as its own differentiable op:
+ *   res[pt, c] = sum_j softmax_j(a[pt, j, c] / sqrt_hd) * (v[nbr(pt, j), c] + pe[pt, j, c])
+ * a, pe, grad_a, grad_pe: [pts*kk, d] (edge rows); v, grad_v: [pts, ld] rows; idx [pts*kk] = in-patch neighbour indices,
+ * m points per patch (pts % m == 0).  The backward zeroes grad_v[., 0:d] and accumulates with float atomics. */
+int sapcu_softmax_agg_forward(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx, int64_t pts,
+                              int m, int kk, int d, float sqrt_hd, float* res, void* stream);
+int sapcu_softmax_agg_backward(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx,
+                               const float* grad_res, int64_t pts, int m, int kk, int d, float sqrt_hd,
+                               float* grad_a, float* grad_pe, float* grad_v, int ldgv, void* stream);
+
 /* In-patch kNN `topk(-|xi|^2 + 2 xi.xj - |xj|^2)` — fn/snn_coder.py:31-39, fd/snn_coder.py:25-32.
  * feat [b, m, ld] f32 (point-major, first c columns used), 1 <= m <= 128, k <= m.
  * idx_out [b,m,k] int32, descending score, equal scores by ascending index. */

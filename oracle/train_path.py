@@ -47,3 +47,14 @@ def conv_bn_lif_train(x, weight, bias, gamma, beta, membrane_decay, threshold_ad
     var = y.var(0, unbiased=False)
     z = (y - mean) / torch.sqrt(var + eps) * gamma + beta
     return lif_selfloop_train(z, membrane_decay, threshold_adapt, refractory_decay, threshold_base, steps)
+
+
+def softmax_agg(a, pe, v, idx, m, sqrt_hd):
+    """fn/snn_coder.py:379-389 on edge rows (the stage oracle/snn_path.py:158-159 evaluates channels-first): a, pe
+    [P*k, d], v [P, d], idx [P*k] in-patch neighbour indices, m points per patch -> [P, d]."""
+    pts, d = v.shape
+    kk = a.shape[0] // pts
+    nbr = (torch.arange(pts).div(m, rounding_mode="floor") * m).repeat_interleave(kk) + idx.long()
+    w = torch.softmax(a.view(pts, kk, d) / sqrt_hd, dim=1)
+    u = v[nbr].view(pts, kk, d) + pe.view(pts, kk, d)
+    return (w * u).sum(1)

@@ -813,3 +813,27 @@ def test_training_layer_conv_bn_neuron_forward_backward():
             assert float(dd.grad.abs().max()) <= 1e-2
             continue
         assert _rel_l2(dd.grad.cpu(), hd.grad) <= 5e-3 + 50 * flips, (nme, _rel_l2(dd.grad.cpu(), hd.grad))
+
+
+def test_training_softmax_aggregate_forward_backward():
+    """fn/snn_coder.py:379-389 as a differentiable op (forward = the inference kernel, backward = softmax_agg_bwd_kernel with a
+    scatter-add into grad_v) against torch autograd on the oracle, for the three block shapes' k and head sizes."""
+    from oracle import train_path as TP
+    from sapcu_amd import train
+    rng = np.random.default_rng(21)
+    for b, m, kk, d, hd in ((3, 48, 24, 128, 16), (2, 48, 18, 256, 32), (2, 20, 12, 512, 64), (1, 5, 5, 64, 8)):
+        pts = b * m
+        ah = rng.normal(0, 2.0, (pts * kk, d)).astype(np.float32)
+        ph = rng.random((pts * kk, d)).astype(np.float32)
+        vh = rng.random((pts, d)).astype(np.float32)
+        ih = rng.integers(0, m, size=pts * kk).astype(np.int32)
+        gh = rng.normal(0, 1, (pts, d)).astype(np.float32)
+        host = [torch.from_numpy(x).clone().requires_grad_(True) for x in (ah, ph, vh)]
+        ro = TP.softmax_agg(*host, torch.from_numpy(ih), m, float(np.sqrt(hd)))
+        (ro * torch.from_numpy(gh)).sum().backward()
+        devt = [_dev(x).clone().requires_grad_(True) for x in (ah, ph, vh)]
+        rd = train.softmax_agg(*devt, _dev(ih), m, float(np.sqrt(hd)))
+        (rd * _dev(gh)).sum().backward()
+        assert (rd.detach().cpu() - ro.detach()).abs().max() <= 2e-6
+        for name, hh, dd in zip(("a", "pe", "v"), host, devt):
+            assert (dd.grad.cpu() - hh.grad).abs().max() <= 1e-5 * max(1.0, float(hh.grad.abs().max())), (name, kk, d)
