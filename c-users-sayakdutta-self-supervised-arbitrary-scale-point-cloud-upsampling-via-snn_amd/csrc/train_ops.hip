@@ -335,6 +335,25 @@ __global__ __launch_bounds__(256) void softmax_agg_bwd_kernel(const float* __res
     }
 }
 
+// ---- row gather (index_points, fn/snn_coder.py:19-29, on flattened rows) and its backward (scatter-add)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int lds_, const int64_t* __restrict__ index,
+                                                          int64_t rows, int d, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * d) return;
+    const int64_t r = t / d;
+    const int c = (int)(t - r * d);
+    out[t] = src[index[r] * lds_ + c];
+}
+
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ gout, const int64_t* __restrict__ index,
+                                                               int64_t rows, int d, float* __restrict__ gsrc, int ldg) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * d) return;
+    const int64_t r = t / d;
+    const int c = (int)(t - r * d);
+    atomicAdd(gsrc + index[r] * ldg + c, gout[t]);
+}
+
 }  // namespace sapcu
 
 using namespace sapcu;
@@ -492,6 +511,28 @@ int sapcu_softmax_agg_backward(const float* a, const float* pe, const float* v, 
     SAPCU_CHECK_HIP(hipMemset2DAsync(grad_v, (size_t)ldgv * 4, 0, (size_t)d * 4, (size_t)pts, st));
     hipLaunchKernelGGL(softmax_agg_bwd_kernel, dim3((unsigned)((pts * d + 255) / 256)), dim3(256), 0, st, a, pe, v, ldv, idx, grad_res,
                        pts, m, kk, d, sqrt_hd, grad_a, grad_pe, grad_v, ldgv);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+
+int sapcu_gather_rows(const float* src, int ld_src, const int64_t* index, int64_t rows, int d, float* out, void* stream) {
+    SAPCU_CHECK_ARG(src && index && out && rows >= 0 && d >= 1 && ld_src >= d, "gather_rows: bad argument");
+    if (rows == 0) return SAPCU_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((rows * d + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src, index,
+                       rows, d, out);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+int sapcu_scatter_add_rows(const float* grad_out, const int64_t* index, int64_t rows, int d, float* grad_src, int ld_grad,
+                           int64_t src_rows, void* stream) {
+    SAPCU_CHECK_ARG(grad_out && index && grad_src && rows >= 0 && d >= 1 && ld_grad >= d && src_rows >= 0, "scatter_add_rows: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (src_rows > 0) SAPCU_CHECK_HIP(hipMemset2DAsync(grad_src, (size_t)ld_grad * 4, 0, (size_t)d * 4, (size_t)src_rows, st));
+    if (rows == 0) return SAPCU_OK;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((rows * d + 255) / 256)), dim3(256), 0, st, grad_out, index, rows, d,
+                       grad_src, ld_grad);
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
 }

@@ -84,19 +84,21 @@ class _ConvBnLifTrain(torch.autograd.Function):
         y = torch.empty((rows, cout), dtype=torch.float32, device=dev)
         z = torch.empty_like(y)
         mean, var, invstd = (torch.empty((cout,), dtype=torch.float32, device=dev) for _ in range(3))
-        spikes = torch.empty_like(y)
         ws, nbytes = _ws(lib, rows, cout, 0, dev)
         with torch.cuda.device(dev):
             _gemm(lib, x, w, bias.detach().contiguous(), y)
             _lib.check(lib.sapcu_bn_train_forward(_lib.ptr(y), rows, cout, _lib.ptr(gamma.detach().contiguous()),
                                                   _lib.ptr(beta.detach().contiguous()), float(eps), _lib.ptr(z), _lib.ptr(mean),
                                                   _lib.ptr(var), _lib.ptr(invstd), _lib.ptr(ws), nbytes, _lib.current_stream()))
-            _lib.check(lib.sapcu_lif_train_forward(_lib.ptr(z), rows, cout, int(steps), *[_lib.ptr(p) for p in prm],
-                                                   _lib.ptr(spikes), _lib.current_stream()))
+            out = z
+            if int(steps) > 0:
+                out = torch.empty_like(y)
+                _lib.check(lib.sapcu_lif_train_forward(_lib.ptr(z), rows, cout, int(steps), *[_lib.ptr(p) for p in prm],
+                                                       _lib.ptr(out), _lib.current_stream()))
         ctx.save_for_backward(x, w, gamma.detach().contiguous(), y, z, mean, invstd, *prm)
         ctx.steps = int(steps)
         ctx.batch_stats = (mean, var)
-        return spikes
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -115,9 +117,13 @@ class _ConvBnLifTrain(torch.autograd.Function):
         lws = torch.empty((lws_bytes,), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             st = _lib.current_stream()
-            _lib.check(lib.sapcu_lif_train_backward(_lib.ptr(z), _lib.ptr(g), rows, cout, ctx.steps, _lib.ptr(md), _lib.ptr(ta),
-                                                    _lib.ptr(rd), _lib.ptr(tb), _lib.ptr(dz), *[_lib.ptr(t) for t in gp],
-                                                    _lib.ptr(lws), lws_bytes, st))
+            if ctx.steps > 0:
+                _lib.check(lib.sapcu_lif_train_backward(_lib.ptr(z), _lib.ptr(g), rows, cout, ctx.steps, _lib.ptr(md), _lib.ptr(ta),
+                                                        _lib.ptr(rd), _lib.ptr(tb), _lib.ptr(dz), *[_lib.ptr(t) for t in gp],
+                                                        _lib.ptr(lws), lws_bytes, st))
+            else:
+                dz = g
+                gp = [torch.zeros_like(md) for _ in range(4)]
             _lib.check(lib.sapcu_bn_train_backward(_lib.ptr(y), _lib.ptr(dz), rows, cout, _lib.ptr(gamma), _lib.ptr(mean),
                                                    _lib.ptr(invstd), _lib.ptr(dy), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws),
                                                    nbytes, st))
@@ -172,3 +178,91 @@ def softmax_agg(a, pe, v, idx, m, sqrt_hd):
     """fn/snn_coder.py:379-389 on edge rows: a, pe [P*k, d]; v [P, d]; idx [P*k] in-patch neighbour indices (m points per
     patch) -> res [P, d] = sum_j softmax_j(a / sqrt_hd) * (v[nbr_j] + pe_j).  Differentiable w.r.t. a, pe and v."""
     return _SoftmaxAgg.apply(a, pe, v, idx, m, sqrt_hd)
+
+
+def conv_bn_train(x, weight, bias, gamma, beta, eps=1e-5):
+    """1x1 convolution + BatchNorm in training mode, no neuron (fn's fc_gamma2 / out_proj / fc2): x [rows, c_in] -> [rows, c_out]."""
+    w2 = weight.reshape(weight.shape[0], -1)
+    dummy = torch.zeros((w2.shape[0],), dtype=torch.float32, device=x.device)
+    return _ConvBnLifTrain.apply(x, w2, bias, gamma, beta, dummy, dummy, dummy, dummy, 0, eps)
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, index):
+        lib = _lib.load()
+        src = src.contiguous()
+        index = index.contiguous().to(torch.int64)
+        rows, d = index.shape[0], src.shape[1]
+        out = torch.empty((rows, d), dtype=torch.float32, device=src.device)
+        with torch.cuda.device(src.device):
+            _lib.check(lib.sapcu_gather_rows(_lib.ptr(src), d, _lib.ptr(index), rows, d, _lib.ptr(out), _lib.current_stream()))
+        ctx.save_for_backward(index)
+        ctx.src_rows = src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        (index,) = ctx.saved_tensors
+        g = grad_out.contiguous()
+        rows, d = g.shape
+        gsrc = torch.empty((ctx.src_rows, d), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(lib.sapcu_scatter_add_rows(_lib.ptr(g), _lib.ptr(index), rows, d, _lib.ptr(gsrc), d, ctx.src_rows,
+                                                  _lib.current_stream()))
+        return gsrc, None
+
+
+def gather_rows(src, index):
+    """out[r] = src[index[r]] on [rows, d] tensors (index_points, fn/snn_coder.py:19-29); backward = scatter-add."""
+    return _GatherRows.apply(src, index)
+
+
+def _pad_channels(t, mult=32):
+    """zero-pad the channel (last) axis to a multiple of 32: the GEMM kernels step the reduction axis by 32"""
+    c = t.shape[-1]
+    pad = (-c) % mult
+    return torch.nn.functional.pad(t, (0, pad)) if pad else t
+
+
+def transformer_block_train(p, xyz, features, knn_idx, time_steps=4, num_heads=8, eps=1e-5):
+    """One ``MultiHeadSNNTransformerBlock`` in TRAINING mode (fn/snn_coder.py:294-396, dropout 0) on channels-last rows.
+
+    p: dict of the block's parameters under the reference's names (``fc1.0.weight``, ``fc1.1.weight`` (BN gamma),
+    ``snn1.membrane_decay`` ...), xyz [B, N, 3], features [B, N, d_points], knn_idx [B, N, k] in-patch neighbours ->
+    [B, N, d_points].  Every 1x1 convolution + BatchNorm (+ neuron loop), the neighbour gathers and the softmax-aggregate
+    are the HIP ops of this module; the adds/subtractions between them are torch glue."""
+    B, N, _ = xyz.shape
+    k = knn_idx.shape[-1]
+    dev = xyz.device
+    P = B * N
+    base = (torch.arange(B, device=dev) * N).view(B, 1, 1)
+    nbr = (knn_idx.to(torch.int64) + base).reshape(P * k)                 # global row of each edge's neighbour
+    ptr = torch.arange(P, device=dev).repeat_interleave(k)                # ... and of its centre point
+    feat = features.reshape(P, -1)
+    xyzr = xyz.reshape(P, 3)
+
+    def layer(x, conv, bn, snn=None):
+        w = _pad_channels(p[conv + ".weight"].reshape(p[conv + ".weight"].shape[0], -1))
+        args = (_pad_channels(x), w, p[conv + ".bias"], p[bn + ".weight"], p[bn + ".bias"])
+        if snn is None:
+            return conv_bn_train(*args, eps=eps)
+        return conv_bn_lif_train(*args, p[snn + ".membrane_decay"], p[snn + ".threshold_adapt"], p[snn + ".refractory_decay"],
+                                 p[snn + ".threshold_base"], steps=time_steps, eps=eps)
+
+    x = layer(feat, "fc1.0", "fc1.1", "snn1")
+    q = layer(x, "w_qs.0", "w_qs.1", "snn_q")
+    kf = layer(x, "w_ks.0", "w_ks.1", "snn_k")
+    v = layer(x, "w_vs.0", "w_vs.1", "snn_v")
+    pos_diff = gather_rows(xyzr, ptr) - gather_rows(xyzr, nbr)            # [P*k, 3]
+    pe = layer(pos_diff, "fc_delta.0", "fc_delta.1", "snn_delta")
+    pe = layer(pe, "fc_delta2.0", "fc_delta2.1", "snn_delta2")
+    attn_in = gather_rows(q, ptr) - gather_rows(kf, nbr) + pe
+    a = layer(attn_in, "fc_gamma.0", "fc_gamma.1", "snn_gamma")
+    a = layer(a, "fc_gamma2.0", "fc_gamma2.1")
+    d_model = a.shape[1]
+    res = softmax_agg(a, pe, v, knn_idx.reshape(P * k), N, float((d_model // num_heads) ** 0.5))
+    res = layer(res, "out_proj.0", "out_proj.1")
+    res = layer(res, "fc2.0", "fc2.1") + feat
+    return res.view(B, N, -1)

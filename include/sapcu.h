@@ -143,6 +143,12 @@ int sapcu_softmax_agg_backward(const float* a, const float* pe, const float* v, 
                                const float* grad_res, int64_t pts, int m, int kk, int d, float sqrt_hd,
                                float* grad_a, float* grad_pe, float* grad_v, int ldgv, void* stream);
 
+/* Row gather out[r,:] = src[index[r],:] (index_points on flattened rows, fn/snn_coder.py:19-29) and its backward: zero
+ * grad_src[0:src_rows, 0:d], then grad_src[index[r],:] += grad_out[r,:] (float atomics). */
+int sapcu_gather_rows(const float* src, int ld_src, const int64_t* index, int64_t rows, int d, float* out, void* stream);
+int sapcu_scatter_add_rows(const float* grad_out, const int64_t* index, int64_t rows, int d, float* grad_src, int ld_grad,
+                           int64_t src_rows, void* stream);
+
 /* In-patch kNN `topk(-|xi|^2 + 2 xi.xj - |xj|^2)` — fn/snn_coder.py:31-39, fd/snn_coder.py:25-32.
  * feat [b, m, ld] f32 (point-major, first c columns used), 1 <= m <= 128, k <= m.
  * idx_out [b,m,k] int32, descending score, equal scores by ascending index. */

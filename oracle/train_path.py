@@ -58,3 +58,37 @@ def softmax_agg(a, pe, v, idx, m, sqrt_hd):
     w = torch.softmax(a.view(pts, kk, d) / sqrt_hd, dim=1)
     u = v[nbr].view(pts, kk, d) + pe.view(pts, kk, d)
     return (w * u).sum(1)
+
+
+def conv_bn_train(x, weight, bias, gamma, beta, eps=1e-5):
+    y = x @ weight.reshape(weight.shape[0], -1).t() + bias
+    return (y - y.mean(0)) / torch.sqrt(y.var(0, unbiased=False) + eps) * gamma + beta
+
+
+def transformer_block_train(p, xyz, features, knn_idx, time_steps=4, num_heads=8, eps=1e-5):
+    """MultiHeadSNNTransformerBlock.forward in training mode (fn/snn_coder.py:294-396, dropout 0), restated on
+    channels-last rows with plain torch ops; p = the block's parameters under the reference's names."""
+    B, N, _ = xyz.shape
+    k = knn_idx.shape[-1]
+    P = B * N
+    nbr = (knn_idx.long() + (torch.arange(B) * N).view(B, 1, 1)).reshape(P * k)
+    ptr = torch.arange(P).repeat_interleave(k)
+    feat, xyzr = features.reshape(P, -1), xyz.reshape(P, 3)
+
+    def layer(x, conv, bn, snn=None):
+        z = conv_bn_train(x, p[conv + ".weight"], p[conv + ".bias"], p[bn + ".weight"], p[bn + ".bias"], eps)
+        if snn is None:
+            return z
+        return lif_selfloop_train(z, p[snn + ".membrane_decay"], p[snn + ".threshold_adapt"], p[snn + ".refractory_decay"],
+                                  p[snn + ".threshold_base"], time_steps)
+
+    x = layer(feat, "fc1.0", "fc1.1", "snn1")
+    q, kf, v = (layer(x, "w_%ss.0" % c, "w_%ss.1" % c, "snn_" + c) for c in "qkv")
+    pe = layer(xyzr[ptr] - xyzr[nbr], "fc_delta.0", "fc_delta.1", "snn_delta")
+    pe = layer(pe, "fc_delta2.0", "fc_delta2.1", "snn_delta2")
+    a = layer(q[ptr] - kf[nbr] + pe, "fc_gamma.0", "fc_gamma.1", "snn_gamma")
+    a = layer(a, "fc_gamma2.0", "fc_gamma2.1")
+    d_model = a.shape[1]
+    res = softmax_agg(a, pe, v, knn_idx.reshape(P * k), N, float((d_model // num_heads) ** 0.5))
+    res = layer(res, "out_proj.0", "out_proj.1")
+    return (layer(res, "fc2.0", "fc2.1") + feat).view(B, N, -1)

@@ -236,6 +236,45 @@ def neuron_train_fixture():
                 "layer_running_mean": npy(bn.running_mean), "layer_running_var": npy(bn.running_var)})
     print("layer", tuple(x.shape), "->", tuple(v.shape), "spike rate %.3f" % float(v.mean()))
     save("neuron_train.npz", **out)
+    block_train_fixture()
+
+
+def block_train_fixture():
+    """One MultiHeadSNNTransformerBlock of the reference IN TRAINING MODE (fn/snn_coder.py:294-396; dropout 0 — the
+    attention dropout is random): forward and the autograd gradients of sum(out * g) w.r.t. the input features and every
+    parameter.  BatchNorm affine and neuron parameters are randomised so that the hard spikes are not degenerate."""
+    rng = np.random.default_rng(23)
+    torch.manual_seed(23)
+    B, N, k, dp, dm, H = 2, 24, 8, 64, 128, 8
+    blk = ref_fn.MultiHeadSNNTransformerBlock(dp, dm, k, 4, num_heads=H, dropout=0.0)
+    with torch.no_grad():
+        for name, prm in blk.named_parameters():
+            if name.endswith(".1.weight"):                                  # BatchNorm gamma
+                prm.copy_(torch.tensor(rng.uniform(0.6, 1.4, prm.shape).astype(np.float32)))
+            elif name.endswith(".1.bias"):
+                prm.copy_(torch.tensor(rng.normal(0.5, 0.4, prm.shape).astype(np.float32)))
+            elif name.endswith("membrane_decay"):
+                prm.copy_(torch.tensor(rng.uniform(0.3, 0.95, prm.shape).astype(np.float32)))
+            elif name.endswith("threshold_adapt"):
+                prm.copy_(torch.tensor(rng.uniform(0.005, 0.08, prm.shape).astype(np.float32)))
+            elif name.endswith("refractory_decay"):
+                prm.copy_(torch.tensor(rng.uniform(0.2, 0.9, prm.shape).astype(np.float32)))
+            elif name.endswith("threshold_base"):
+                prm.copy_(torch.tensor(rng.normal(0.6, 0.3, prm.shape).astype(np.float32)))
+    blk.train()
+    xyz = torch.tensor((rng.normal(0, 0.05, (B, N, 3))).astype(np.float32))
+    feats = torch.tensor(rng.normal(0, 1, (B, N, dp)).astype(np.float32), requires_grad=True)
+    g = torch.tensor(rng.normal(0, 1, (B, N, dp)).astype(np.float32))
+    res, _ = blk(xyz, feats)
+    (res * g).sum().backward()
+    knn_idx = blk.knn_cache.get_knn(xyz, k, "block_%d" % id(blk))
+    out = {"xyz": npy(xyz), "features": npy(feats), "g": npy(g), "out": npy(res), "g_features": npy(feats.grad),
+           "knn_idx": npy(knn_idx).astype(np.int32), "names": np.array([n for n, _ in blk.named_parameters()])}
+    for n, prm in blk.named_parameters():
+        out["p:" + n] = npy(prm)
+        out["g:" + n] = npy(prm.grad) if prm.grad is not None else np.zeros(tuple(prm.shape), np.float32)
+    print("block", tuple(res.shape), "|out| %.3f" % float(res.abs().mean()), "|g_feat| %.3g" % float(feats.grad.abs().mean()))
+    save("block_train.npz", **out)
 
 
 def main():

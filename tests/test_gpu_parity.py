@@ -837,3 +837,23 @@ def test_training_softmax_aggregate_forward_backward():
         assert (rd.detach().cpu() - ro.detach()).abs().max() <= 2e-6
         for name, hh, dd in zip(("a", "pe", "v"), host, devt):
             assert (dd.grad.cpu() - hh.grad).abs().max() <= 1e-5 * max(1.0, float(hh.grad.abs().max())), (name, kk, d)
+
+
+def test_training_transformer_block_forward_backward_against_reference_run():
+    """Row f-4: one whole MultiHeadSNNTransformerBlock in training mode composed from the HIP training ops
+    (sapcu_amd.train.transformer_block_train) against the reference block's own forward and autograd gradients."""
+    from sapcu_amd import train
+    g = golden("block_train.npz")
+    p = {str(n): _dev(g["p:" + str(n)]).clone().requires_grad_(True) for n in g["names"]}
+    feats = _dev(g["features"]).clone().requires_grad_(True)
+    out = train.transformer_block_train(p, _dev(g["xyz"]), feats, _dev(g["knn_idx"]))
+    assert (out.detach().cpu() - torch.from_numpy(g["out"])).abs().max() <= 2e-4
+    (out * _dev(g["g"])).sum().backward()
+    ref = torch.from_numpy(g["g_features"])
+    assert _rel_l2(feats.grad.cpu(), ref) <= 2e-3
+    floor = 5e-5 * max(float(np.abs(g["g:" + str(n)]).max()) for n in g["names"])
+    for n in g["names"]:
+        n = str(n)
+        ref = torch.from_numpy(g["g:" + n])
+        got = p[n].grad.cpu() if p[n].grad is not None else torch.zeros_like(ref)
+        assert float((got - ref).abs().max()) <= 5e-3 * float(ref.abs().max()) + floor, (n, float((got - ref).abs().max()))

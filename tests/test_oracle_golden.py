@@ -238,3 +238,36 @@ def test_training_layer_conv_bn_neuron_against_reference_run():
             np.testing.assert_allclose(p.grad.numpy(), g[key].reshape(p.shape), rtol=1e-3, atol=5e-4, err_msg=key)
         for i, p in enumerate(raw):
             np.testing.assert_allclose(p.grad.numpy(), g["layer_graw"][i], rtol=1e-3, atol=5e-4)
+
+
+def _block_params(g, device=None):
+    p = {}
+    for n in g["names"]:
+        tt = t(g["p:" + str(n)]).clone()
+        if device is not None:
+            tt = tt.to(device)
+        p[str(n)] = tt.requires_grad_(True)
+    return p
+
+
+def test_training_transformer_block_against_reference_run():
+    """Row f-4: one whole MultiHeadSNNTransformerBlock in training mode — the oracle's rows-layout restatement against the
+    reference block's forward and autograd gradients (input features + all 60 parameter tensors)."""
+    from oracle import train_path as TP
+    g = golden("block_train.npz")
+    p = _block_params(g)
+    feats = t(g["features"]).clone().requires_grad_(True)
+    out = TP.transformer_block_train(p, t(g["xyz"]), feats, t(g["knn_idx"]))
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], rtol=0, atol=2e-4)
+    (out * t(g["g"])).sum().backward()
+    ref = t(g["g_features"])
+    assert float((feats.grad - ref).norm() / ref.norm()) <= 1e-3
+    # the gradients reach 1e4 (surrogate slope 10 through seven neuron layers); convolution biases in front of a BatchNorm
+    # have a mathematically zero gradient that comes out as cancellation noise: noise floor relative to the largest gradient
+    floor = 2e-5 * max(float(np.abs(g["g:" + str(n)]).max()) for n in g["names"])
+    for n in g["names"]:
+        n = str(n)
+        ref = t(g["g:" + n])
+        got = p[n].grad if p[n].grad is not None else torch.zeros_like(ref)
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 2e-3 * scale + floor, (n, float((got - ref).abs().max()), scale, floor)
