@@ -46,6 +46,8 @@ _SIGNATURES = {
                                           c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "sapcu_gather_rows": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "sapcu_scatter_add_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "sapcu_group_max_forward": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sapcu_group_max_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "sapcu_neuron_selfloop": (c_int, [c_void_p, c_int64, c_int, c_int] + [c_void_p] * 6 + [c_void_p] * 4 + [c_void_p]),
     "sapcu_patch_knn": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sapcu_model_create": (c_int, [c_int, POINTER(c_int32), c_int, c_void_p, c_int64, POINTER(c_int64), c_int,

@@ -354,6 +354,37 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
     atomicAdd(gsrc + index[r] * ldg + c, gout[t]);
 }
 
+// ---- max over the points of a patch (adaptive_max_pool1d(., 1), fn/snn_coder.py:472) with the arg-max kept for the backward;
+// ties go to the FIRST point (what torch's pooling does) — with hard 0/1 spikes ties are the rule, so the tie rule decides
+// where the gradient goes.
+__global__ __launch_bounds__(256) void group_max_fwd_kernel(const float* __restrict__ x, int64_t groups, int m, int c,
+                                                            float* __restrict__ out, int32_t* __restrict__ arg) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= groups * c) return;
+    const int cc = (int)(t % c);
+    const int64_t g = t / c;
+    const float* p = x + g * m * c + cc;
+    float mx = p[0];
+    int am = 0;
+    for (int i = 1; i < m; ++i) {
+        const float v = p[(int64_t)i * c];
+        if (v > mx) { mx = v; am = i; }
+    }
+    out[t] = mx;
+    arg[t] = am;
+}
+
+__global__ __launch_bounds__(256) void group_max_bwd_kernel(const float* __restrict__ gout, const int32_t* __restrict__ arg,
+                                                            int64_t groups, int m, int c, float* __restrict__ gx) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // over [groups*m, c]
+    if (t >= groups * m * c) return;
+    const int cc = (int)(t % c);
+    const int64_t row = t / c;
+    const int64_t g = row / m;
+    const int i = (int)(row - g * m);
+    gx[t] = arg[g * c + cc] == i ? gout[g * c + cc] : 0.f;
+}
+
 }  // namespace sapcu
 
 using namespace sapcu;
@@ -533,6 +564,25 @@ int sapcu_scatter_add_rows(const float* grad_out, const int64_t* index, int64_t 
     if (rows == 0) return SAPCU_OK;
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((rows * d + 255) / 256)), dim3(256), 0, st, grad_out, index, rows, d,
                        grad_src, ld_grad);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+
+int sapcu_group_max_forward(const float* x, int64_t groups, int m, int c, float* out, int32_t* argmax_out, void* stream) {
+    SAPCU_CHECK_ARG(x && out && argmax_out && groups >= 0 && m >= 1 && c >= 1, "group_max_forward: bad argument");
+    if (groups == 0) return SAPCU_OK;
+    hipLaunchKernelGGL(group_max_fwd_kernel, dim3((unsigned)((groups * c + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, groups, m, c,
+                       out, argmax_out);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+int sapcu_group_max_backward(const float* grad_out, const int32_t* argmax, int64_t groups, int m, int c, float* grad_x, void* stream) {
+    SAPCU_CHECK_ARG(grad_out && argmax && grad_x && groups >= 0 && m >= 1 && c >= 1, "group_max_backward: bad argument");
+    if (groups == 0) return SAPCU_OK;
+    hipLaunchKernelGGL(group_max_bwd_kernel, dim3((unsigned)((groups * m * c + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad_out,
+                       argmax, groups, m, c, grad_x);
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
 }

@@ -76,6 +76,36 @@ def conditioned_state_dict(template, seed=0, w_gain=1.0, bn_stats=None, bn_gain=
     return out
 
 
+def training_state_dict(template, seed=0):
+    """Parameters for TRAINING-mode cases (row f-4): conditioned_state_dict with the BatchNorm affine and the neuron
+    parameters redrawn so that the HARD spikes of train() mode are not degenerate under batch statistics (BatchNorm output
+    ~N(beta, gamma^2); thresholds ~N(0, 0.4^2): with the closed refractory gate a T-step self-loop neuron only keeps firing when
+    its threshold is negative, so all-positive thresholds leave the net's output independent of its input)."""
+    out = conditioned_state_dict(template, seed, bn_gain=1.0)
+    for name, v in out.items():
+        r = _rng(seed + 1000, name)
+        leaf = name.rsplit(".", 1)[-1]
+        parent = name.rsplit(".", 1)[0] if "." in name else ""
+        is_bn = (parent + ".running_mean") in out
+        shape = tuple(v.shape)
+        if is_bn and leaf == "weight":
+            a = r.uniform(0.6, 1.4, shape)
+        elif is_bn and leaf == "bias":
+            a = r.normal(0.5, 0.4, shape)
+        elif leaf == "membrane_decay":
+            a = r.uniform(0.3, 0.95, shape)
+        elif leaf == "threshold_adapt":
+            a = r.uniform(0.005, 0.08, shape)
+        elif leaf == "refractory_decay":
+            a = r.uniform(0.2, 0.9, shape)
+        elif leaf == "threshold_base":
+            a = r.normal(0.0, 0.4, shape)
+        else:
+            continue
+        out[name] = torch.from_numpy(np.asarray(a, dtype=np.float32).reshape(shape))
+    return out
+
+
 def sphere_cloud(n=5000, seed=0):
     """unit-normal directions * 0.5, rounded to 6 decimals, float64."""
     rng = np.random.default_rng(seed)

@@ -266,3 +266,123 @@ def transformer_block_train(p, xyz, features, knn_idx, time_steps=4, num_heads=8
     res = layer(res, "out_proj.0", "out_proj.1")
     res = layer(res, "fc2.0", "fc2.1") + feat
     return res.view(B, N, -1)
+
+
+class _LinearTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        x, w = x.contiguous(), weight.detach().contiguous()
+        out = torch.empty((x.shape[0], w.shape[0]), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _gemm(lib, x, w, bias.detach().contiguous(), out)
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        rows, cin = x.shape
+        cout = w.shape[0]
+        g = grad_out.contiguous()
+        dw, db, dx = torch.empty_like(w), torch.empty((cout,), dtype=torch.float32, device=x.device), torch.empty_like(x)
+        ws, nbytes = _ws(lib, rows, cout, cin, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.sapcu_conv1x1_wgrad_f32(_lib.ptr(g), cout, _lib.ptr(x), cin, rows, cout, cin, _lib.ptr(dw), _lib.ptr(db),
+                                                   _lib.ptr(ws), nbytes, _lib.current_stream()))
+            _gemm(lib, g, w.t().contiguous(), None, dx)
+        return dx, dw, db
+
+
+def linear_train(x, weight, bias):
+    """y = x . W^T + b with HIP forward / weight-gradient / data-gradient kernels.  Both channel counts are zero-padded to
+    multiples of 32 here (the exact-f32 GEMM steps its reduction axis by 32: c_in forward, c_out in the data gradient)."""
+    cout = weight.shape[0]
+    w = _pad_channels(weight.reshape(cout, -1))
+    pad_o = (-cout) % 32
+    if pad_o:
+        w = torch.nn.functional.pad(w, (0, 0, 0, pad_o))
+        bias = torch.nn.functional.pad(bias, (0, pad_o))
+    return _LinearTrain.apply(_pad_channels(x), w, bias)[:, :cout]
+
+
+class _GroupMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, m):
+        lib = _lib.load()
+        x = x.contiguous()
+        c = x.shape[1]
+        groups = x.shape[0] // m
+        out = torch.empty((groups, c), dtype=torch.float32, device=x.device)
+        arg = torch.empty((groups, c), dtype=torch.int32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.sapcu_group_max_forward(_lib.ptr(x), groups, int(m), c, _lib.ptr(out), _lib.ptr(arg), _lib.current_stream()))
+        ctx.save_for_backward(arg)
+        ctx.m = int(m)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        (arg,) = ctx.saved_tensors
+        groups, c = arg.shape
+        gx = torch.empty((groups * ctx.m, c), dtype=torch.float32, device=arg.device)
+        with torch.cuda.device(arg.device):
+            _lib.check(lib.sapcu_group_max_backward(_lib.ptr(grad_out.contiguous()), _lib.ptr(arg), groups, ctx.m, c, _lib.ptr(gx),
+                                                    _lib.current_stream()))
+        return gx, None
+
+
+def group_max(x, m):
+    """max over the m points of each patch: x [groups*m, c] -> [groups, c]; gradient to the first arg-max (fn:472)."""
+    return _GroupMax.apply(x, m)
+
+
+def inpatch_knn(xyz, k):
+    """In-patch kNN of fn's blocks (fn/snn_coder.py:31-39) on the device: xyz [B, N, 3] -> int32 [B, N, k]."""
+    lib = _lib.load()
+    B, N, _ = xyz.shape
+    x = xyz.contiguous()
+    idx = torch.empty((B, N, k), dtype=torch.int32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.check(lib.sapcu_patch_knn(_lib.ptr(x), B, N, 3, 3, k, _lib.ptr(idx), _lib.current_stream()))
+    return idx
+
+
+def fn_train_forward(p, points, k_values=(24, 18, 12), time_steps_enc=4, num_heads=8, eps=1e-5, knn=None):
+    """``ImprovedSNNNormalEstimation.forward`` in TRAINING mode (fn/snn_coder.py:430-476, 542-549, 670-699; every dropout off:
+    dropout is random) on the HIP training ops: points [B, M, 3] -> unit normals [B, 3], differentiable w.r.t. every tensor
+    of p (the model's parameters under the reference's state_dict names).  GELU, LayerNorm(3), the concatenation, the
+    residual adds and the final normalisation are torch glue on small tensors."""
+    B, N, _ = points.shape
+    P = B * N
+    F = torch.nn.functional
+
+    def sub(prefix):
+        return {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)}
+
+    enc = sub("encoder.")
+    feat = conv_bn_lif_train(_pad_channels(points.reshape(P, 3)), _pad_channels(enc["conv1.0.weight"].reshape(64, -1)), enc["conv1.0.bias"],
+                             enc["conv1.1.weight"], enc["conv1.1.bias"], enc["snn_init.membrane_decay"], enc["snn_init.threshold_adapt"],
+                             enc["snn_init.refractory_decay"], enc["snn_init.threshold_base"], steps=time_steps_enc, eps=eps)
+    feats, cur = [], feat.view(B, N, 64)
+    for i, kk in enumerate(k_values):
+        k = min(kk, N)
+        idx = knn[i] if knn is not None else inpatch_knn(points, k)
+        cur = transformer_block_train(sub("encoder.trans%d." % (i + 1)), points, cur, idx, time_steps=4, num_heads=num_heads, eps=eps)
+        feats.append(cur)
+    multi = torch.cat(feats, dim=2).reshape(P, 192)
+    g = conv_bn_lif_train(multi, enc["conv_final.0.weight"].reshape(enc["conv_final.0.weight"].shape[0], -1), enc["conv_final.0.bias"],
+                          enc["conv_final.1.weight"], enc["conv_final.1.bias"], enc["snn_final.membrane_decay"],
+                          enc["snn_final.threshold_adapt"], enc["snn_final.refractory_decay"], enc["snn_final.threshold_base"],
+                          steps=time_steps_enc, eps=eps)
+    x = linear_train(group_max(g, N), enc["fc_out.weight"], enc["fc_out.bias"])
+    dec = sub("decoder.")
+    lin = sorted({int(k.split(".")[1]) for k in dec if k.startswith("mlp.") and k.endswith(".weight") and dec[k].dim() == 2})
+    for li in lin:                                               # Linear, BatchNorm1d, GELU (, Dropout off)
+        x = F.gelu(conv_bn_train(_pad_channels(x), _pad_channels(dec["mlp.%d.weight" % li]), dec["mlp.%d.bias" % li],
+                                 dec["mlp.%d.weight" % (li + 1)], dec["mlp.%d.bias" % (li + 1)], eps=eps))
+    x = linear_train(x, dec["fc_out.weight"], dec["fc_out.bias"])
+    x = F.layer_norm(x, (3,), dec["norm_out.weight"], dec["norm_out.bias"], 1e-5)
+    return F.normalize(x, dim=1)

@@ -149,6 +149,12 @@ int sapcu_gather_rows(const float* src, int ld_src, const int64_t* index, int64_
 int sapcu_scatter_add_rows(const float* grad_out, const int64_t* index, int64_t rows, int d, float* grad_src, int ld_grad,
                            int64_t src_rows, void* stream);
 
+/* Max over the m points of each patch, x [groups*m, c] -> out [groups, c] (adaptive_max_pool1d, fn/snn_coder.py:472), with
+ * the arg-max (ties -> first point) for the backward, which routes grad_out to that point. */
+int sapcu_group_max_forward(const float* x, int64_t groups, int m, int c, float* out, int32_t* argmax_out, void* stream);
+int sapcu_group_max_backward(const float* grad_out, const int32_t* argmax, int64_t groups, int m, int c, float* grad_x,
+                             void* stream);
+
 /* In-patch kNN `topk(-|xi|^2 + 2 xi.xj - |xj|^2)` — fn/snn_coder.py:31-39, fd/snn_coder.py:25-32.
  * feat [b, m, ld] f32 (point-major, first c columns used), 1 <= m <= 128, k <= m.
  * idx_out [b,m,k] int32, descending score, equal scores by ascending index. */

@@ -92,3 +92,44 @@ def transformer_block_train(p, xyz, features, knn_idx, time_steps=4, num_heads=8
     res = softmax_agg(a, pe, v, knn_idx.reshape(P * k), N, float((d_model // num_heads) ** 0.5))
     res = layer(res, "out_proj.0", "out_proj.1")
     return (layer(res, "fc2.0", "fc2.1") + feat).view(B, N, -1)
+
+
+def fn_train_forward(p, points, knn, time_steps_enc=4, num_heads=8, eps=1e-5):
+    """ImprovedSNNNormalEstimation.forward in training mode, dropout off (fn/snn_coder.py:430-476, 542-549), restated with
+    plain torch ops on channels-last rows; knn = the three blocks' in-patch neighbour tables [B, N, k]."""
+    import torch.nn.functional as F
+    B, N, _ = points.shape
+    P = B * N
+
+    def sub(prefix):
+        return {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)}
+
+    def lif(z, e, name):
+        return lif_selfloop_train(z, e[name + ".membrane_decay"], e[name + ".threshold_adapt"], e[name + ".refractory_decay"],
+                                  e[name + ".threshold_base"], time_steps_enc)
+
+    enc = sub("encoder.")
+    cur = lif(conv_bn_train(points.reshape(P, 3), enc["conv1.0.weight"], enc["conv1.0.bias"], enc["conv1.1.weight"], enc["conv1.1.bias"], eps),
+              enc, "snn_init").view(B, N, 64)
+    feats = []
+    for i in range(3):
+        cur = transformer_block_train(sub("encoder.trans%d." % (i + 1)), points, cur, knn[i], 4, num_heads, eps)
+        feats.append(cur)
+    g = lif(conv_bn_train(torch.cat(feats, 2).reshape(P, 192), enc["conv_final.0.weight"], enc["conv_final.0.bias"],
+                          enc["conv_final.1.weight"], enc["conv_final.1.bias"], eps), enc, "snn_final")
+    x = g.view(B, N, -1).max(dim=1)[0] @ enc["fc_out.weight"].t() + enc["fc_out.bias"]
+    dec = sub("decoder.")
+    for li in sorted({int(k.split(".")[1]) for k in dec if k.startswith("mlp.") and k.endswith(".weight") and dec[k].dim() == 2}):
+        x = F.gelu(conv_bn_train(x, dec["mlp.%d.weight" % li], dec["mlp.%d.bias" % li], dec["mlp.%d.weight" % (li + 1)],
+                                 dec["mlp.%d.bias" % (li + 1)], eps))
+    x = x @ dec["fc_out.weight"].t() + dec["fc_out.bias"]
+    return F.normalize(F.layer_norm(x, (3,), dec["norm_out.weight"], dec["norm_out.bias"], 1e-5), dim=1)
+
+
+def angular_loss(pred, gt, temperature=0.1, alpha=0.1):
+    """enhanced_angular_loss_with_consistency without the consistency term (fn/snn_coder.py:603-612): for [B, 3] predictions
+    that term compares each normal with copies of itself — its value is 0.15 * mean(1 - 1) and its gradient is zero."""
+    cos = torch.nn.functional.cosine_similarity(pred, gt, dim=1)
+    err = torch.acos(torch.clamp(cos, -1 + 1e-6, 1 - 1e-6))
+    conf = torch.sigmoid(err.detach() / temperature)
+    return (err * conf + alpha * (conf - 0.5) ** 2).mean()

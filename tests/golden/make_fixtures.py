@@ -12,6 +12,7 @@ No reference source text is stored.  Weights are NOT stored: every box rebuilds 
 ``testing.conditioned_state_dict(shapes, seed=0, bn_stats=<bn_calib_*.npz>)``.
 """
 import argparse
+import zlib
 import os
 import shutil
 import subprocess
@@ -277,11 +278,55 @@ def block_train_fixture():
     save("block_train.npz", **out)
 
 
+def fn_train_fixture():
+    """One TRAINING step of the reference's whole fn model (fn/snn_coder.py:627-699 in train() mode, every nn.Dropout set to
+    p=0 because dropout is random): unit normals, enhanced_angular_loss_with_consistency (fn:587-625, xyz passed as the
+    reference's trainer does) and the autograd gradients of the loss.  Parameters are testing.training_state_dict(seed 5), so the
+    fixture carries only inputs, outputs and gradients; gradients of tensors above 8192 elements are stored as a seeded
+    sample of 2048 entries plus their L2 norm."""
+    rng = np.random.default_rng(31)
+    torch.manual_seed(31)
+    B, N = 6, 32
+    model = ref_fn.ImprovedSNNNormalEstimation(**FN_KW)
+    model.load_state_dict(T.training_state_dict(model.state_dict(), 5), strict=True)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    model.train()
+    d = rng.normal(size=(B, N, 3))
+    d /= np.linalg.norm(d, axis=2, keepdims=True)
+    pts = torch.tensor((d * rng.uniform(0.2, 1.0, (B, N, 1)) * np.array([1.0, 1.0, 0.15])).astype(np.float32))
+    gt = rng.normal(size=(B, 3))
+    gt = torch.tensor((gt / np.linalg.norm(gt, axis=1, keepdims=True)).astype(np.float32))
+    normals = model(pts)
+    loss, conf = ref_fn.enhanced_angular_loss_with_consistency(normals, gt, xyz=pts)
+    loss.backward()
+    enc = model.encoder
+    out = {"points": npy(pts), "gt": npy(gt), "normals": npy(normals), "loss": np.float64(loss.item()), "seed": np.int64(5)}
+    for i, blk in enumerate((enc.trans1, enc.trans2, enc.trans3)):
+        out["knn%d" % i] = npy(blk.knn_cache.get_knn(pts, min(blk.k, N), "block_%d" % id(blk))).astype(np.int32)
+    names = []
+    for n, prm in model.named_parameters():
+        g = npy(prm.grad).ravel() if prm.grad is not None else np.zeros(prm.numel(), np.float32)
+        names.append(n)
+        if g.size <= 8192:
+            out["g:" + n] = g.reshape(tuple(prm.shape))
+        else:
+            sel = np.sort(np.random.default_rng(zlib.crc32(n.encode())).choice(g.size, 2048, replace=False))
+            out["gi:" + n] = sel.astype(np.int64)
+            out["gs:" + n] = g[sel]
+            out["gn:" + n] = np.float64(np.linalg.norm(g.astype(np.float64)))
+    out["names"] = np.array(names)
+    print("fn train step: loss %.6f  normals[0] %s" % (loss.item(), npy(normals)[0]))
+    save("fn_train.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-e2e", action="store_true")
     ap.add_argument("--only-fps", action="store_true", help="only (re)generate fps.npz")
     ap.add_argument("--only-train", action="store_true", help="only (re)generate neuron_train.npz")
+    ap.add_argument("--only-fn-train", action="store_true", help="only (re)generate fn_train.npz")
     ap.add_argument("--only-seeds", action="store_true", help="only (re)generate dense_seeds.npz")
     args = ap.parse_args()
     if args.only_seeds:
@@ -292,6 +337,9 @@ def main():
         return
     if args.only_train:
         neuron_train_fixture()
+        return
+    if args.only_fn_train:
+        fn_train_fixture()
         return
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -464,6 +512,7 @@ def main():
     seed_fixture()
     fps_fixture()
     neuron_train_fixture()
+    fn_train_fixture()
 
     # ---- 10. end-to-end Generator3D6.upsample on sphere N=2048, dense_spacing 0.03 (~900 seeds)
     if not args.skip_e2e:

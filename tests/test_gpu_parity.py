@@ -857,3 +857,57 @@ def test_training_transformer_block_forward_backward_against_reference_run():
         ref = torch.from_numpy(g["g:" + n])
         got = p[n].grad.cpu() if p[n].grad is not None else torch.zeros_like(ref)
         assert float((got - ref).abs().max()) <= 5e-3 * float(ref.abs().max()) + floor, (n, float((got - ref).abs().max()))
+
+
+def test_training_group_max_and_linear_ops():
+    """Row f-4 building blocks: max over each patch's points with gradient to the FIRST arg-max (adaptive_max_pool1d on
+    {0,1} spikes ties constantly) and the Linear layer with HIP forward / weight / data gradients, against torch."""
+    from sapcu_amd import train
+    rng = np.random.default_rng(3)
+    for groups, m, c in ((5, 32, 640), (3, 7, 96), (1, 1, 32)):
+        x = torch.tensor((rng.uniform(size=(groups * m, c)) > 0.7).astype(np.float32)) * torch.tensor(rng.integers(1, 3, (groups * m, c)).astype(np.float32))
+        go = torch.tensor(rng.normal(size=(groups, c)).astype(np.float32))
+        xd = x.cuda().requires_grad_(True)
+        yd = train.group_max(xd, m)
+        yd.backward(go.cuda())
+        xh = x.clone().requires_grad_(True)
+        val, arg = xh.view(groups, m, c).max(dim=1)
+        first = (xh.view(groups, m, c) == val.unsqueeze(1)).float().argmax(dim=1)           # first index of the maximum
+        gh = torch.zeros(groups, m, c).scatter_(1, first.unsqueeze(1), go.unsqueeze(1)).view(groups * m, c)
+        assert torch.equal(yd.detach().cpu(), val.detach())
+        assert torch.equal(xd.grad.cpu(), gh)
+    for rows, cin, cout in ((6, 2048, 1024), (6, 256, 3), (192, 3, 64), (40, 70, 33)):
+        x = torch.tensor(rng.normal(size=(rows, cin)).astype(np.float32))
+        w = torch.tensor(rng.normal(size=(cout, cin)).astype(np.float32) / np.sqrt(cin))
+        b = torch.tensor(rng.normal(size=(cout,)).astype(np.float32))
+        go = torch.tensor(rng.normal(size=(rows, cout)).astype(np.float32))
+        d = [v.cuda().requires_grad_(True) for v in (x, w, b)]
+        h = [v.clone().requires_grad_(True) for v in (x, w, b)]
+        yd = train.linear_train(*d)
+        yh = torch.nn.functional.linear(*h)
+        assert (yd.detach().cpu() - yh.detach()).abs().max() <= 2e-5 * max(1.0, float(yh.abs().max()))
+        yd.backward(go.cuda())
+        yh.backward(go)
+        for dd, hh in zip(d, h):
+            assert (dd.grad.cpu() - hh.grad).abs().max() <= 2e-5 * max(1.0, float(hh.grad.abs().max())), (rows, cin, cout)
+
+
+def test_training_step_of_whole_fn_model_against_reference_run():
+    """Row f-4: one training step of the whole fn model (train() mode, dropout off) composed from the HIP training ops —
+    unit normals, loss and the gradient of every parameter against the reference's own run (tests/golden/fn_train.npz).
+    The in-patch kNN tables come from sapcu_patch_knn and must equal the reference's."""
+    from sapcu_amd import train
+    from oracle import train_path as TP
+    from test_oracle_golden import _fn_train_params, check_fn_train_grads
+    g = golden("fn_train.npz")
+    p, names = _fn_train_params(g, "cuda")
+    pts = _dev(g["points"])
+    for i, k in enumerate((24, 18, 12)):
+        idx = train.inpatch_knn(pts, k).cpu().numpy()
+        assert np.array_equal(np.sort(idx, axis=2), np.sort(g["knn%d" % i], axis=2))
+    normals = train.fn_train_forward(p, pts)
+    assert (normals.detach().cpu() - torch.from_numpy(g["normals"])).abs().max() <= 2e-4
+    loss = TP.angular_loss(normals, _dev(g["gt"]))                      # a dozen torch ops on [B, 3]: the checker's copy
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 2e-4
+    loss.backward()
+    check_fn_train_grads(g, p, names, 2e-2, 5e-5)

@@ -271,3 +271,49 @@ def test_training_transformer_block_against_reference_run():
         got = p[n].grad if p[n].grad is not None else torch.zeros_like(ref)
         scale = float(ref.abs().max())
         assert float((got - ref).abs().max()) <= 2e-3 * scale + floor, (n, float((got - ref).abs().max()), scale, floor)
+
+
+def _fn_train_params(g, device="cpu"):
+    import sapcu_amd
+    from sapcu_amd import testing as T
+    shell = sapcu_amd.ImprovedSNNNormalEstimation(k_values=[24, 18, 12], emb_dims=640, time_steps_enc=4, time_steps_dec=12, num_heads=8,
+                                                  use_snn_decoder=False, decoder_dropout=0.1)
+    sd = T.training_state_dict(shell.state_dict(), int(g["seed"]))
+    names = [str(n) for n in g["names"]]
+    return {n: sd[n].to(device).clone().requires_grad_(True) for n in names}, names
+
+
+def check_fn_train_grads(g, p, names, tol, floor_rel):
+    """Compare p[n].grad with the fixture: full tensors, or the stored sample + L2 norm of the large ones."""
+    peak = max(float(np.abs(g[("g:" if ("g:" + n) in g else "gs:") + n]).max()) for n in names)
+    floor = floor_rel * peak
+    worst = 0.0
+    for n in names:
+        got = p[n].grad.detach().cpu().numpy().ravel() if p[n].grad is not None else np.zeros(p[n].numel(), np.float32)
+        if ("g:" + n) in g:
+            ref = g["g:" + n].ravel()
+        else:
+            ref = g["gs:" + n]
+            norm = float(np.linalg.norm(got.astype(np.float64)))
+            assert abs(norm - float(g["gn:" + n])) <= tol * float(g["gn:" + n]) + floor, (n, norm, float(g["gn:" + n]))
+            got = got[g["gi:" + n]]
+        scale = float(np.abs(ref).max())
+        err = float(np.abs(got - ref).max())
+        worst = max(worst, err / (scale + floor))
+        assert err <= tol * scale + floor, (n, err, scale, floor)
+    return worst
+
+
+def test_fn_training_step_matches_reference():
+    """Row f-4: one training step of the WHOLE fn model (train() mode, dropout off) — the oracle's restatement against the
+    reference's normals, loss and parameter gradients (tests/golden/fn_train.npz)."""
+    from oracle import train_path as TP
+    g = golden("fn_train.npz")
+    p, names = _fn_train_params(g)
+    knn = [t(g["knn%d" % i]) for i in range(3)]
+    normals = TP.fn_train_forward(p, t(g["points"]), knn)
+    np.testing.assert_allclose(normals.detach().numpy(), g["normals"], rtol=0, atol=2e-4)
+    loss = TP.angular_loss(normals, t(g["gt"]))
+    assert abs(float(loss) - float(g["loss"])) <= 2e-4
+    loss.backward()
+    check_fn_train_grads(g, p, names, 1e-2, 2e-5)
