@@ -878,7 +878,7 @@ def test_training_group_max_and_linear_ops():
         assert torch.equal(xd.grad.cpu(), gh)
     for rows, cin, cout in ((6, 2048, 1024), (6, 256, 3), (192, 3, 64), (40, 70, 33)):
         x = torch.tensor(rng.normal(size=(rows, cin)).astype(np.float32))
-        w = torch.tensor(rng.normal(size=(cout, cin)).astype(np.float32) / np.sqrt(cin))
+        w = torch.tensor((rng.normal(size=(cout, cin)) / np.sqrt(cin)).astype(np.float32))
         b = torch.tensor(rng.normal(size=(cout,)).astype(np.float32))
         go = torch.tensor(rng.normal(size=(rows, cout)).astype(np.float32))
         d = [v.cuda().requires_grad_(True) for v in (x, w, b)]
