@@ -302,7 +302,8 @@ static int wgrad_slabs(int64_t rows) {
 __global__ __launch_bounds__(256) void softmax_agg_bwd_kernel(const float* __restrict__ a, const float* __restrict__ pe,
                                                               const float* __restrict__ v, int ldv, const int32_t* __restrict__ idx,
                                                               const float* __restrict__ gres, int64_t pts, int m, int kk, int d,
-                                                              float sqrt_hd, float* __restrict__ ga, float* __restrict__ gpe,
+                                                              float sqrt_hd, const float* __restrict__ keep,
+                                                              float* __restrict__ ga, float* __restrict__ gpe,
                                                               float* __restrict__ gv, int ldgv) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= pts * d) return;
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(256) void softmax_agg_bwd_kernel(const float* __res
     const int64_t patch_i = pt / m;
     const float* ar = a + pt * kk * d + c;
     const float* pr = pe + pt * kk * d + c;
+    const float* kr = keep ? keep + pt * kk * d + c : nullptr;
     const int32_t* ir = idx + pt * kk;
     const float inv_sqrt_hd = __fdiv_rn(1.0f, sqrt_hd);
     float mx = -__builtin_huge_valf();
@@ -320,19 +322,50 @@ __global__ __launch_bounds__(256) void softmax_agg_bwd_kernel(const float* __res
     const float inv_den = __fdiv_rn(1.0f, den);
     float res = 0.f;
     for (int j = 0; j < kk; ++j) {
-        const float wj = __fmul_rn(fast_exp(__fsub_rn(__fmul_rn(ar[(int64_t)j * d], inv_sqrt_hd), mx)), inv_den);
+        float wj = __fmul_rn(fast_exp(__fsub_rn(__fmul_rn(ar[(int64_t)j * d], inv_sqrt_hd), mx)), inv_den);
+        if (kr) wj = __fmul_rn(wj, kr[(int64_t)j * d]);
         res = __fmaf_rn(wj, __fadd_rn(v[(patch_i * m + ir[j]) * ldv + c], pr[(int64_t)j * d]), res);
     }
     const float g = gres[t];
     for (int j = 0; j < kk; ++j) {
         const float wj = __fmul_rn(fast_exp(__fsub_rn(__fmul_rn(ar[(int64_t)j * d], inv_sqrt_hd), mx)), inv_den);
+        const float kj = kr ? kr[(int64_t)j * d] : 1.0f;                    // dropout on the softmax weights (fn:383)
         const int64_t nb = patch_i * m + ir[j];
         const float u = __fadd_rn(v[nb * ldv + c], pr[(int64_t)j * d]);
-        const float wg = wj * g;
+        const float wg = wj * kj * g;
         gpe[(pt * kk + j) * d + c] = wg;
         atomicAdd(gv + nb * ldgv + c, wg);
-        ga[(pt * kk + j) * d + c] = wg * (u - res) * inv_sqrt_hd;
+        ga[(pt * kk + j) * d + c] = wj * g * (kj * u - res) * inv_sqrt_hd;
     }
+}
+
+// Forward with dropout on the softmax weights (train() mode, fn/snn_coder.py:381-388): keep holds 0 or 1/(1-p) per
+// (edge row, channel).  Same arithmetic as the backward's recomputation above.
+__global__ __launch_bounds__(256) void softmax_agg_keep_fwd_kernel(const float* __restrict__ a, const float* __restrict__ pe,
+                                                                   const float* __restrict__ v, int ldv, const int32_t* __restrict__ idx,
+                                                                   const float* __restrict__ keep, int64_t pts, int m, int kk, int d,
+                                                                   float sqrt_hd, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pts * d) return;
+    const int c = (int)(t % d);
+    const int64_t pt = t / d;
+    const int64_t patch_i = pt / m;
+    const float* ar = a + pt * kk * d + c;
+    const float* pr = pe + pt * kk * d + c;
+    const float* kr = keep + pt * kk * d + c;
+    const int32_t* ir = idx + pt * kk;
+    const float inv_sqrt_hd = __fdiv_rn(1.0f, sqrt_hd);
+    float mx = -__builtin_huge_valf();
+    for (int j = 0; j < kk; ++j) mx = fmaxf(mx, __fmul_rn(ar[(int64_t)j * d], inv_sqrt_hd));
+    float den = 0.f;
+    for (int j = 0; j < kk; ++j) den = __fadd_rn(den, fast_exp(__fsub_rn(__fmul_rn(ar[(int64_t)j * d], inv_sqrt_hd), mx)));
+    const float inv_den = __fdiv_rn(1.0f, den);
+    float res = 0.f;
+    for (int j = 0; j < kk; ++j) {
+        const float wj = __fmul_rn(__fmul_rn(fast_exp(__fsub_rn(__fmul_rn(ar[(int64_t)j * d], inv_sqrt_hd), mx)), inv_den), kr[(int64_t)j * d]);
+        res = __fmaf_rn(wj, __fadd_rn(v[(patch_i * m + ir[j]) * ldv + c], pr[(int64_t)j * d]), res);
+    }
+    out[t] = res;
 }
 
 // ---- row gather (index_points, fn/snn_coder.py:19-29, on flattened rows) and its backward (scatter-add)
@@ -524,14 +557,20 @@ int sapcu_conv1x1_wgrad_f32(const float* grad_y, int ldy, const float* x, int ld
 }
 
 
-int sapcu_softmax_agg_forward(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx, int64_t pts, int m,
-                              int kk, int d, float sqrt_hd, float* res, void* stream) {
+int sapcu_softmax_agg_forward(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx, const float* keep,
+                              int64_t pts, int m, int kk, int d, float sqrt_hd, float* res, void* stream) {
     SAPCU_CHECK_ARG(a && pe && v && idx && res && pts >= 0 && m >= 1 && kk >= 1 && d >= 1 && ldv >= d && sqrt_hd > 0.f,
                     "softmax_agg_forward: bad argument");
-    return launch_fn_softmax_agg(a, pe, v, ldv, idx, pts, m, kk, d, sqrt_hd, res, 0, (hipStream_t)stream);
+    if (!keep) return launch_fn_softmax_agg(a, pe, v, ldv, idx, pts, m, kk, d, sqrt_hd, res, 0, (hipStream_t)stream);
+    if (pts == 0) return SAPCU_OK;
+    SAPCU_CHECK_ARG(pts % m == 0, "softmax_agg_forward: points must come in whole patches of m");
+    hipLaunchKernelGGL(softmax_agg_keep_fwd_kernel, dim3((unsigned)((pts * d + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, pe, v, ldv,
+                       idx, keep, pts, m, kk, d, sqrt_hd, res);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
 }
 
-int sapcu_softmax_agg_backward(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx,
+int sapcu_softmax_agg_backward(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx, const float* keep,
                                const float* grad_res, int64_t pts, int m, int kk, int d, float sqrt_hd, float* grad_a,
                                float* grad_pe, float* grad_v, int ldgv, void* stream) {
     SAPCU_CHECK_ARG(a && pe && v && idx && grad_res && grad_a && grad_pe && grad_v && pts >= 0 && m >= 1 && kk >= 1 && d >= 1 &&
@@ -541,7 +580,7 @@ int sapcu_softmax_agg_backward(const float* a, const float* pe, const float* v, 
     hipStream_t st = (hipStream_t)stream;
     SAPCU_CHECK_HIP(hipMemset2DAsync(grad_v, (size_t)ldgv * 4, 0, (size_t)d * 4, (size_t)pts, st));
     hipLaunchKernelGGL(softmax_agg_bwd_kernel, dim3((unsigned)((pts * d + 255) / 256)), dim3(256), 0, st, a, pe, v, ldv, idx, grad_res,
-                       pts, m, kk, d, sqrt_hd, grad_a, grad_pe, grad_v, ldgv);
+                       pts, m, kk, d, sqrt_hd, keep, grad_a, grad_pe, grad_v, ldgv);
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
 }

@@ -203,7 +203,37 @@ class ImprovedSNNNormalEstimation(_HipModel):
         # SHAPE, never cleared by reset_states().  'reference' replays it, 'fresh' recomputes.
         self.knn_cache_mode = "reference"
         self._knn_cache = {}
+        self.decoder_dropout = float(decoder_dropout)
+        self.attn_dropout = 0.1                   # MultiHeadSNNTransformerBlock's default, which the encoder never overrides (fn:213, 421-423)
         super().train(False)
+
+    def train(self, mode=True):
+        """fn has a training path (row f-4, sapcu_amd/train.py): train() switches forward() to hard spikes, batch statistics,
+        dropout and autograd through the HIP training ops."""
+        return nn.Module.train(self, mode)
+
+    def _train_forward(self, point_cloud):
+        from . import train as T
+        if point_cloud.ndim == 4:
+            B, N, M, C = point_cloud.shape
+            return self._train_forward(point_cloud.reshape(B * N, M, C)).view(B, N, 3)
+        x = self._as_patches(point_cloud)
+        self._device()
+        p = dict(self.named_parameters())
+        p.update(dict(self.named_buffers()))
+        return T.fn_train_forward(p, x, tuple(self.k_values), self.time_steps_enc, self.num_heads, momentum=0.1,
+                                  attn_dropout=self.attn_dropout, decoder_dropout=self.decoder_dropout)
+
+    def compute_loss(self, pred_normals, gt_normals, xyz=None, consistency_weight=0.15, k_neighbors=8):
+        """fn/snn_coder.py:701-724: (loss, {'total_loss', 'confidence'}) — angular loss with confidence weighting plus the
+        neighbour-consistency term (fn:557-625).  A few dozen torch ops on [B(,N),3] tensors; the neighbour search of the
+        consistency term is sapcu_patch_knn."""
+        from . import train as T
+        if xyz is not None and xyz.ndim == 4:
+            xyz = xyz.mean(dim=2)
+        loss, confidence = T.angular_loss_with_consistency(pred_normals, gt_normals, xyz, consistency_weight=consistency_weight,
+                                                           k_neighbors=k_neighbors)
+        return loss, {"total_loss": loss.item(), "confidence": confidence.item()}
 
     def _hparams(self):
         return list(self.k_values) + [self.emb_dims, self.time_steps_enc, self.num_heads]
@@ -218,6 +248,8 @@ class ImprovedSNNNormalEstimation(_HipModel):
         """[B,M,3] | [B,3,M] -> [B,3];  [B,N,M,3] -> [B,N,3]  (fn/snn_coder.py:670-699).
         knn_in (ours, optional): explicit in-patch neighbour tables (flat int32, three [B,M,k] blocks) — used by
         Generator3D6 to run several reference batches in one device pass; bypasses the shape-keyed cache."""
+        if self.training:
+            return self._train_forward(point_cloud)
         if point_cloud.ndim == 4:
             B, N, M, C = point_cloud.shape
             return self.forward(point_cloud.reshape(B * N, M, C), taps).view(B, N, 3)

@@ -71,7 +71,8 @@ def _gemm(lib, a, w, bias, out):
 
 class _ConvBnLifTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, membrane_decay, threshold_adapt, refractory_decay, threshold_base, steps, eps):
+    def forward(ctx, x, weight, bias, gamma, beta, membrane_decay, threshold_adapt, refractory_decay, threshold_base, steps, eps,
+                running=None):
         lib = _lib.load()
         rows, cin = x.shape
         cout = weight.shape[0]
@@ -95,9 +96,17 @@ class _ConvBnLifTrain(torch.autograd.Function):
                 out = torch.empty_like(y)
                 _lib.check(lib.sapcu_lif_train_forward(_lib.ptr(z), rows, cout, int(steps), *[_lib.ptr(p) for p in prm],
                                                        _lib.ptr(out), _lib.current_stream()))
+        if running is not None:                     # nn.BatchNorm's train()-mode bookkeeping: momentum update, unbiased variance
+            r_mean, r_var, n_tracked, momentum = running
+            if rows < 2:
+                raise ValueError("BatchNorm in training mode needs more than 1 value per channel (got %d rows)" % rows)
+            with torch.no_grad():
+                r_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+                r_var.mul_(1.0 - momentum).add_(var, alpha=momentum * rows / (rows - 1.0))
+                if n_tracked is not None:
+                    n_tracked.add_(1)
         ctx.save_for_backward(x, w, gamma.detach().contiguous(), y, z, mean, invstd, *prm)
         ctx.steps = int(steps)
-        ctx.batch_stats = (mean, var)
         return out
 
     @staticmethod
@@ -130,33 +139,36 @@ class _ConvBnLifTrain(torch.autograd.Function):
             _lib.check(lib.sapcu_conv1x1_wgrad_f32(_lib.ptr(dy), cout, _lib.ptr(x), cin, rows, cout, cin, _lib.ptr(dw),
                                                    _lib.ptr(dbias), _lib.ptr(ws), nbytes, st))
             _gemm(lib, dy, w.t().contiguous(), None, dx)            # dx[r, cin] = dy[r, cout] . (W^T)[cin, cout]^T
-        return (dx, dw, dbias, dgamma, dbeta, gp[0], gp[1], gp[2], gp[3], None, None)
+        return (dx, dw, dbias, dgamma, dbeta, gp[0], gp[1], gp[2], gp[3], None, None, None)
 
 
 def conv_bn_lif_train(x, weight, bias, gamma, beta, membrane_decay, threshold_adapt, refractory_decay, threshold_base,
-                      steps=4, eps=1e-5):
+                      steps=4, eps=1e-5, running=None):
     """fn's basic layer in TRAINING mode (fn/snn_coder.py:225-229 + 317-320): x [rows, c_in] (channels last) ->
     hard spikes [rows, c_out] of `steps` neuron steps on BatchNorm_train(x . W^T + b).  Differentiable w.r.t. x and all nine
-    parameter tensors.  (The BatchNorm running statistics are not touched: `batch_stats(out)` returns the batch mean and
-    biased variance for the caller's momentum update.)"""
+    parameter tensors.  running: None, or (running_mean, running_var, num_batches_tracked | None, momentum) updated in place
+    the way nn.BatchNorm does in train() mode."""
     w2 = weight.reshape(weight.shape[0], -1)                      # Conv1d/Conv2d 1x1 weights [c_out, c_in, 1(,1)]
     return _ConvBnLifTrain.apply(x, w2, bias, gamma, beta, membrane_decay, threshold_adapt, refractory_decay, threshold_base,
-                                 steps, eps)
+                                 steps, eps, running)
 
 
 class _SoftmaxAgg(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, pe, v, idx, m, sqrt_hd):
+    def forward(ctx, a, pe, v, idx, m, sqrt_hd, keep):
         lib = _lib.load()
         pts, d = v.shape
         kk = a.shape[0] // pts
         a, pe, v = a.contiguous(), pe.contiguous(), v.contiguous()
         idx = idx.contiguous().to(torch.int32)
+        keep = keep.contiguous() if keep is not None else None
         res = torch.empty((pts, d), dtype=torch.float32, device=a.device)
         with torch.cuda.device(a.device):
-            _lib.check(lib.sapcu_softmax_agg_forward(_lib.ptr(a), _lib.ptr(pe), _lib.ptr(v), d, _lib.ptr(idx), pts, int(m), kk, d,
+            _lib.check(lib.sapcu_softmax_agg_forward(_lib.ptr(a), _lib.ptr(pe), _lib.ptr(v), d, _lib.ptr(idx),
+                                                     _lib.ptr(keep) if keep is not None else None, pts, int(m), kk, d,
                                                      float(sqrt_hd), _lib.ptr(res), _lib.current_stream()))
         ctx.save_for_backward(a, pe, v, idx)
+        ctx.keep = keep
         ctx.m, ctx.sqrt_hd = int(m), float(sqrt_hd)
         return res
 
@@ -169,22 +181,29 @@ class _SoftmaxAgg(torch.autograd.Function):
         ga, gpe, gv = torch.empty_like(a), torch.empty_like(pe), torch.empty_like(v)
         with torch.cuda.device(a.device):
             _lib.check(lib.sapcu_softmax_agg_backward(_lib.ptr(a), _lib.ptr(pe), _lib.ptr(v), d, _lib.ptr(idx),
+                                                      _lib.ptr(ctx.keep) if ctx.keep is not None else None,
                                                       _lib.ptr(grad_res.contiguous()), pts, ctx.m, kk, d, ctx.sqrt_hd, _lib.ptr(ga),
                                                       _lib.ptr(gpe), _lib.ptr(gv), d, _lib.current_stream()))
-        return ga, gpe, gv, None, None, None
+        return ga, gpe, gv, None, None, None, None
 
 
-def softmax_agg(a, pe, v, idx, m, sqrt_hd):
+def softmax_agg(a, pe, v, idx, m, sqrt_hd, keep=None):
     """fn/snn_coder.py:379-389 on edge rows: a, pe [P*k, d]; v [P, d]; idx [P*k] in-patch neighbour indices (m points per
-    patch) -> res [P, d] = sum_j softmax_j(a / sqrt_hd) * (v[nbr_j] + pe_j).  Differentiable w.r.t. a, pe and v."""
-    return _SoftmaxAgg.apply(a, pe, v, idx, m, sqrt_hd)
+    patch) -> res [P, d] = sum_j softmax_j(a / sqrt_hd) * keep_j * (v[nbr_j] + pe_j).  keep: None, or [P*k, d] holding 0 or
+    1/(1-p) (the attention dropout of train() mode, fn:383).  Differentiable w.r.t. a, pe and v."""
+    return _SoftmaxAgg.apply(a, pe, v, idx, m, sqrt_hd, keep)
 
 
-def conv_bn_train(x, weight, bias, gamma, beta, eps=1e-5):
+def dropout_keep(shape, p, device, generator=None):
+    """The scale mask nn.Dropout(p) multiplies with in train() mode: 0 with probability p, else 1/(1-p)."""
+    return torch.empty(shape, dtype=torch.float32, device=device).bernoulli_(1.0 - p, generator=generator).div_(1.0 - p)
+
+
+def conv_bn_train(x, weight, bias, gamma, beta, eps=1e-5, running=None):
     """1x1 convolution + BatchNorm in training mode, no neuron (fn's fc_gamma2 / out_proj / fc2): x [rows, c_in] -> [rows, c_out]."""
     w2 = weight.reshape(weight.shape[0], -1)
     dummy = torch.zeros((w2.shape[0],), dtype=torch.float32, device=x.device)
-    return _ConvBnLifTrain.apply(x, w2, bias, gamma, beta, dummy, dummy, dummy, dummy, 0, eps)
+    return _ConvBnLifTrain.apply(x, w2, bias, gamma, beta, dummy, dummy, dummy, dummy, 0, eps, running)
 
 
 class _GatherRows(torch.autograd.Function):
@@ -226,7 +245,15 @@ def _pad_channels(t, mult=32):
     return torch.nn.functional.pad(t, (0, pad)) if pad else t
 
 
-def transformer_block_train(p, xyz, features, knn_idx, time_steps=4, num_heads=8, eps=1e-5):
+def _running(p, bn, momentum):
+    """(running_mean, running_var, num_batches_tracked, momentum) of BatchNorm `bn` when p carries its buffers, else None."""
+    if momentum is None or (bn + ".running_mean") not in p:
+        return None
+    return (p[bn + ".running_mean"], p[bn + ".running_var"], p.get(bn + ".num_batches_tracked"), float(momentum))
+
+
+def transformer_block_train(p, xyz, features, knn_idx, time_steps=4, num_heads=8, eps=1e-5, momentum=None, attn_dropout=0.0,
+                            generator=None):
     """One ``MultiHeadSNNTransformerBlock`` in TRAINING mode (fn/snn_coder.py:294-396, dropout 0) on channels-last rows.
 
     p: dict of the block's parameters under the reference's names (``fc1.0.weight``, ``fc1.1.weight`` (BN gamma),
@@ -246,10 +273,11 @@ def transformer_block_train(p, xyz, features, knn_idx, time_steps=4, num_heads=8
     def layer(x, conv, bn, snn=None):
         w = _pad_channels(p[conv + ".weight"].reshape(p[conv + ".weight"].shape[0], -1))
         args = (_pad_channels(x), w, p[conv + ".bias"], p[bn + ".weight"], p[bn + ".bias"])
+        run = _running(p, bn, momentum)
         if snn is None:
-            return conv_bn_train(*args, eps=eps)
+            return conv_bn_train(*args, eps=eps, running=run)
         return conv_bn_lif_train(*args, p[snn + ".membrane_decay"], p[snn + ".threshold_adapt"], p[snn + ".refractory_decay"],
-                                 p[snn + ".threshold_base"], steps=time_steps, eps=eps)
+                                 p[snn + ".threshold_base"], steps=time_steps, eps=eps, running=run)
 
     x = layer(feat, "fc1.0", "fc1.1", "snn1")
     q = layer(x, "w_qs.0", "w_qs.1", "snn_q")
@@ -262,7 +290,8 @@ def transformer_block_train(p, xyz, features, knn_idx, time_steps=4, num_heads=8
     a = layer(attn_in, "fc_gamma.0", "fc_gamma.1", "snn_gamma")
     a = layer(a, "fc_gamma2.0", "fc_gamma2.1")
     d_model = a.shape[1]
-    res = softmax_agg(a, pe, v, knn_idx.reshape(P * k), N, float((d_model // num_heads) ** 0.5))
+    keep = dropout_keep((P * k, d_model), attn_dropout, dev, generator) if attn_dropout > 0 else None
+    res = softmax_agg(a, pe, v, knn_idx.reshape(P * k), N, float((d_model // num_heads) ** 0.5), keep)
     res = layer(res, "out_proj.0", "out_proj.1")
     res = layer(res, "fc2.0", "fc2.1") + feat
     return res.view(B, N, -1)
@@ -350,11 +379,15 @@ def inpatch_knn(xyz, k):
     return idx
 
 
-def fn_train_forward(p, points, k_values=(24, 18, 12), time_steps_enc=4, num_heads=8, eps=1e-5, knn=None):
+def fn_train_forward(p, points, k_values=(24, 18, 12), time_steps_enc=4, num_heads=8, eps=1e-5, knn=None, momentum=None,
+                     attn_dropout=0.0, decoder_dropout=0.0, generator=None):
     """``ImprovedSNNNormalEstimation.forward`` in TRAINING mode (fn/snn_coder.py:430-476, 542-549, 670-699; every dropout off:
     dropout is random) on the HIP training ops: points [B, M, 3] -> unit normals [B, 3], differentiable w.r.t. every tensor
     of p (the model's parameters under the reference's state_dict names).  GELU, LayerNorm(3), the concatenation, the
-    residual adds and the final normalisation are torch glue on small tensors."""
+    residual adds and the final normalisation are torch glue on small tensors.  momentum: when set and p also carries the
+    BatchNorm buffers, the running statistics are updated as train() mode does (0.1 in the reference).  attn_dropout /
+    decoder_dropout: the blocks' attention dropout (fn:286, 0.1 in the reference) and the decoder's (fn:532-533), drawn from
+    torch's generator on the device."""
     B, N, _ = points.shape
     P = B * N
     F = torch.nn.functional
@@ -365,24 +398,51 @@ def fn_train_forward(p, points, k_values=(24, 18, 12), time_steps_enc=4, num_hea
     enc = sub("encoder.")
     feat = conv_bn_lif_train(_pad_channels(points.reshape(P, 3)), _pad_channels(enc["conv1.0.weight"].reshape(64, -1)), enc["conv1.0.bias"],
                              enc["conv1.1.weight"], enc["conv1.1.bias"], enc["snn_init.membrane_decay"], enc["snn_init.threshold_adapt"],
-                             enc["snn_init.refractory_decay"], enc["snn_init.threshold_base"], steps=time_steps_enc, eps=eps)
+                             enc["snn_init.refractory_decay"], enc["snn_init.threshold_base"], steps=time_steps_enc, eps=eps,
+                             running=_running(enc, "conv1.1", momentum))
     feats, cur = [], feat.view(B, N, 64)
     for i, kk in enumerate(k_values):
         k = min(kk, N)
         idx = knn[i] if knn is not None else inpatch_knn(points, k)
-        cur = transformer_block_train(sub("encoder.trans%d." % (i + 1)), points, cur, idx, time_steps=4, num_heads=num_heads, eps=eps)
+        cur = transformer_block_train(sub("encoder.trans%d." % (i + 1)), points, cur, idx, time_steps=4, num_heads=num_heads, eps=eps,
+                                      momentum=momentum, attn_dropout=attn_dropout, generator=generator)
         feats.append(cur)
     multi = torch.cat(feats, dim=2).reshape(P, 192)
     g = conv_bn_lif_train(multi, enc["conv_final.0.weight"].reshape(enc["conv_final.0.weight"].shape[0], -1), enc["conv_final.0.bias"],
                           enc["conv_final.1.weight"], enc["conv_final.1.bias"], enc["snn_final.membrane_decay"],
                           enc["snn_final.threshold_adapt"], enc["snn_final.refractory_decay"], enc["snn_final.threshold_base"],
-                          steps=time_steps_enc, eps=eps)
+                          steps=time_steps_enc, eps=eps, running=_running(enc, "conv_final.1", momentum))
     x = linear_train(group_max(g, N), enc["fc_out.weight"], enc["fc_out.bias"])
     dec = sub("decoder.")
     lin = sorted({int(k.split(".")[1]) for k in dec if k.startswith("mlp.") and k.endswith(".weight") and dec[k].dim() == 2})
     for li in lin:                                               # Linear, BatchNorm1d, GELU (, Dropout off)
         x = F.gelu(conv_bn_train(_pad_channels(x), _pad_channels(dec["mlp.%d.weight" % li]), dec["mlp.%d.bias" % li],
-                                 dec["mlp.%d.weight" % (li + 1)], dec["mlp.%d.bias" % (li + 1)], eps=eps))
+                                 dec["mlp.%d.weight" % (li + 1)], dec["mlp.%d.bias" % (li + 1)], eps=eps,
+                                 running=_running(dec, "mlp.%d" % (li + 1), momentum)))
+        if decoder_dropout > 0:
+            x = x * dropout_keep(x.shape, decoder_dropout, x.device, generator)
     x = linear_train(x, dec["fc_out.weight"], dec["fc_out.bias"])
     x = F.layer_norm(x, (3,), dec["norm_out.weight"], dec["norm_out.bias"], 1e-5)
     return F.normalize(x, dim=1)
+
+
+def angular_loss_with_consistency(pred_normals, gt_normals, xyz=None, temperature=0.1, alpha=0.1, consistency_weight=0.15,
+                                  k_neighbors=8):
+    """enhanced_angular_loss_with_consistency (fn/snn_coder.py:587-625) + normal_consistency_loss (fn:557-583):
+    -> (loss, mean confidence).  pred/gt [B, 3] or [B, N, 3]; xyz [B, N, 3] (patch centres) or None."""
+    F = torch.nn.functional
+    pred = pred_normals.reshape(-1, 3)
+    gt = gt_normals.reshape(-1, 3)
+    cos = F.cosine_similarity(pred, gt, dim=1)
+    err = torch.acos(torch.clamp(cos, -1 + 1e-6, 1 - 1e-6))
+    conf = torch.sigmoid(err.detach() / temperature)
+    loss = (err * conf + alpha * (conf - 0.5) ** 2).mean()
+    if xyz is not None and consistency_weight > 0:
+        B, N, _ = xyz.shape
+        k = min(k_neighbors + 1, N)
+        # dists.argsort()[:, :, 1:k+1]: the k nearest after the first entry (the point itself, distance 0)
+        nbr = inpatch_knn(xyz.detach().float(), k)[:, :, 1:].to(torch.int64)
+        full = pred_normals.unsqueeze(1).expand(B, N, 3) if pred_normals.dim() == 2 else pred_normals.view(B, N, 3)
+        nb = torch.gather(full.unsqueeze(1).expand(B, N, N, 3), 2, nbr.unsqueeze(-1).expand(B, N, nbr.shape[2], 3))
+        loss = loss + consistency_weight * (1 - F.cosine_similarity(full.unsqueeze(2), nb, dim=-1)).mean()
+    return loss, conf.mean()

@@ -136,10 +136,12 @@ int sapcu_conv1x1_wgrad_f32(const float* grad_y, int ldy, const float* x, int ld
 /* Per-channel softmax over the k neighbours + weighted aggregation (fn/snn_coder.py:379-389), as its own differentiable op:
  *   res[pt, c] = sum_j softmax_j(a[pt, j, c] / sqrt_hd) * (v[nbr(pt, j), c] + pe[pt, j, c])
  * a, pe, grad_a, grad_pe: [pts*kk, d] (edge rows); v, grad_v: [pts, ld] rows; idx [pts*kk] = in-patch neighbour indices,
- * m points per patch (pts % m == 0).  The backward zeroes grad_v[., 0:d] and accumulates with float atomics. */
-int sapcu_softmax_agg_forward(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx, int64_t pts,
-                              int m, int kk, int d, float sqrt_hd, float* res, void* stream);
-int sapcu_softmax_agg_backward(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx,
+ * m points per patch (pts % m == 0).  keep: NULL, or [pts*kk, d] holding 0 or 1/(1-p) — the attention dropout of train()
+ * mode applied to the softmax weights (fn/snn_coder.py:383); the caller draws it.  The backward zeroes grad_v[., 0:d] and
+ * accumulates with float atomics. */
+int sapcu_softmax_agg_forward(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx, const float* keep,
+                              int64_t pts, int m, int kk, int d, float sqrt_hd, float* res, void* stream);
+int sapcu_softmax_agg_backward(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx, const float* keep,
                                const float* grad_res, int64_t pts, int m, int kk, int d, float sqrt_hd,
                                float* grad_a, float* grad_pe, float* grad_v, int ldgv, void* stream);
 

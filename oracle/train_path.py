@@ -133,3 +133,18 @@ def angular_loss(pred, gt, temperature=0.1, alpha=0.1):
     err = torch.acos(torch.clamp(cos, -1 + 1e-6, 1 - 1e-6))
     conf = torch.sigmoid(err.detach() / temperature)
     return (err * conf + alpha * (conf - 0.5) ** 2).mean()
+
+
+def angular_loss_with_consistency(pred, gt, xyz, temperature=0.1, alpha=0.1, consistency_weight=0.15, k_neighbors=8):
+    """enhanced_angular_loss_with_consistency with its consistency term (fn/snn_coder.py:557-625): pred/gt [B, N, 3] or [B, 3],
+    xyz [B, N, 3] -> (loss, mean confidence)."""
+    F = torch.nn.functional
+    base = angular_loss(pred.reshape(-1, 3), gt.reshape(-1, 3), temperature, alpha)
+    cos = F.cosine_similarity(pred.reshape(-1, 3), gt.reshape(-1, 3), dim=1)
+    conf = torch.sigmoid(torch.acos(torch.clamp(cos, -1 + 1e-6, 1 - 1e-6)).detach() / temperature).mean()
+    B, N, _ = xyz.shape
+    d = ((xyz[:, :, None, :] - xyz[:, None, :, :]) ** 2).sum(-1)
+    nbr = d.argsort()[:, :, 1:k_neighbors + 1]
+    full = pred.unsqueeze(1).expand(B, N, 3) if pred.dim() == 2 else pred.view(B, N, 3)
+    nb = torch.gather(full.unsqueeze(1).expand(B, N, N, 3), 2, nbr.unsqueeze(-1).expand(B, N, nbr.shape[2], 3))
+    return base + consistency_weight * (1 - F.cosine_similarity(full.unsqueeze(2), nb, dim=-1)).mean(), conf

@@ -321,6 +321,77 @@ def fn_train_fixture():
     save("fn_train.npz", **out)
 
 
+def fn_trainer_fixture():
+    """One ``Trainer.train_step`` of the reference (fn/trainer.py:41-148) on a 4-D batch [B, patches, points, 3] — the shape
+    its data loader yields — with plain SGD (lr 1e-3) and grad_clip 0.15 ('norm'), dropout off: the returned loss and
+    confidence, every BatchNorm running statistic after the step, and the parameter UPDATE (new - old; tensors above 1024
+    elements as a seeded sample of 256 entries plus the L2 norm of the whole update).  Exercises the 4-D path, the
+    consistency term of the loss (fn:557-583), global-norm clipping and the BatchNorm bookkeeping."""
+    from fn import trainer as ref_trainer
+    from oracle import train_path as TP
+    B, NP, M = 2, 8, 12
+    # Hard spikes make the forward discontinuous: an input whose pre-activation lies within f32 rounding of a threshold gives
+    # different spikes under ANY reordering of the sums (torch CPU vs GPU included).  Take the first input seed for which
+    # the oracle's differently-ordered f32 arithmetic reproduces the reference's normals, i.e. one away from every threshold.
+    for data_seed in range(41, 80):
+        rng = np.random.default_rng(data_seed)
+        torch.manual_seed(data_seed)
+        model = ref_fn.ImprovedSNNNormalEstimation(**FN_KW)
+        model.load_state_dict(T.training_state_dict(model.state_dict(), 7), strict=True)
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        centres = rng.normal(size=(B, NP, 1, 3)) * 0.4
+        pts = torch.tensor((centres + rng.normal(size=(B, NP, M, 3)) * np.array([0.08, 0.08, 0.01])).astype(np.float32))
+        gt = torch.tensor(rng.normal(size=(B, NP, 3)).astype(np.float32))
+        model.train()
+        with torch.no_grad():
+            flat = pts.reshape(B * NP, M, 3)
+            d2 = ((flat[:, :, None, :] - flat[:, None, :, :]) ** 2).sum(-1)
+            knn = [d2.topk(min(k, M), dim=-1, largest=False)[1] for k in FN_KW["k_values"]]
+            mine = TP.fn_train_forward({n: v.detach() for n, v in model.named_parameters()}, flat, knn)
+            # (the probe forward below must not leave its BatchNorm statistics behind: rebuild the model afterwards)
+            theirs = model(pts).reshape(B * NP, 3)
+        gap = float((mine - theirs).abs().max())
+        print("data seed %d: oracle vs reference normals %.2e" % (data_seed, gap))
+        if gap < 1e-5:
+            break
+    else:
+        raise RuntimeError("no well-conditioned input found")
+    model = ref_fn.ImprovedSNNNormalEstimation(**FN_KW)
+    model.load_state_dict(T.training_state_dict(model.state_dict(), 7), strict=True)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    old = {n: prm.detach().clone() for n, prm in model.named_parameters()}
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+    tr = ref_trainer.Trainer(model, opt, device=torch.device("cpu"), grad_clip=0.15, grad_clip_type="norm")
+    loss_value, loss_dict = tr.train_step({"input": pts, "normal": gt})
+    assert loss_value is not None
+    out = {"points": npy(pts), "gt": npy(gt), "loss": np.float64(loss_value), "confidence": np.float64(loss_dict["confidence"]),
+           "seed": np.int64(7), "lr": np.float64(1e-3), "grad_clip": np.float64(0.15)}
+    names = []
+    for n, prm in model.named_parameters():
+        d = (prm.detach() - old[n]).numpy().ravel()
+        names.append(n)
+        if d.size <= 1024:
+            out["d:" + n] = d.reshape(tuple(prm.shape))
+        else:
+            sel = np.sort(np.random.default_rng(zlib.crc32(n.encode())).choice(d.size, 256, replace=False))
+            out["di:" + n] = sel.astype(np.int64)
+            out["ds:" + n] = d[sel]
+            out["dn:" + n] = np.float64(np.linalg.norm(d.astype(np.float64)))
+    out["names"] = np.array(names)
+    bufs = []
+    for n, b in model.named_buffers():
+        if n.endswith("running_mean") or n.endswith("running_var") or n.endswith("num_batches_tracked"):
+            out["b:" + n] = npy(b)
+            bufs.append(n)
+    out["buffers"] = np.array(bufs)
+    print("fn trainer step: loss %.6f confidence %.4f" % (loss_value, loss_dict["confidence"]))
+    save("fn_trainer.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-e2e", action="store_true")
@@ -340,6 +411,7 @@ def main():
         return
     if args.only_fn_train:
         fn_train_fixture()
+        fn_trainer_fixture()
         return
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -513,6 +585,7 @@ def main():
     fps_fixture()
     neuron_train_fixture()
     fn_train_fixture()
+    fn_trainer_fixture()
 
     # ---- 10. end-to-end Generator3D6.upsample on sphere N=2048, dense_spacing 0.03 (~900 seeds)
     if not args.skip_e2e:

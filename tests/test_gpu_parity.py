@@ -911,3 +911,71 @@ def test_training_step_of_whole_fn_model_against_reference_run():
     assert abs(float(loss.detach()) - float(g["loss"])) <= 2e-4
     loss.backward()
     check_fn_train_grads(g, p, names, 2e-2, 5e-5)
+
+
+def test_training_softmax_aggregate_with_attention_dropout():
+    """The attention dropout of train() mode (fn:383) inside the softmax-aggregate op: forward and the three gradients with a
+    given keep mask against the same composition in torch autograd."""
+    from sapcu_amd import train
+    rng = np.random.default_rng(9)
+    B, N, k, d, H = 3, 16, 6, 64, 8
+    P = B * N
+    a, pe = (torch.tensor(rng.normal(size=(P * k, d)).astype(np.float32)) for _ in range(2))
+    v = torch.tensor(rng.normal(size=(P, d)).astype(np.float32))
+    idx = torch.tensor(rng.integers(0, N, (P * k,)).astype(np.int32))
+    go = torch.tensor(rng.normal(size=(P, d)).astype(np.float32))
+    keep = train.dropout_keep((P * k, d), 0.3, "cuda")
+    assert set(np.unique(keep.cpu().numpy()).round(5)) <= {0.0, np.float32(1 / 0.7).round(5)}
+    assert 0.2 < float((keep == 0).float().mean()) < 0.4
+    dv = [x.cuda().requires_grad_(True) for x in (a, pe, v)]
+    out = train.softmax_agg(*dv, idx.cuda(), N, float((d // H) ** 0.5), keep)
+    out.backward(go.cuda())
+    hv = [x.clone().requires_grad_(True) for x in (a, pe, v)]
+    w = torch.softmax(hv[0].view(P, k, d) / float((d // H) ** 0.5), dim=1) * keep.cpu().view(P, k, d)
+    nb = (idx.view(P, k).to(torch.int64) + (torch.arange(P) // N * N).view(P, 1))
+    ref = (w * (hv[2][nb] + hv[1].view(P, k, d))).sum(1)
+    ref.backward(go)
+    assert (out.detach().cpu() - ref.detach()).abs().max() <= 1e-5
+    for dd, hh in zip(dv, hv):
+        assert (dd.grad.cpu() - hh.grad).abs().max() <= 1e-5 * max(1.0, float(hh.grad.abs().max()))
+
+
+def test_fn_trainer_step_against_reference_trainer_run():
+    """Row f-4: sapcu_amd.fn_trainer.Trainer.train_step on the drop-in model in train() mode (dropout off) against the
+    reference Trainer's own step: returned loss and confidence, every parameter update after global-norm clipping + SGD, and
+    every BatchNorm running statistic (tests/golden/fn_trainer.npz); then the model goes back to eval() and infers."""
+    import sapcu_amd
+    from sapcu_amd import fn_trainer, testing as T
+    from test_oracle_golden import check_fn_trainer_updates
+    g = golden("fn_trainer.npz")
+    model = sapcu_amd.ImprovedSNNNormalEstimation(k_values=[24, 18, 12], emb_dims=640, time_steps_enc=4, time_steps_dec=12, num_heads=8,
+                                                  use_snn_decoder=False, decoder_dropout=0.1)
+    model.load_state_dict(T.training_state_dict(model.state_dict(), int(g["seed"])), strict=True)
+    model.attn_dropout = model.decoder_dropout = 0.0
+    model.cuda()
+    names = [str(n) for n in g["names"]]
+    old = {n: prm.detach().clone() for n, prm in model.named_parameters()}
+    opt = torch.optim.SGD(model.parameters(), lr=float(g["lr"]))
+    tr = fn_trainer.Trainer(model, opt, device=torch.device("cuda"), grad_clip=float(g["grad_clip"]), grad_clip_type="norm")
+    loss, loss_dict = tr.train_step({"input": torch.from_numpy(g["points"]), "normal": torch.from_numpy(g["gt"])})
+    assert loss is not None and abs(loss - float(g["loss"])) <= 2e-4 and abs(loss_dict["confidence"] - float(g["confidence"])) <= 2e-4
+    check_fn_trainer_updates(g, dict(model.named_parameters()), old, names, 3e-2, 1e-4)
+    bufs = dict(model.named_buffers())
+    for n in g["buffers"]:
+        n = str(n)
+        ref = torch.from_numpy(np.asarray(g["b:" + n]))
+        got = bufs[n].cpu()
+        if n.endswith("num_batches_tracked"):
+            assert int(got) == int(ref) == 1
+        else:
+            assert (got - ref).abs().max() <= 2e-5 * max(1.0, float(ref.abs().max())), n
+    assert all(prm.grad is None or float(prm.grad.abs().max()) == 0.0 for prm in model.parameters())      # zero_grad ran
+    # with dropout on, a step still runs and is finite; afterwards eval() re-packs the updated parameters and infers
+    model.attn_dropout, model.decoder_dropout = 0.1, 0.1
+    loss2, _ = tr.train_step({"input": torch.from_numpy(g["points"]), "normal": torch.from_numpy(g["gt"])})
+    assert loss2 is not None and np.isfinite(loss2)
+    model.eval()
+    with torch.no_grad():
+        n_eval = model(torch.from_numpy(g["points"]).cuda())
+    assert n_eval.shape == (2, 8, 3) and bool(torch.isfinite(n_eval).all())
+    assert (n_eval.norm(dim=-1) - 1).abs().max() <= 1e-5

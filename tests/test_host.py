@@ -65,10 +65,14 @@ def test_constructor_and_forward_error_conventions():
         m(torch.zeros(2, 48, 4))                 # not xyz
     with pytest.raises(RuntimeError):
         m(torch.zeros(2, 48, 3))                 # CPU tensors: no CPU path
-    with pytest.raises(NotImplementedError):
-        m.train()
+    m.train()                                    # fn has a training path (row f-4) ...
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 48, 3))                 # ... which has no CPU path either
     m.reset_states()
     m.eval()
+    assert not m.training
+    with pytest.raises(NotImplementedError):
+        sapcu_amd.EnhancedSNNDistanceEstimation(**FD_KW).train()     # fd is inference-only
 
 
 def test_packer_slot_tables(weights):

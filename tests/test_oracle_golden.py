@@ -314,6 +314,52 @@ def test_fn_training_step_matches_reference():
     normals = TP.fn_train_forward(p, t(g["points"]), knn)
     np.testing.assert_allclose(normals.detach().numpy(), g["normals"], rtol=0, atol=2e-4)
     loss = TP.angular_loss(normals, t(g["gt"]))
-    assert abs(float(loss) - float(g["loss"])) <= 2e-4
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 2e-4
     loss.backward()
     check_fn_train_grads(g, p, names, 1e-2, 2e-5)
+
+
+def check_fn_trainer_updates(g, new, old, names, tol, floor_rel):
+    """Parameter updates (new - old) against the fixture's: full tensors, or the stored sample + L2 norm."""
+    peak = max(float(np.abs(g[("d:" if ("d:" + n) in g else "ds:") + n]).max()) for n in names)
+    floor = floor_rel * peak
+    for n in names:
+        got = (new[n].detach().cpu().double() - old[n].detach().cpu().double()).numpy().ravel()
+        if ("d:" + n) in g:
+            ref = g["d:" + n].ravel()
+        else:
+            ref = g["ds:" + n]
+            assert abs(float(np.linalg.norm(got)) - float(g["dn:" + n])) <= tol * float(g["dn:" + n]) + floor, n
+            got = got[g["di:" + n]]
+        # f32 parameters: an update far below the parameter's own ulp is rounded away on both sides
+        ulp = float(np.abs(old[n].detach().cpu().numpy()).max()) * 1.2e-7
+        assert float(np.abs(got - ref).max()) <= tol * float(np.abs(ref).max()) + floor + ulp, (n, float(np.abs(got - ref).max()))
+
+
+def test_fn_trainer_step_matches_reference():
+    """Row f-4: the reference Trainer's train_step (4-D batch, consistency loss, global-norm clipping, SGD) restated with the
+    oracle's forward: loss, confidence and every parameter update (tests/golden/fn_trainer.npz)."""
+    import sapcu_amd
+    from sapcu_amd import testing as T
+    from oracle import train_path as TP
+    g = golden("fn_trainer.npz")
+    shell = sapcu_amd.ImprovedSNNNormalEstimation(k_values=[24, 18, 12], emb_dims=640, time_steps_enc=4, time_steps_dec=12, num_heads=8,
+                                                  use_snn_decoder=False, decoder_dropout=0.1)
+    sd = T.training_state_dict(shell.state_dict(), int(g["seed"]))
+    names = [str(n) for n in g["names"]]
+    p = {n: sd[n].clone().requires_grad_(True) for n in names}
+    pts = t(g["points"])
+    B, NP, M, _ = pts.shape
+    flat = pts.reshape(B * NP, M, 3)
+    d = ((flat[:, :, None, :] - flat[:, None, :, :]) ** 2).sum(-1)
+    knn = [d.topk(min(k, M), dim=-1, largest=False)[1] for k in (24, 18, 12)]
+    pred = torch.nn.functional.normalize(TP.fn_train_forward(p, flat, knn).view(B, NP, 3), dim=-1)
+    gt = torch.nn.functional.normalize(t(g["gt"]), dim=-1)
+    loss, conf = TP.angular_loss_with_consistency(pred, gt, pts.mean(dim=2))
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 2e-4 and abs(float(conf) - float(g["confidence"])) <= 2e-4
+    loss.backward()
+    grads = [p[n].grad if p[n].grad is not None else torch.zeros_like(p[n]) for n in names]
+    total = torch.sqrt(sum((gr.double() ** 2).sum() for gr in grads))
+    coef = min(1.0, float(g["grad_clip"]) / (float(total) + 1e-6))
+    new = {n: (p[n].detach() - float(g["lr"]) * coef * gr) for n, gr in zip(names, grads)}
+    check_fn_trainer_updates(g, new, {n: p[n] for n in names}, names, 2e-2, 5e-5)
