@@ -189,10 +189,22 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
 #ifndef SAPCU_ABL_NO_DMA       // (compute-only experiment: the rings are never refilled)
             lds_byte* sb = ring0 + issue_slot * ROPSLOT;
             const char* src = pf_base + pf_kt * (RBK * 2);
+#ifdef SAPCU_ABL_A_CONTIG   // DRAM-locality experiment (garbage results): a k-step's activation slot is read as ONE contiguous
+                            // 16 KiB run of the tile's region (what a tiled activation layout would give) instead of 128 x 2 x 64 B
+            if (is_a) {
+                const char* s0 = pf_base + (int64_t)pf_kt * ROPSLOT + sub * 2048 + lane * 16;
+                __builtin_amdgcn_global_load_lds((gptr_t)(s0), sb, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(s0 + 1024), sb + 1024, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(s0 + RPLANE), sb + RPLANE, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(s0 + RPLANE + 1024), sb + RPLANE + 1024, 16, 0, 0);
+            } else
+#endif
+            {
             __builtin_amdgcn_global_load_lds((gptr_t)(src + pf_off0), sb, 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(src + pf_off1), sb + 1024, 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(src + lo_delta + pf_off0), sb + RPLANE, 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(src + lo_delta + pf_off1), sb + RPLANE + 1024, 16, 0, 0);
+            }
 #endif
             ++issued;
             if (++issue_slot == depth) issue_slot = 0;

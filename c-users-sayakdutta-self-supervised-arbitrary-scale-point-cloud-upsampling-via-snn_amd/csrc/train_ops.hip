@@ -42,9 +42,13 @@ struct StepRec {      // what the reverse sweep needs from one forward step
     float gate;       // (r <= 0)
 };
 
-__device__ __forceinline__ float train_forward(float x, const TrainP& p, int T, StepRec (&rec)[LT_MAX_T]) {
+// TT = number of steps at compile time: the loops unroll and rec[] stays in registers (a run-time trip count would put it
+// in scratch memory).
+template <int TT>
+__device__ __forceinline__ float train_forward(float x, const TrainP& p, StepRec (&rec)[TT]) {
     float m = 0.f, r = 0.f, th = p.theta0, in = x, sp = 0.f;
-    for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
         StepRec& q = rec[t];
         q.m = m; q.r = r; q.th = th;
         q.gate = r <= 0.f ? 1.f : 0.f;
@@ -61,19 +65,21 @@ __device__ __forceinline__ float train_forward(float x, const TrainP& p, int T, 
     return sp;
 }
 
-__global__ __launch_bounds__(256) void lif_train_fwd_kernel(const float* __restrict__ x, int64_t rows, int ch, int T,
+template <int TT>
+__global__ __launch_bounds__(256) void lif_train_fwd_kernel(const float* __restrict__ x, int64_t rows, int ch,
                                                             const float* md, const float* ta, const float* rd, const float* tb,
                                                             float* __restrict__ spikes) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= rows * ch) return;
     const TrainP p = load_train_params(md, ta, rd, tb, (int)(t % ch));
-    StepRec rec[LT_MAX_T];
-    spikes[t] = train_forward(x[t], p, T, rec);
+    StepRec rec[TT];
+    spikes[t] = train_forward<TT>(x[t], p, rec);
 }
 
 // grid: (ceil(rows / 64), ceil(ch / 64)); thread (slab = tid >> 6, lane = tid & 63) walks rows slab*16 .. +16 of its column
+template <int TT>
 __global__ __launch_bounds__(256) void lif_train_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gout,
-                                                            int64_t rows, int ch, int T, const float* md, const float* ta,
+                                                            int64_t rows, int ch, const float* md, const float* ta,
                                                             const float* rd, const float* tb, float* __restrict__ gx,
                                                             float* __restrict__ partial /*[gridDim.x][4][ch]*/) {
     __shared__ float red[4][4][64];
@@ -84,14 +90,23 @@ __global__ __launch_bounds__(256) void lif_train_bwd_kernel(const float* __restr
     if (live) {
         const TrainP p = load_train_params(md, ta, rd, tb, c);
         const int64_t row0 = (int64_t)blockIdx.x * LT_ROWS_PER_WG + slab * 16;
+        float xv[16], gv[16];                             // all 32 loads in flight before the first dependent use
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool ok = row0 + i < rows;
+            xv[i] = ok ? x[(row0 + i) * ch + c] : 0.f;
+            gv[i] = ok ? gout[(row0 + i) * ch + c] : 0.f;
+        }
+#pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int64_t row = row0 + i;
             if (row >= rows) break;
-            StepRec rec[LT_MAX_T];
-            train_forward(x[row * ch + c], p, T, rec);
+            StepRec rec[TT];
+            train_forward<TT>(xv[i], p, rec);
             // reverse sweep; adjoints of the state AFTER step t
-            float a_sp = gout[row * ch + c], a_m = 0.f, a_r = 0.f, a_th = 0.f;
-            for (int t = T - 1; t >= 0; --t) {
+            float a_sp = gv[i], a_m = 0.f, a_r = 0.f, a_th = 0.f;
+#pragma unroll
+            for (int t = TT - 1; t >= 0; --t) {
                 const StepRec& q = rec[t];
                 // th' = theta0 + ((th + adapt*sp) - theta0) * 0.95
                 const float a_tht = 0.95f * a_th;
@@ -136,21 +151,41 @@ __global__ __launch_bounds__(256) void lif_train_bwd_kernel(const float* __restr
     }
 }
 
-// sums the per-workgroup partials in ascending order and applies the clamp masks of the raw parameters
+// sums the per-workgroup partials and applies the clamp masks of the raw parameters.  Workgroup = 64 channels x 4 lanes:
+// lane g adds partials g, g+4, ... in ascending order, the four lane sums are added in the order g = 0..3 (deterministic).
 __global__ __launch_bounds__(256) void lif_train_param_reduce_kernel(const float* __restrict__ partial, int64_t nblocks, int ch,
                                                                      const float* md, const float* ta, const float* rd,
                                                                      float* __restrict__ g_md, float* __restrict__ g_ta,
                                                                      float* __restrict__ g_rd, float* __restrict__ g_tb) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ch) return;
+    __shared__ float red[4][4][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool live = c < ch;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t b = 0; b < nblocks; ++b)
+    if (live) {
+        for (int64_t b = g; b < nblocks; b += 16) {
+            float v[4][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) s[q] += partial[(b * 4 + q) * ch + c];
-    g_md[c] = (md[c] >= 0.1f && md[c] <= 0.99f) ? s[0] : 0.f;
-    g_ta[c] = (ta[c] >= 0.001f && ta[c] <= 0.1f) ? s[1] : 0.f;
-    g_rd[c] = (rd[c] >= 0.1f && rd[c] <= 0.95f) ? s[2] : 0.f;
-    g_tb[c] = s[3];
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[i][q] = (b + 4 * i < nblocks) ? partial[((b + 4 * i) * 4 + q) * ch + c] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s[q] += v[i][q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[g][q][lane] = s[q];
+    __syncthreads();
+    if (g == 0 && live) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = ((red[0][q][lane] + red[1][q][lane]) + red[2][q][lane]) + red[3][q][lane];
+        g_md[c] = (md[c] >= 0.1f && md[c] <= 0.99f) ? s[0] : 0.f;
+        g_ta[c] = (ta[c] >= 0.001f && ta[c] <= 0.1f) ? s[1] : 0.f;
+        g_rd[c] = (rd[c] >= 0.1f && rd[c] <= 0.95f) ? s[2] : 0.f;
+        g_tb[c] = s[3];
+    }
 }
 
 // =============================================================================================
@@ -163,37 +198,77 @@ constexpr int CR_ROWS = 256;     // rows per workgroup of the column reductions
 
 // partial[b][q][c] (f64), q = 0: sum of u(row,c), q = 1: sum of u*v.   MODE 0: u = a, v = a (sum, sum of squares)
 //                                                                    MODE 1: u = a (= dz), v = (b - mean) * invstd (= y_hat)
+// Workgroup = 64 channels x 4 row lanes: thread (g = tid >> 6, lane = tid & 63) sums rows r0+g, r0+g+4, ... of its channel
+// (8 loads in flight per round), the 4 lanes' sums are added in the order g = 0..3 through LDS.
 template <int MODE>
 __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t rows,
                                                           int ch, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           double* __restrict__ partial) {
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= ch) return;
+    __shared__ double red[2][4][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    const bool live = c < ch;
     const int64_t r0 = (int64_t)blockIdx.x * CR_ROWS;
     const int64_t r1 = r0 + CR_ROWS < rows ? r0 + CR_ROWS : rows;
-    const float mu = MODE == 1 ? mean[c] : 0.f, is = MODE == 1 ? invstd[c] : 0.f;
     double s0 = 0.0, s1 = 0.0;
-    for (int64_t r = r0; r < r1; ++r) {
-        const float u = a[r * ch + c];
-        const float v = MODE == 0 ? u : (b[r * ch + c] - mu) * is;
-        s0 += (double)u;
-        s1 += (double)u * (double)v;
+    if (live) {
+        const float mu = MODE == 1 ? mean[c] : 0.f, is = MODE == 1 ? invstd[c] : 0.f;
+        for (int64_t r = r0 + g; r < r1; r += 32) {
+            float u[8], w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t rr = r + 4 * i;
+                u[i] = rr < r1 ? a[rr * ch + c] : 0.f;
+                w[i] = (MODE == 1 && rr < r1) ? b[rr * ch + c] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (r + 4 * i >= r1) break;
+                const float v = MODE == 0 ? u[i] : (w[i] - mu) * is;
+                s0 += (double)u[i];
+                s1 += (double)u[i] * (double)v;
+            }
+        }
     }
-    partial[((int64_t)blockIdx.x * 2 + 0) * ch + c] = s0;
-    partial[((int64_t)blockIdx.x * 2 + 1) * ch + c] = s1;
+    red[0][g][lane] = s0;
+    red[1][g][lane] = s1;
+    __syncthreads();
+    if (g == 0 && live) {
+        partial[((int64_t)blockIdx.x * 2 + 0) * ch + c] = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
+        partial[((int64_t)blockIdx.x * 2 + 1) * ch + c] = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
+    }
 }
 
 __global__ __launch_bounds__(256) void col_final_kernel(const double* __restrict__ partial, int64_t nb, int ch,
                                                         double* __restrict__ sums /*[2][ch]*/) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= ch) return;
+    __shared__ double red[2][4][64];                     // 64 channels x 4 lanes, lane sums combined in the order g = 0..3
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool live = c < ch;
     double s0 = 0.0, s1 = 0.0;
-    for (int64_t b = 0; b < nb; ++b) {
-        s0 += partial[(b * 2 + 0) * ch + c];
-        s1 += partial[(b * 2 + 1) * ch + c];
+    if (live) {
+        for (int64_t b = g; b < nb; b += 16) {
+            double u[4], w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = b + 4 * i < nb;
+                u[i] = ok ? partial[((b + 4 * i) * 2 + 0) * ch + c] : 0.0;
+                w[i] = ok ? partial[((b + 4 * i) * 2 + 1) * ch + c] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s0 += u[i];
+                s1 += w[i];
+            }
+        }
     }
-    sums[c] = s0;
-    sums[ch + c] = s1;
+    red[0][g][lane] = s0;
+    red[1][g][lane] = s1;
+    __syncthreads();
+    if (g == 0 && live) {
+        sums[c] = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
+        sums[ch + c] = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_train_apply_kernel(const float* __restrict__ y, int64_t rows, int ch,
@@ -256,12 +331,17 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(const float* __restr
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     const bool nok = nn < n, kok = kc < k;
-    for (int64_t r = r0; r < r1; r += 2) {
-        const int64_t rr = r + par;
-        const bool rok = rr < r1;
-        const float av = (rok && nok) ? dy[rr * ldy + nn] : 0.f;
-        const float bv = (rok && kok) ? x[rr * ldx + kc] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    for (int64_t r = r0; r < r1; r += 16) {               // 8 row pairs per round: 16 loads in flight ahead of the 8 MFMAs
+        float av[8], bv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t rr = r + 2 * i + par;
+            const bool rok = rr < r1;
+            av[i] = (rok && nok) ? dy[rr * ldy + nn] : 0.f;
+            bv[i] = (rok && kok) ? x[rr * ldx + kc] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
     }
     // accumulator layout: lane = column (k index within the block) + 32 * h, register e = row (e&3) + 8*(e>>2) + 4h (n index)
     float* out = partial + (int64_t)blockIdx.z * n * k;
@@ -288,8 +368,8 @@ __global__ __launch_bounds__(256) void colsum_to_float_kernel(const double* __re
 }
 
 static int64_t col_blocks(int64_t rows) { return rows > 0 ? (rows + CR_ROWS - 1) / CR_ROWS : 0; }
-static int wgrad_slabs(int64_t rows) {
-    int64_t s = (rows + 8191) / 8192;
+static int wgrad_slabs(int64_t rows) {                       // ~1024 rows per slab: enough workgroups at training batch sizes
+    int64_t s = (rows + 1023) / 1024;
     return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
 }
 
@@ -432,8 +512,15 @@ int sapcu_lif_train_forward(const float* x, int64_t rows, int channels, int step
     SAPCU_CHECK_ARG(rows >= 0 && channels >= 1 && steps >= 1 && steps <= LT_MAX_T, "lif_train_forward: need 1 <= steps <= %d", LT_MAX_T);
     const int64_t total = rows * channels;
     if (total == 0) return SAPCU_OK;
-    hipLaunchKernelGGL(lif_train_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, rows,
-                       channels, steps, membrane_decay, threshold_adapt, refractory_decay, threshold_base, spikes_out);
+#define SAPCU_LT_FWD(TT)                                                                                                       \
+    case TT:                                                                                                                   \
+        hipLaunchKernelGGL(lif_train_fwd_kernel<TT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, \
+                           rows, channels, membrane_decay, threshold_adapt, refractory_decay, threshold_base, spikes_out);     \
+        break;
+    switch (steps) {
+        SAPCU_LT_FWD(1) SAPCU_LT_FWD(2) SAPCU_LT_FWD(3) SAPCU_LT_FWD(4) SAPCU_LT_FWD(5) SAPCU_LT_FWD(6) SAPCU_LT_FWD(7) SAPCU_LT_FWD(8)
+    }
+#undef SAPCU_LT_FWD
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
 }
@@ -461,12 +548,19 @@ int sapcu_lif_train_backward(const float* x, const float* grad_spikes, int64_t r
     const int64_t nb = (rows + LT_ROWS_PER_WG - 1) / LT_ROWS_PER_WG;
     if (nb > 0) {
         SAPCU_CHECK_ARG(nb < 0x7fffffffLL, "lif_train_backward: too many rows");
-        hipLaunchKernelGGL(lif_train_bwd_kernel, dim3((unsigned)nb, (unsigned)((channels + 63) / 64)), dim3(256), 0,
-                           (hipStream_t)stream, x, grad_spikes, rows, channels, steps, membrane_decay, threshold_adapt,
-                           refractory_decay, threshold_base, grad_x, (float*)workspace);
+#define SAPCU_LT_BWD(TT)                                                                                                       \
+    case TT:                                                                                                                   \
+        hipLaunchKernelGGL(lif_train_bwd_kernel<TT>, dim3((unsigned)nb, (unsigned)((channels + 63) / 64)), dim3(256), 0,           \
+                           (hipStream_t)stream, x, grad_spikes, rows, channels, membrane_decay, threshold_adapt,               \
+                           refractory_decay, threshold_base, grad_x, (float*)workspace);                                       \
+        break;
+        switch (steps) {
+            SAPCU_LT_BWD(1) SAPCU_LT_BWD(2) SAPCU_LT_BWD(3) SAPCU_LT_BWD(4) SAPCU_LT_BWD(5) SAPCU_LT_BWD(6) SAPCU_LT_BWD(7) SAPCU_LT_BWD(8)
+        }
+#undef SAPCU_LT_BWD
         SAPCU_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(lif_train_param_reduce_kernel, dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(lif_train_param_reduce_kernel, dim3((unsigned)((channels + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, nb, channels, membrane_decay, threshold_adapt, refractory_decay,
                        grad_membrane_decay, grad_threshold_adapt, grad_refractory_decay, grad_threshold_base);
     SAPCU_CHECK_LAUNCH();
@@ -486,13 +580,13 @@ static int column_sums(int mode, const float* a, const float* b, int64_t rows, i
     const int64_t nb = col_blocks(rows);
     double* partial = ws;
     double* sums = ws + nb * 2 * (int64_t)ch;
-    const dim3 grid((unsigned)(nb > 0 ? nb : 1), (unsigned)((ch + 255) / 256));
+    const dim3 grid((unsigned)(nb > 0 ? nb : 1), (unsigned)((ch + 63) / 64));
     if (nb > 0) {
         if (mode == 0) hipLaunchKernelGGL(col_partial_kernel<0>, grid, dim3(256), 0, st, a, b, rows, ch, mean, invstd, partial);
         else hipLaunchKernelGGL(col_partial_kernel<1>, grid, dim3(256), 0, st, a, b, rows, ch, mean, invstd, partial);
         SAPCU_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(col_final_kernel, dim3((unsigned)((ch + 255) / 256)), dim3(256), 0, st, partial, nb, ch, sums);
+    hipLaunchKernelGGL(col_final_kernel, dim3((unsigned)((ch + 63) / 64)), dim3(256), 0, st, partial, nb, ch, sums);
     SAPCU_CHECK_LAUNCH();
     *sums_out = sums;
     return SAPCU_OK;

@@ -56,17 +56,22 @@ class Trainer:
         amp = self.use_amp and self.scaler is not None
         (self.scaler.scale(scaled) if amp else scaled).backward()
         if self.accumulation_step % self.gradient_accumulation == 0:
+            total = None
             if self.grad_clip is not None:
                 if amp:
                     self.scaler.unscale_(self.optimizer)
                 if self.grad_clip_type == 'norm':
-                    torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip)
+                    total = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip)
                 else:
                     torch.nn.utils.clip_grad_value_(self.model.parameters(), self.grad_clip)
-            for name, prm in self.model.named_parameters():
-                if prm.grad is not None and not self._finite(prm.grad):
-                    print("WARNING: NaN/Inf in gradient for %s" % name)
-                    return self._abort()
+            if total is None:
+                grads = [prm.grad for prm in self.model.parameters() if prm.grad is not None]
+                total = torch.stack(torch._foreach_norm(grads)).sum() if grads else torch.zeros(())
+            # the reference tests every gradient tensor for NaN/Inf (one host sync each); the global norm is finite exactly
+            # when all of them are, so one sync decides
+            if not self._finite(total):
+                print("WARNING: NaN/Inf in gradients")
+                return self._abort()
             if amp:
                 self.scaler.step(self.optimizer)
                 self.scaler.update()

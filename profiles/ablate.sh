@@ -4,6 +4,7 @@
 #   epilogue ablations   NO_GATHER  NO_C2  NO_LIF          one piece of the attention/LIF epilogue compiled out
 #   delivery / compute   NO_MFMA (DMAs, waits, barriers only)   NO_DMA (LDS reads + MFMAs, rings never refilled)
 #   latency              A_HOT (every tile reads the first row panel: all activation reads hit L2)
+#   DRAM locality        A_CONTIG (each k-step's activation slot read as one contiguous 16 KiB run), A_CONTIG_NO_MFMA
 #   tile order           CONTIG (-DSAPCU_RING_TILES_CONTIGUOUS: same speed, 3.8x the HBM fetches)
 #   stamps               STAMPS (s_memtime per producer k-step segment; read with profiles/ring_stamps.py)
 # Usage: bash profiles/ablate.sh [NAME ...]      (default: all)
@@ -21,6 +22,7 @@ for v in ${@:-NO_GATHER NO_C2 NO_LIF NO_MFMA NO_DMA A_HOT CONTIG STAMPS}; do
   case $v in
     CONTIG) build $v -DSAPCU_RING_TILES_CONTIGUOUS ;;
     STAMPS) build $v -DSAPCU_RING_STAMPS ;;
+    A_CONTIG_NO_MFMA) build $v "-DSAPCU_ABL_A_CONTIG -DSAPCU_ABL_NO_MFMA" ;;
     *)      build $v -DSAPCU_ABL_$v ;;
   esac
 done
