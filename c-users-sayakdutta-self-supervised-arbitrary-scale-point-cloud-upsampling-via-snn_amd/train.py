@@ -81,7 +81,7 @@ class _ConvBnLifTrain(torch.autograd.Function):
         dev = x.device
         x = x.contiguous()
         w = weight.detach().contiguous()
-        prm = [p.detach().contiguous() for p in (membrane_decay, threshold_adapt, refractory_decay, threshold_base)]
+        prm = [p.detach().contiguous() for p in (membrane_decay, threshold_adapt, refractory_decay, threshold_base)] if int(steps) > 0 else []
         y = torch.empty((rows, cout), dtype=torch.float32, device=dev)
         z = torch.empty_like(y)
         mean, var, invstd = (torch.empty((cout,), dtype=torch.float32, device=dev) for _ in range(3))
@@ -112,33 +112,37 @@ class _ConvBnLifTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         lib = _lib.load()
-        x, w, gamma, y, z, mean, invstd, md, ta, rd, tb = ctx.saved_tensors
+        x, w, gamma, y, z, mean, invstd, *nrn = ctx.saved_tensors
         rows, cin = x.shape
         cout = w.shape[0]
         dev = x.device
         g = grad_out.contiguous()
         dz, dy, dx = torch.empty_like(y), torch.empty_like(y), torch.empty_like(x)
-        gp = [torch.empty_like(md) for _ in range(4)]
+        gp = [None] * 4                                   # no neuron (steps == 0): the four parameter slots are placeholders
         dgamma, dbeta, dbias = (torch.empty((cout,), dtype=torch.float32, device=dev) for _ in range(3))
         dw = torch.empty_like(w)
         ws, nbytes = _ws(lib, rows, cout, cin, dev)
-        lws_bytes = int(lib.sapcu_lif_train_workspace_bytes(rows, cout))
-        lws = torch.empty((lws_bytes,), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             st = _lib.current_stream()
             if ctx.steps > 0:
+                md, ta, rd, tb = nrn
+                gp = [torch.empty_like(md) for _ in range(4)]
+                lws_bytes = int(lib.sapcu_lif_train_workspace_bytes(rows, cout))
+                lws = torch.empty((lws_bytes,), dtype=torch.uint8, device=dev)
                 _lib.check(lib.sapcu_lif_train_backward(_lib.ptr(z), _lib.ptr(g), rows, cout, ctx.steps, _lib.ptr(md), _lib.ptr(ta),
                                                         _lib.ptr(rd), _lib.ptr(tb), _lib.ptr(dz), *[_lib.ptr(t) for t in gp],
                                                         _lib.ptr(lws), lws_bytes, st))
             else:
                 dz = g
-                gp = [torch.zeros_like(md) for _ in range(4)]
             _lib.check(lib.sapcu_bn_train_backward(_lib.ptr(y), _lib.ptr(dz), rows, cout, _lib.ptr(gamma), _lib.ptr(mean),
                                                    _lib.ptr(invstd), _lib.ptr(dy), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws),
                                                    nbytes, st))
             _lib.check(lib.sapcu_conv1x1_wgrad_f32(_lib.ptr(dy), cout, _lib.ptr(x), cin, rows, cout, cin, _lib.ptr(dw),
                                                    _lib.ptr(dbias), _lib.ptr(ws), nbytes, st))
-            _gemm(lib, dy, w.t().contiguous(), None, dx)            # dx[r, cin] = dy[r, cout] . (W^T)[cin, cout]^T
+            if ctx.needs_input_grad[0]:
+                _gemm(lib, dy, w.t().contiguous(), None, dx)        # dx[r, cin] = dy[r, cout] . (W^T)[cin, cout]^T
+            else:
+                dx = None
         return (dx, dw, dbias, dgamma, dbeta, gp[0], gp[1], gp[2], gp[3], None, None, None)
 
 
@@ -202,8 +206,7 @@ def dropout_keep(shape, p, device, generator=None):
 def conv_bn_train(x, weight, bias, gamma, beta, eps=1e-5, running=None):
     """1x1 convolution + BatchNorm in training mode, no neuron (fn's fc_gamma2 / out_proj / fc2): x [rows, c_in] -> [rows, c_out]."""
     w2 = weight.reshape(weight.shape[0], -1)
-    dummy = torch.zeros((w2.shape[0],), dtype=torch.float32, device=x.device)
-    return _ConvBnLifTrain.apply(x, w2, bias, gamma, beta, dummy, dummy, dummy, dummy, 0, eps, running)
+    return _ConvBnLifTrain.apply(x, w2, bias, gamma, beta, None, None, None, None, 0, eps, running)
 
 
 class _GatherRows(torch.autograd.Function):
