@@ -1,0 +1,393 @@
+// Split-f16 MFMA GEMM on split rows, BIG-TILE version (gfx950): 256 x BN output tile per 512-thread workgroup.
+//
+//   C[r, n] = epi( A[r, k] . W[n, k]^T + bias[n] ),   A in "split rows" (gemm_epi.h), W pre-split and x16
+//
+// Same arithmetic, in the same order, as gemm_sf16_ring.hip (per k16: a_lo.w_hi, a_hi.w_lo, a_hi.w_hi into one f32
+// accumulator) — the results are bit-identical to the ring kernel's.  What changes is the shape of the work:
+//
+//   ring kernel   128x128 tile, 16 waves (8 MFMA + 8 epilogue), 128 registers per wave: every operand byte that reaches LDS
+//                 feeds 128 rows/columns of the other operand; per MFMA one 16-byte LDS fragment read per lane.
+//   this kernel   256xBN tile (BN = 256 or 128), 8 waves of 256 registers, wave tile 128 x BN/4 (4 x 2 MFMA blocks = 128
+//                 accumulator registers): half the operand bytes per flop through the DMA path and through the LDS read
+//                 port (12 fragment reads per 24 MFMAs), four times the matrix work between two barriers.  The epilogue
+//                 runs in the MFMA waves themselves: the blocks are computed TRANSPOSED (weight fragment as the first MFMA
+//                 operand), so a lane holds 4 consecutive columns of one row per register quad — the row layout of
+//                 gemm_epi.h (epilogue_row4_*: 16-byte stores and gathers) with no LDS hand-off.
+//
+// Pipeline: k-step = 32.  Waves 0-3 stream the activation operand (3 slots of 32 KiB, 2 k-steps ahead: first touches, HBM
+// latency), waves 4-7 the weight operand (2 slots, 1 step ahead, L2 hits); one stream per wave because a wave's vector-
+// memory counter completes in order.  The rings run on across tile boundaries (global step counter).  Per step:
+// fragment reads of the second k16 half -> 24 MFMAs -> own DMAs of the next step landed -> barrier -> refill the slot just
+// read -> fragment reads of the next step's first half -> 24 MFMAs.  LDS = 96 + 64 (BN = 256) KiB = all 160 KiB.
+// The epilogue's global stores also count in vmcnt: the waits after a tile boundary over-wait for them (safe: completion is
+// in order), which costs a short bubble per 256x256 tile.
+#include "common.h"
+#include "gemm_epi.h"
+
+namespace sapcu {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+
+constexpr int TBM = 256, TBK = 32;
+constexpr int TA_PLANE = TBM * TBK * 2;          // 16 KiB: [256 rows][32 halves]
+constexpr int TA_SLOT = 2 * TA_PLANE;            // hi | lo
+constexpr int TA_SLOTS = 3;
+constexpr int TW_SLOTS = 2;
+
+template <int N>
+__device__ __forceinline__ void bt_wait_vm() {
+    if (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int EPI, int BN>
+__global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    constexpr int W_PLANE = BN * TBK * 2;
+    constexpr int W_SLOT = 2 * W_PLANE;
+    constexpr int A_BYTES = TA_SLOTS * TA_SLOT;
+    constexpr int CT = BN / 128;                       // 32-column blocks per wave (wave tile = 128 x 32*CT)
+    constexpr int W_PIECES = BN / 64;                  // 16-row DMA pieces per weight wave and plane
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    const int ntn = g.n / BN;
+    const int64_t ntm = (g.r + TBM - 1) / TBM;
+    const int64_t ntiles = ntm * ntn;
+    const int nk = g.k / TBK;
+    // tile order: the column tiles of one 256-row panel run at the same time on workgroups of ONE XCD (blockIdx & 7), so the
+    // activation panel leaves HBM once (see gemm_sf16_ring.hip)
+    int64_t first_logical, my_tiles, step_tm;
+    int step_tn;
+    {
+        const int nx = gridDim.x < 8 ? 1 : 8;
+        const int xcd = nx == 1 ? 0 : (int)(blockIdx.x & 7);
+        const int wg_in_x = nx == 1 ? (int)blockIdx.x : (int)(blockIdx.x >> 3);
+        const int wgs_per_x = nx == 1 ? (int)gridDim.x : (int)((gridDim.x - xcd + 7) >> 3);
+        const int64_t qd = ntiles / nx, rem = ntiles % nx;
+        const int64_t x_begin = xcd * qd + (xcd < rem ? xcd : rem);
+        const int64_t x_count = qd + (xcd < rem ? 1 : 0);
+        my_tiles = x_count > wg_in_x ? (x_count - wg_in_x + wgs_per_x - 1) / wgs_per_x : 0;
+        first_logical = x_begin + wg_in_x;
+        step_tm = wgs_per_x / ntn;
+        step_tn = wgs_per_x - (int)step_tm * ntn;
+    }
+    if (my_tiles == 0) return;
+#ifdef SAPCU_BT_STAGGER
+    // Epilogues are write bursts (256 KiB per workgroup): started together, all 256 workgroups hit them together and the
+    // burst drains at the HBM write rate while nobody computes.  Start the workgroup pairs of an XCD in 8 phases.
+    {
+        const int phase = ((blockIdx.x >> 3) >> (ntn > 1 ? 1 : 0)) & 7;
+        for (int i = 0; i < phase * SAPCU_BT_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+    const int64_t first_tm = first_logical / ntn;
+    const int first_tn = (int)(first_logical - first_tm * ntn);
+
+    // ---- DMA role of this wave
+    const bool is_a = wave < 4;
+    const int sub = wave & 3;
+    const int dsb = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;         // source byte offset of this lane's (swizzled) LDS chunk
+    const int64_t pitch_b = is_a ? 4 * (int64_t)g.lda : 2 * (int64_t)g.k;
+    const int64_t lo_delta = is_a ? 2 * (int64_t)g.lda
+                                  : reinterpret_cast<const char*>(g.w16_lo) - reinterpret_cast<const char*>(g.w16_hi);
+    const char* const op_base = is_a ? reinterpret_cast<const char*>(g.a) : reinterpret_cast<const char*>(g.w16_hi);
+    const int pieces = is_a ? 4 : W_PIECES;                         // wave-uniform
+    const int rows_per_wave = 16 * pieces;
+    const int depth = is_a ? TA_SLOTS : TW_SLOTS;
+    const int slot_bytes = is_a ? TA_SLOT : W_SLOT;
+    const int plane_bytes = is_a ? TA_PLANE : W_PLANE;
+    const int64_t total_steps = my_tiles * nk;
+    int64_t pf_tile = 0, pf_tm = first_tm;
+    int pf_kt = 0, pf_tn = first_tn;
+    const char* pf_base = nullptr;
+    unsigned pf_off[4] = {0, 0, 0, 0};
+    const int lrow = rows_per_wave * sub + (lane >> 2);
+    auto pf_setup = [&]() {
+        const int64_t first = is_a ? pf_tm * TBM : (int64_t)pf_tn * BN;
+        const int64_t left = (is_a ? g.r : (int64_t)g.n) - first;    // >= 1
+        pf_base = op_base + first * pitch_b;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int rr = lrow + 16 * p;
+            if (rr >= left) rr = (int)(left - 1);                     // edge tile: clamped rows only feed masked outputs
+            pf_off[p] = (unsigned)(rr * (int)pitch_b + dsb);
+        }
+    };
+    lds_byte* const ring0 = (lds_byte*)(smem_raw + (is_a ? 0 : A_BYTES) + sub * rows_per_wave * 64);
+    int issue_slot = 0;
+    int64_t issued = 0;
+    auto issue = [&]() {
+        lds_byte* sb = ring0 + issue_slot * slot_bytes;
+        const char* src = pf_base + pf_kt * (TBK * 2);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (p < pieces) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + pf_off[p]), sb + p * 1024, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + lo_delta + pf_off[p]), sb + plane_bytes + p * 1024, 16, 0, 0);
+            }
+        }
+        ++issued;
+        if (++issue_slot == depth) issue_slot = 0;
+        if (++pf_kt == nk) {
+            pf_kt = 0;
+            ++pf_tile;
+            pf_tm += step_tm;
+            pf_tn += step_tn;
+            if (pf_tn >= ntn) { pf_tn -= ntn; ++pf_tm; }
+            if (pf_tile < my_tiles) pf_setup();
+        }
+    };
+    pf_setup();
+    while (issued < depth && issued < total_steps) issue();
+    // this wave's DMAs of `step` have landed: 2*pieces DMAs per step, in order
+    auto wait_landed = [&](int64_t step) {
+        const int64_t ahead = issued - step - 1;
+        if (is_a) {                                                   // 8 per step
+            if (ahead >= 2) bt_wait_vm<16>();
+            else if (ahead == 1) bt_wait_vm<8>();
+            else bt_wait_vm<0>();
+        } else if (W_PIECES == 4) {
+            if (ahead >= 1) bt_wait_vm<8>();
+            else bt_wait_vm<0>();
+        } else {
+            if (ahead >= 1) bt_wait_vm<4>();
+            else bt_wait_vm<0>();
+        }
+    };
+
+    // ---- MFMA role: fragments of the wave tile (rows wm*128 + i*32 + r32, weight rows wn*32*CT + j*32 + r32)
+    const int sw = (r32 >> 2) & 3;
+    const unsigned a_frag0 = (unsigned)((wm * 128 + r32) * (TBK * 2));
+    const unsigned w_frag0 = (unsigned)(A_BYTES + (wn * 32 * CT + r32) * (TBK * 2));
+    struct Frags {
+        half8 ah[4], al[4], wh[CT], wl[CT];
+    };
+    auto read_frags = [&](int a_slot, int w_slot, int k16, Frags& f) {
+        const unsigned ko = (unsigned)(((k16 * 2 + h) ^ sw) * 16);
+        const unsigned char* sA = smem_raw + a_slot * TA_SLOT + a_frag0 + ko;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f.ah[i] = *reinterpret_cast<const half8*>(sA + i * 32 * (TBK * 2));
+            f.al[i] = *reinterpret_cast<const half8*>(sA + i * 32 * (TBK * 2) + TA_PLANE);
+        }
+        const unsigned char* sW = smem_raw + w_slot * W_SLOT + w_frag0 + ko;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            f.wh[j] = *reinterpret_cast<const half8*>(sW + j * 32 * (TBK * 2));
+            f.wl[j] = *reinterpret_cast<const half8*>(sW + j * 32 * (TBK * 2) + W_PLANE);
+        }
+    };
+    f32x16 acc[4][CT];
+    auto mfma_all = [&](const Frags& f) {
+#ifdef SAPCU_ABL_BT_NO_MFMA   // delivery + epilogue only (diagnostic build, garbage results)
+        return;
+#endif
+        // same product order per accumulator as the ring kernel (a_lo.w_hi, a_hi.w_lo, a_hi.w_hi); consecutive MFMAs go to
+        // different accumulators.  The WEIGHT fragment is the first MFMA operand: the block comes out transposed (lane =
+        // activation row, register quad = 4 consecutive output columns), which is the row layout of gemm_epi.h —
+        // 16-byte stores, float4 parameter loads — at no cost (both fragments have the same LDS image).
+#ifdef SAPCU_BT_ROW_LAYOUT
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wh[j], f.al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wl[j], f.ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wh[j], f.ah[i], acc[i][j], 0, 0, 0);
+#else
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.wh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.wl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.wh[j], acc[i][j], 0, 0, 0);
+#endif
+    };
+
+    wait_landed(0);
+    lds_barrier();
+    int ca = 0, cw = 0, na = 1, nw = 1;
+    Frags f0, f1;
+    int64_t gstep = 0;
+    int64_t tm = first_tm;
+    int tn = first_tn;
+    for (int64_t ti = 0; ti < my_tiles; ++ti) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        read_frags(ca, cw, 0, f0);          // (not prefetched across the tile boundary: the epilogue needs those 48 registers)
+        for (int kt = 0; kt < nk; ++kt, ++gstep) {
+            read_frags(ca, cw, 1, f1);
+            mfma_all(f0);
+            if (gstep + 1 < total_steps) {
+                wait_landed(gstep + 1);
+                lds_barrier();                                        // step gstep+1 is in for everyone; this step's slots fully read
+                if (issued < total_steps) issue();
+                if (kt + 1 < nk) read_frags(na, nw, 0, f0);
+            } else {
+                lds_barrier();
+            }
+            mfma_all(f1);
+            ca = na;
+            cw = nw;
+            if (++na == TA_SLOTS) na = 0;
+            if (++nw == TW_SLOTS) nw = 0;
+        }
+        // ---- epilogue in the accumulator layout: lane = column, register quad q = rows 8q + 4h + 0..3 of the 32x32 block
+#ifdef SAPCU_ABL_BT_NO_EPI    // k-loop only (diagnostic build: one store per tile keeps the accumulators alive)
+        if (acc[0][0][0] == 12345.678f) g.c[0] = acc[3][CT - 1][15] + acc[1][0][7] + acc[2][0][3];
+        tm += step_tm;
+        tn += step_tn;
+        if (tn >= ntn) { tn -= ntn; ++tm; }
+        continue;
+#endif
+#ifdef SAPCU_BT_ROW_LAYOUT   // transposed blocks: 16-byte stores, but only 32 contiguous bytes per row and instruction (slower)
+        const int64_t row0 = tm * TBM + wm * 128 + r32;            // this lane's row in row block i: row0 + 32 i
+        const int col0 = tn * BN + wn * 32 * CT + 4 * h;             // ... its 4 columns in (block j, quad q): col0 + 32 j + 8 q
+        int2 tabr[4];
+        if (EPI == EPI_LIF_ATTN) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tabr[i] = row0 + 32 * i < g.r ? g.tab[row0 + 32 * i] : make_int2(0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int col = col0 + 32 * j + 8 * q4;
+                const ColParams4 cp = load_col_params4<EPI, true>(g, col, true);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t row = row0 + 32 * i;
+                    if (row < g.r) {
+                        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), kv = qv;
+                        if (EPI == EPI_LIF_ATTN) {
+                            qv = ld4(g.q + (int64_t)tabr[i].x * g.ldq + col);
+                            kv = ld4(g.kf + (int64_t)tabr[i].y * g.ldq + col);
+                        }
+                        const float4 a4 = make_float4(acc[i][j][q4 * 4], acc[i][j][q4 * 4 + 1], acc[i][j][q4 * 4 + 2], acc[i][j][q4 * 4 + 3]);
+                        float v[4];
+                        epilogue_row4_compute<EPI, true>(g, a4, row, col, cp, v);
+                        epilogue_row4_store<EPI, true>(g, v, row, col, qv, kv);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);          // keep the column groups apart (register pressure: 128 accumulators live)
+            }
+        }
+#else
+        const int64_t row0 = tm * TBM + wm * 128;
+        const int col0 = tn * BN + wn * 32 * CT;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const int col = col0 + j * 32 + r32;
+            const float bias = g.bias ? g.bias[col] : 0.f;
+            NeuronP np = NeuronP{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) np = load_lif(g.lif, g.n, col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int64_t row = row0 + i * 32 + 8 * q4 + 4 * h;
+                    if (row >= g.r) continue;
+                    float a4[4], cq[4] = {0.f, 0.f, 0.f, 0.f}, ckf[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a4[u] = __fmul_rn(acc[i][j][q4 * 4 + u], 0.0625f);      // undo W x 16
+                    if (EPI == EPI_LIF_ATTN) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (row + u < g.r) {
+                                const int2 t = g.tab[row + u];
+                                cq[u] = g.q[(int64_t)t.x * g.ldq + col];
+                                ckf[u] = g.kf[(int64_t)t.y * g.ldq + col];
+                            }
+                        }
+                    }
+                    epilogue_group4<EPI>(g, a4, row, col, bias, np, cq, ckf);
+                    __builtin_amdgcn_sched_barrier(0);      // keep the groups apart (128 accumulators live)
+                }
+            }
+        }
+#endif
+        tm += step_tm;
+        tn += step_tn;
+        if (tn >= ntn) { tn -= ntn; ++tm; }
+    }
+}
+
+static int g_num_cus_bt = 0;
+
+template <int EPI, int BN>
+static int launch_bt_t(const GemmArgs& g, hipStream_t st) {
+    constexpr int LDS = TA_SLOTS * TA_SLOT + TW_SLOTS * 2 * BN * TBK * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SAPCU_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bt_kernel<EPI, BN>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    if (g_num_cus_bt == 0) {
+        int dev = 0;
+        SAPCU_CHECK_HIP(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        SAPCU_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        g_num_cus_bt = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int64_t tiles = ((g.r + TBM - 1) / TBM) * (g.n / BN);
+    const int64_t grid = tiles < g_num_cus_bt ? tiles : g_num_cus_bt;
+    hipLaunchKernelGGL((gemm_bt_kernel<EPI, BN>), dim3((unsigned)grid), dim3(512), LDS, st, g);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+// shapes this kernel takes (everything else stays on the ring kernel)
+bool gemm_sf16_bt_ok(const GemmArgs& g) {
+    if (!g.a_split || !g.w16_hi || !g.w16_lo || g.k <= 0 || g.k % TBK || g.k > g.lda || g.lda % 8) return false;
+    if (((uintptr_t)g.a & 15) || ((uintptr_t)g.w16_hi & 15) || ((uintptr_t)g.w16_lo & 15)) return false;
+    if (g.n % 128) return false;
+    if (4 * (int64_t)g.lda * TBM >= (1LL << 31)) return false;        // 32-bit per-lane DMA offsets inside a tile
+    if (g.r < 4 * TBM) return false;                                   // small launches: the 128x128 tiles fill the chip better
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };       // the row-layout epilogue works on float4s
+    if (g.ldc % 4 || !al16(g.c) || (g.bias && !al16(g.bias))) return false;
+    if ((g.epi == EPI_LIF || g.epi == EPI_LIF_ATTN) && !al16(g.lif)) return false;
+    if (g.epi == EPI_LIF_ATTN && (g.ldq % 4 || !al16(g.q) || !al16(g.kf) || !al16(g.c2))) return false;
+#ifndef SAPCU_BT_ROW_LAYOUT
+    if (g.epi == EPI_LIF_ATTN && g.n % 256 == 0) return false;      // (the 256-wide column-layout attention epilogue spills)
+#endif
+    return g.epi == EPI_BIAS || g.epi == EPI_LIF || g.epi == EPI_LIF_ATTN;
+}
+
+int launch_gemm_sf16_bt(const GemmArgs& g, hipStream_t st) {
+    if (g.r == 0 || g.n == 0) return SAPCU_OK;
+    SAPCU_CHECK_ARG(gemm_sf16_bt_ok(g), "gemm_bt: unsupported shape or epilogue");
+    if (g.epi == EPI_LIF || g.epi == EPI_LIF_ATTN) SAPCU_CHECK_ARG(g.lif, "gemm_bt: missing neuron parameters");
+    if (g.epi == EPI_LIF_ATTN) SAPCU_CHECK_ARG(g.ldq > 0 && g.tab && g.q && g.kf && g.c2, "gemm_bt: bad attn operands");
+    const bool wide = g.n % 256 == 0;
+    switch (g.epi) {
+        case EPI_BIAS: return wide ? launch_bt_t<EPI_BIAS, 256>(g, st) : launch_bt_t<EPI_BIAS, 128>(g, st);
+        case EPI_LIF: return wide ? launch_bt_t<EPI_LIF, 256>(g, st) : launch_bt_t<EPI_LIF, 128>(g, st);
+        default: return wide ? launch_bt_t<EPI_LIF_ATTN, 256>(g, st) : launch_bt_t<EPI_LIF_ATTN, 128>(g, st);
+    }
+}
+
+}  // namespace sapcu

@@ -111,6 +111,15 @@ struct Arena {
 static inline int64_t imax(int64_t a, int64_t b) { return a > b ? a : b; }
 static inline int imin(int a, int b) { return a < b ? a : b; }
 
+// GEMM on split rows: the big-tile kernel for the shapes it takes (SAPCU_BT=0 keeps everything on the ring kernel; the two
+// are bit-identical), else the 128x128 ring kernel.
+int launch_gemm_split_rows(const GemmArgs& g, hipStream_t st) {
+    const char* e = getenv("SAPCU_BT");                 // read per call: the parity test flips it inside one process
+    const bool use_bt = e && strcmp(e, "1") == 0;
+    if (use_bt && gemm_sf16_bt_ok(g)) return launch_gemm_sf16_bt(g, st);
+    return launch_gemm_sf16_ring(g, st);
+}
+
 // Route a GEMM to the split-f16 kernel when the model carries pre-split weights, else to the f32 MFMA kernel.
 static int run_gemm(const sapcu_model* m, GemmArgs& g, hipStream_t st) {
     const bool have16 = m && m->sf16 && g.w >= m->blob && g.w < m->blob + m->blob_floats;
@@ -119,7 +128,7 @@ static int run_gemm(const sapcu_model* m, GemmArgs& g, hipStream_t st) {
         g.w16_hi = (const _Float16*)m->w16_hi + off;
         g.w16_lo = (const _Float16*)m->w16_lo + off;
         g.ovf = m->ovf_dev;
-        if (g.a_split) return launch_gemm_sf16_ring(g, st);          // A already split by its producer: all-DMA ring
+        if (g.a_split) return launch_gemm_split_rows(g, st);         // A already split by its producer: all-DMA kernels
         if (g.k % 64 == 0) return launch_gemm_sf16(g, st);
     }
     if (g.a_split || g.c_split || g.c2_split) {
@@ -557,7 +566,7 @@ int sapcu_gemm_f32(const float* a, int64_t r, int k, int lda, const float* w, in
     g.a_split = a_split_rows ? 1 : 0; g.c_split = c_split_rows ? 1 : 0;
     if (w16_ws && (g.a_split || k % 64 == 0)) {   // f32-A split-f16 kernel steps k by 64; other depths run on exact f32
         SAPCU_TRY(split_into_ws(w, (int64_t)n * k, w16_ws, g, (hipStream_t)stream));
-        return g.a_split ? launch_gemm_sf16_ring(g, (hipStream_t)stream) : launch_gemm_sf16(g, (hipStream_t)stream);
+        return g.a_split ? launch_gemm_split_rows(g, (hipStream_t)stream) : launch_gemm_sf16(g, (hipStream_t)stream);
     }
     SAPCU_CHECK_ARG(!g.c_split, "gemm: split-row output needs k %% 64 == 0 on the f32-A path");
     return launch_gemm(g, (hipStream_t)stream);
@@ -586,7 +595,7 @@ int sapcu_posenc_gemm_f32(const float* pe1, int64_t r, int d, const float* w, co
         if (split_rows) {     // the production form: pe1 arrives as split rows, attn_in leaves as split rows
             g.a_split = 1;
             g.c2_split = 1;
-            return launch_gemm_sf16_ring(g, (hipStream_t)stream);
+            return launch_gemm_split_rows(g, (hipStream_t)stream);
         }
         return launch_gemm_sf16(g, (hipStream_t)stream);
     }

@@ -6,6 +6,7 @@
 #   latency              A_HOT (every tile reads the first row panel: all activation reads hit L2)
 #   DRAM locality        A_CONTIG (each k-step's activation slot read as one contiguous 16 KiB run), A_CONTIG_NO_MFMA
 #   tile order           CONTIG (-DSAPCU_RING_TILES_CONTIGUOUS: same speed, 3.8x the HBM fetches)
+#   big-tile kernel      BT_NO_MFMA (delivery + epilogue)  BT_NO_EPI (k-loop only)   — run with SAPCU_BT=1
 #   stamps               STAMPS (s_memtime per producer k-step segment; read with profiles/ring_stamps.py)
 # Usage: bash profiles/ablate.sh [NAME ...]      (default: all)
 set -e
@@ -18,10 +19,18 @@ build() {   # name, extra flags
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o profiles/abl/libsapcu_$1.so profiles/abl/ring_$1.o \
       $(ls $SRC/*.o | grep -v gemm_sf16_ring.o)
 }
+build_bt() {   # name, extra flags: diagnostic builds of the big-tile kernel
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off $2 -c $SRC/gemm_sf16_bt.hip -o profiles/abl/bt_$1.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o profiles/abl/libsapcu_$1.so profiles/abl/bt_$1.o \
+      $(ls $SRC/*.o | grep -v gemm_sf16_bt.o)
+}
 for v in ${@:-NO_GATHER NO_C2 NO_LIF NO_MFMA NO_DMA A_HOT CONTIG STAMPS}; do
   case $v in
     CONTIG) build $v -DSAPCU_RING_TILES_CONTIGUOUS ;;
     STAMPS) build $v -DSAPCU_RING_STAMPS ;;
+    BT_STAGGER*) build_bt $v -DSAPCU_BT_STAGGER=${v#BT_STAGGER} ;;
+    BT_ROW) build_bt $v -DSAPCU_BT_ROW_LAYOUT ;;
+    BT_*) build_bt $v -DSAPCU_ABL_$v ;;
     A_CONTIG_NO_MFMA) build $v "-DSAPCU_ABL_A_CONTIG -DSAPCU_ABL_NO_MFMA" ;;
     *)      build $v -DSAPCU_ABL_$v ;;
   esac

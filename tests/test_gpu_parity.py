@@ -979,3 +979,60 @@ def test_fn_trainer_step_against_reference_trainer_run():
         n_eval = model(torch.from_numpy(g["points"]).cuda())
     assert n_eval.shape == (2, 8, 3) and bool(torch.isfinite(n_eval).all())
     assert (n_eval.norm(dim=-1) - 1).abs().max() <= 1e-5
+
+
+@pytest.mark.parametrize("r,k,n,lif,csplit", [(1024, 128, 128, 0, 0), (2048 + 77, 256, 256, 1, 1), (4096 + 3, 512, 512, 0, 0), (3000, 512, 512, 1, 0),
+                                              (1500, 64, 384, 1, 1), (70000, 512, 512, 1, 1), (36864, 128, 128, 1, 1)])
+def test_big_tile_gemm_is_bit_identical_to_the_ring_kernel(r, k, n, lif, csplit, monkeypatch):
+    """gemm_sf16_bt.hip (256-row tiles, epilogue in the MFMA waves, SAPCU_BT=1) against gemm_sf16_ring.hip through the C ABI
+    on the same split-row operands: same products in the same order, so every output bit must agree — bias-only and
+    neuron epilogues, f32 and split-row outputs, ragged last row tile, 1/2/3 column tiles."""
+    from sapcu_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(r + n)
+    A = _dev(rng.normal(size=(r, k)).astype(np.float32))
+    W = _dev((rng.normal(size=(n, k)) / np.sqrt(k)).astype(np.float32))
+    Bv = _dev(rng.normal(size=n).astype(np.float32))
+    L = _dev(np.stack([rng.uniform(0.05, 1.1, n), rng.uniform(0.0, 0.2, n), rng.uniform(0.05, 1.0, n), rng.normal(0.5, 0.3, n)]).astype(np.float32))
+    As = torch.empty_like(A)
+    _lib.check(lib.sapcu_to_split_rows(_lib.ptr(A), r, k, k, _lib.ptr(As), k, _lib.current_stream()))
+    outs = []
+    for bt in ("0", "1"):
+        monkeypatch.setenv("SAPCU_BT", bt)
+        C = torch.full((r, n), float("nan"), device=U.dev())
+        ws = torch.zeros(4 * n * k + 16, dtype=torch.uint8, device=U.dev())
+        _lib.check(lib.sapcu_gemm_f32(_lib.ptr(As), r, k, k, _lib.ptr(W), n, _lib.ptr(Bv), _lib.ptr(L) if lif else None, 4, _lib.ptr(C), n,
+                                      _lib.ptr(ws), 1, csplit, _lib.current_stream()))
+        torch.cuda.synchronize()
+        outs.append(C.cpu().view(torch.int32))
+    assert not bool(torch.isnan(outs[1].view(torch.float32)).any()) or csplit
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("b,m,kk,d", [(4, 48, 12, 512), (3, 48, 18, 256), (5, 48, 24, 128), (37, 48, 12, 512)])
+def test_big_tile_posenc_attention_gemm_is_bit_identical_to_the_ring_kernel(b, m, kk, d, monkeypatch):
+    """The production form of sapcu_posenc_gemm_f32 (split rows in, pe f32 + attn_in split rows out, q/k gathers) on the
+    big-tile kernel (SAPCU_BT=1) against the ring kernel: every bit of both outputs."""
+    from sapcu_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(b * 1000 + d)
+    r = b * m * kk
+    P1 = _dev(rng.random((r, d)).astype(np.float32))
+    W, Bv = _dev((rng.normal(size=(d, d)) / np.sqrt(d)).astype(np.float32)), _dev(rng.normal(size=d).astype(np.float32))
+    L = _dev(np.stack([rng.uniform(0.05, 1.1, d), rng.uniform(0.0, 0.2, d), rng.uniform(0.05, 1.0, d), rng.normal(0.5, 0.3, d)]).astype(np.float32))
+    Q, I = _dev(rng.random((b * m, 3 * d)).astype(np.float32)), _dev(rng.integers(0, m, size=(b, m, kk)).astype(np.int32))
+    P1s = torch.empty_like(P1)
+    _lib.check(lib.sapcu_to_split_rows(_lib.ptr(P1), r, d, d, _lib.ptr(P1s), d, _lib.current_stream()))
+    outs = []
+    for bt in ("0", "1"):
+        monkeypatch.setenv("SAPCU_BT", bt)
+        pe = torch.full((r, d), float("nan"), device=U.dev())
+        att = torch.full((r, d), float("nan"), device=U.dev())
+        tab = torch.empty((r, 2), dtype=torch.int32, device=U.dev())
+        ws = torch.zeros(4 * d * d + 16, dtype=torch.uint8, device=U.dev())
+        _lib.check(lib.sapcu_posenc_gemm_f32(_lib.ptr(P1s), r, d, _lib.ptr(W), _lib.ptr(Bv), _lib.ptr(L), 4, _lib.ptr(Q), _lib.ptr(I), kk, m,
+                                             _lib.ptr(pe), _lib.ptr(att), _lib.ptr(tab), _lib.ptr(ws), 1, _lib.current_stream()))
+        torch.cuda.synchronize()
+        outs.append((pe.cpu().view(torch.int32), att.cpu().view(torch.int32)))
+    assert not bool(torch.isnan(outs[1][0].view(torch.float32)).any())
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
