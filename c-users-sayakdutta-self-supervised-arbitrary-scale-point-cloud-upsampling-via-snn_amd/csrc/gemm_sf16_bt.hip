@@ -298,34 +298,45 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
 #else
         const int64_t row0 = tm * TBM + wm * 128;
         const int col0 = tn * BN + wn * 32 * CT;
+        // column parameters of this lane for BOTH column blocks up front: a load waited for in the middle of the epilogue would
+        // also wait (in-order counter) for every store issued before it
+        float pbias[CT];
+        NeuronP pnp[CT];
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
             const int col = col0 + j * 32 + r32;
-            const float bias = g.bias ? g.bias[col] : 0.f;
-            NeuronP np = NeuronP{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) np = load_lif(g.lif, g.n, col);
+            pbias[j] = g.bias ? g.bias[col] : 0.f;
+            pnp[j] = NeuronP{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) pnp[j] = load_lif(g.lif, g.n, col);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int64_t row = row0 + i * 32 + 8 * q4 + 4 * h;
-                    if (row >= g.r) continue;
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int64_t row = row0 + i * 32 + 8 * q4 + 4 * h;
+                if (row >= g.r) continue;
+                int2 t4[4];                                  // (point row, neighbour row) of this group's 4 edge rows: once for both column blocks
+                if (EPI == EPI_LIF_ATTN) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) t4[u] = row + u < g.r ? g.tab[row + u] : make_int2(0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    const int col = col0 + j * 32 + r32;
                     float a4[4], cq[4] = {0.f, 0.f, 0.f, 0.f}, ckf[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int u = 0; u < 4; ++u) a4[u] = __fmul_rn(acc[i][j][q4 * 4 + u], 0.0625f);      // undo W x 16
                     if (EPI == EPI_LIF_ATTN) {
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            if (row + u < g.r) {
-                                const int2 t = g.tab[row + u];
-                                cq[u] = g.q[(int64_t)t.x * g.ldq + col];
-                                ckf[u] = g.kf[(int64_t)t.y * g.ldq + col];
-                            }
+                            cq[u] = g.q[(int64_t)t4[u].x * g.ldq + col];
+                            ckf[u] = g.kf[(int64_t)t4[u].y * g.ldq + col];
                         }
                     }
-                    epilogue_group4<EPI>(g, a4, row, col, bias, np, cq, ckf);
-                    __builtin_amdgcn_sched_barrier(0);      // keep the groups apart (128 accumulators live)
+                    epilogue_group4<EPI>(g, a4, row, col, pbias[j], pnp[j], cq, ckf);
                 }
+                __builtin_amdgcn_sched_barrier(0);          // keep the groups apart (128 accumulators live)
             }
         }
 #endif
@@ -371,9 +382,6 @@ bool gemm_sf16_bt_ok(const GemmArgs& g) {
     if (g.ldc % 4 || !al16(g.c) || (g.bias && !al16(g.bias))) return false;
     if ((g.epi == EPI_LIF || g.epi == EPI_LIF_ATTN) && !al16(g.lif)) return false;
     if (g.epi == EPI_LIF_ATTN && (g.ldq % 4 || !al16(g.q) || !al16(g.kf) || !al16(g.c2))) return false;
-#ifndef SAPCU_BT_ROW_LAYOUT
-    if (g.epi == EPI_LIF_ATTN && g.n % 256 == 0) return false;      // (the 256-wide column-layout attention epilogue spills)
-#endif
     return g.epi == EPI_BIAS || g.epi == EPI_LIF || g.epi == EPI_LIF_ATTN;
 }
 
