@@ -10,7 +10,7 @@ outer kNN + gather/centre -> fn forward -> normalise -> gather/rotate -> fd forw
 before the timed region.  Weak scaling: every rank refines its own 4096 queries per step.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel symbol (the positional-encoding GEMM gemm_ring_kernel<EPI_LIF_ATTN>,
+  roofline      the dominant kernel (the positional-encoding GEMM gemm_bt_kernel<EPI_LIF_ATTN, .>,
                 fn/snn_coder.py:360-368: d x d contraction + 4-step neuron loop + q-k+pe gather), its
                 three per-block shapes launched back to back on the current stream between two
                 events: achieved = mean algorithmic HBM bytes per launch (3*r*d*4: read pe1, write pe,
@@ -60,7 +60,7 @@ def build_models(dev):
 
 
 def roofline_leg(dev, reps=3):
-    """Time the dominant kernel symbol alone: gemm_ring_kernel<EPI_LIF_ATTN> (pos-enc GEMM, fn/snn_coder.py:360-368),
+    """Time the dominant kernel alone: gemm_bt_kernel<EPI_LIF_ATTN, .> (pos-enc GEMM, fn/snn_coder.py:360-368; gemm_ring_kernel with SAPCU_BT=0),
     its three per-block launches for one chunk of patches, back to back on the current stream.
 
     The kernel reads pe1 [r,d] and writes pe [r,d] and attn_in [r,d] (f32) and runs the 4-step neuron loop on
@@ -118,7 +118,8 @@ def roofline_leg(dev, reps=3):
     for cand in sorted([f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json")], reverse=True):
         try:
             recs = json.load(open(os.path.join(ROOT, "profiles", cand)))
-            rec = recs.get("gemm_ring_kernel<6, true>") or recs.get("gemm_ring_kernel<6>")
+            bt_off = os.environ.get("SAPCU_BT") == "0"
+            rec = (None if bt_off else recs.get("gemm_bt_kernel<6>")) or recs.get("gemm_ring_kernel<6, true>") or recs.get("gemm_ring_kernel<6>")
             if rec:
                 traffic, src = float(rec["hbm_bytes_per_launch"]), "profiles/" + cand
                 busy = rec.get("mfma_busy_frac")      # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs), third PMC pass
@@ -127,7 +128,8 @@ def roofline_leg(dev, reps=3):
             pass
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": src,
-            "kernel": "gemm_ring_kernel<EPI_LIF_ATTN>", "avg_launch_ms": round(avg_s * 1e3, 4),
+            "kernel": ("gemm_ring_kernel<EPI_LIF_ATTN>" if os.environ.get("SAPCU_BT") == "0" else "gemm_bt_kernel<EPI_LIF_ATTN, 256|128>"),
+            "avg_launch_ms": round(avg_s * 1e3, 4),
             "bytes_per_launch": byts, "launches_timed": n_launch, "chunk_patches": chunk,
             "mfma": {"algorithmic_tflops": round(flop / avg_s / 1e12, 2), "issued_f16_tflops": round(3 * flop / avg_s / 1e12, 2),
                      "peak_f16_dense_tflops": PEAK_F16_MFMA_TFLOPS, "issued_frac": round(3 * flop / avg_s / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),

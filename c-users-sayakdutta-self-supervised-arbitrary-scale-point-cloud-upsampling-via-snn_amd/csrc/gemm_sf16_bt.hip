@@ -10,9 +10,9 @@
 //   this kernel   256xBN tile (BN = 256 or 128), 8 waves of 256 registers, wave tile 128 x BN/4 (4 x 2 MFMA blocks = 128
 //                 accumulator registers): half the operand bytes per flop through the DMA path and through the LDS read
 //                 port (12 fragment reads per 24 MFMAs), four times the matrix work between two barriers.  The epilogue
-//                 runs in the MFMA waves themselves: the blocks are computed TRANSPOSED (weight fragment as the first MFMA
-//                 operand), so a lane holds 4 consecutive columns of one row per register quad — the row layout of
-//                 gemm_epi.h (epilogue_row4_*: 16-byte stores and gathers) with no LDS hand-off.
+//                 runs in the MFMA waves themselves, in the accumulator layout (lane = column: bias and neuron parameters
+//                 are per-lane constants; a register quad = 4 consecutive rows -> gemm_epi.h epilogue_group4; a store
+//                 instruction writes two full 128-byte lines).
 //
 // Pipeline: k-step = 32.  Waves 0-3 stream the activation operand (3 slots of 32 KiB, 2 k-steps ahead: first touches, HBM
 // latency), waves 4-7 the weight operand (2 slots, 1 step ahead, L2 hits); one stream per wave because a wave's vector-
@@ -42,6 +42,97 @@ __device__ __forceinline__ void bt_wait_vm() {
     else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// A global load the compiler does not see as one (it would protect the destination registers with a vmcnt(0) at the top of
+// the next tile, which drains the DMA look-ahead and the epilogue's stores): the caller waits with bt_wait_vm<0>().
+__device__ __forceinline__ float bt_load_f32(const float* p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// Epilogue of one wave tile, FAST path: every row of the tile exists (interior tile) and the output formats are compile-time
+// — no per-element row masks, no run-time format branches, no overflow counter (the generic epilogue_group4 path costs about
+// 40 instructions and 3 scalar branches per stored element, 128 elements per lane and tile).  Same arithmetic, bit for bit.
+//   C_SPLIT / C2_SPLIT: c / c2 (attn_in) leave as split rows instead of f32.
+template <int EPI, int CT, bool C_SPLIT, bool C2_SPLIT>
+__device__ __forceinline__ void bt_epilogue_fast(const GemmArgs& g, const f32x16 (&acc)[4][CT], int64_t row0, int col0, int r32, int h,
+                                                 const float (&pbias)[CT], const NeuronP (&pnp)[CT]) {
+    constexpr bool ATTN = EPI == EPI_LIF_ATTN;
+    // Attention epilogue, software-pipelined over the 16 row groups: the (point, neighbour) rows of group n+1 are loaded and
+    // the q / k gathers of group n issued BEFORE the neuron arithmetic of group n, so every wait of the in-order counter is
+    // for loads issued one arithmetic block earlier (and the stores issued before them).
+    int2 t_nxt[4];
+    if (ATTN) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t_nxt[u] = g.tab[row0 + 4 * h + u];
+    }
+#pragma unroll
+    for (int gi = 0; gi < 16; ++gi) {
+        const int i = gi >> 2, q4 = gi & 3;
+        const int64_t row = row0 + i * 32 + 8 * q4 + 4 * h;
+        float qv[CT][4], kv[CT][4];
+        if (ATTN) {
+            int2 t4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t4[u] = t_nxt[u];
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const int col = col0 + j * 32 + r32;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    qv[j][u] = g.q[(int64_t)t4[u].x * g.ldq + col];
+                    kv[j][u] = g.kf[(int64_t)t4[u].y * g.ldq + col];
+                }
+            }
+            if (gi + 1 < 16) {
+                const int64_t nrow = row0 + ((gi + 1) >> 2) * 32 + 8 * ((gi + 1) & 3) + 4 * h;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t_nxt[u] = g.tab[nrow + u];
+            }
+            __builtin_amdgcn_sched_barrier(0);              // loads first, arithmetic after
+        }
+        float v[CT][4];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[j][u] = __fadd_rn(__fmul_rn(acc[i][j][q4 * 4 + u], 0.0625f), pbias[j]);
+            if (EPI == EPI_LIF || ATTN) lif_selfloop_n<4>(v[j], pnp[j], g.lif_T);
+        }
+        if (ATTN) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const int col = col0 + j * 32 + r32;
+            float* cp = g.c + row * g.ldc + col;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (C_SPLIT) {
+                    _Float16* rp = reinterpret_cast<_Float16*>(g.c + (row + u) * g.ldc);
+                    const _Float16 hi = (_Float16)v[j][u];
+                    rp[col] = hi;
+                    rp[g.ldc + col] = (_Float16)(v[j][u] - (float)hi);
+                } else {
+                    cp[(int64_t)u * g.ldc] = v[j][u];
+                }
+            }
+            if (ATTN) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float ai = __fadd_rn(__fsub_rn(qv[j][u], kv[j][u]), v[j][u]);
+                    if (C2_SPLIT) {
+                        _Float16* rp = reinterpret_cast<_Float16*>(g.c2 + (row + u) * g.ldc);
+                        const _Float16 hi = (_Float16)ai;
+                        rp[col] = hi;
+                        rp[g.ldc + col] = (_Float16)(ai - (float)hi);
+                    } else {
+                        g.c2[(row + u) * g.ldc + col] = ai;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                  // keep the groups apart (128 accumulators live)
+    }
 }
 
 template <int EPI, int BN>
@@ -148,7 +239,9 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
     pf_setup();
     while (issued < depth && issued < total_steps) issue();
     // this wave's DMAs of `step` have landed: 2*pieces DMAs per step, in order
+    int64_t landed_upto = 0;            // every step below this index is known to have landed (a vmcnt(0) since its issue)
     auto wait_landed = [&](int64_t step) {
+        if (step < landed_upto) return;
         const int64_t ahead = issued - step - 1;
         if (is_a) {                                                   // 8 per step
             if (ahead >= 2) bt_wait_vm<16>();
@@ -191,23 +284,8 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
         return;
 #endif
         // same product order per accumulator as the ring kernel (a_lo.w_hi, a_hi.w_lo, a_hi.w_hi); consecutive MFMAs go to
-        // different accumulators.  The WEIGHT fragment is the first MFMA operand: the block comes out transposed (lane =
-        // activation row, register quad = 4 consecutive output columns), which is the row layout of gemm_epi.h —
-        // 16-byte stores, float4 parameter loads — at no cost (both fragments have the same LDS image).
-#ifdef SAPCU_BT_ROW_LAYOUT
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wh[j], f.al[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wl[j], f.ah[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wh[j], f.ah[i], acc[i][j], 0, 0, 0);
-#else
+        // different accumulators.  (Tried: the weight fragment as the first operand, which transposes the block into the row
+        // layout of gemm_epi.h — 16-byte stores, but only 32 contiguous bytes per row and instruction: 10 % slower.)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -220,7 +298,6 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.wh[j], acc[i][j], 0, 0, 0);
-#endif
     };
 
     wait_landed(0);
@@ -244,7 +321,8 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
             if (gstep + 1 < total_steps) {
                 wait_landed(gstep + 1);
                 lds_barrier();                                        // step gstep+1 is in for everyone; this step's slots fully read
-                if (issued < total_steps) issue();
+                // the activation waves defer the refill of a tile's LAST step to the start of the epilogue (see there)
+                if (issued < total_steps && !(is_a && kt + 1 == nk)) issue();
                 if (kt + 1 < nk) read_frags(na, nw, 0, f0);
             } else {
                 lds_barrier();
@@ -263,59 +341,60 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
         if (tn >= ntn) { tn -= ntn; ++tm; }
         continue;
 #endif
-#ifdef SAPCU_BT_ROW_LAYOUT   // transposed blocks: 16-byte stores, but only 32 contiguous bytes per row and instruction (slower)
-        const int64_t row0 = tm * TBM + wm * 128 + r32;            // this lane's row in row block i: row0 + 32 i
-        const int col0 = tn * BN + wn * 32 * CT + 4 * h;             // ... its 4 columns in (block j, quad q): col0 + 32 j + 8 q
-        int2 tabr[4];
-        if (EPI == EPI_LIF_ATTN) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) tabr[i] = row0 + 32 * i < g.r ? g.tab[row0 + 32 * i] : make_int2(0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < CT; ++j) {
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int col = col0 + 32 * j + 8 * q4;
-                const ColParams4 cp = load_col_params4<EPI, true>(g, col, true);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int64_t row = row0 + 32 * i;
-                    if (row < g.r) {
-                        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), kv = qv;
-                        if (EPI == EPI_LIF_ATTN) {
-                            qv = ld4(g.q + (int64_t)tabr[i].x * g.ldq + col);
-                            kv = ld4(g.kf + (int64_t)tabr[i].y * g.ldq + col);
-                        }
-                        const float4 a4 = make_float4(acc[i][j][q4 * 4], acc[i][j][q4 * 4 + 1], acc[i][j][q4 * 4 + 2], acc[i][j][q4 * 4 + 3]);
-                        float v[4];
-                        epilogue_row4_compute<EPI, true>(g, a4, row, col, cp, v);
-                        epilogue_row4_store<EPI, true>(g, v, row, col, qv, kv);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);          // keep the column groups apart (register pressure: 128 accumulators live)
-            }
-        }
-#else
         const int64_t row0 = tm * TBM + wm * 128;
         const int col0 = tn * BN + wn * 32 * CT;
         // column parameters of this lane for BOTH column blocks up front: a load waited for in the middle of the epilogue would
         // also wait (in-order counter) for every store issued before it
-        float pbias[CT];
+        float pbias[CT], praw[CT][4];
         NeuronP pnp[CT];
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
             const int col = col0 + j * 32 + r32;
-            pbias[j] = g.bias ? g.bias[col] : 0.f;
-            pnp[j] = NeuronP{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) pnp[j] = load_lif(g.lif, g.n, col);
+            pbias[j] = 0.f;
+            if (g.bias) pbias[j] = bt_load_f32(g.bias + col);
+            if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) praw[j][q] = bt_load_f32(g.lif + (int64_t)q * g.n + col);
+            }
         }
+        // Tile-boundary protocol.  The counter completes in order and counts stores, so (a) waiting for the parameter loads
+        // waits for every DMA issued before them and (b) any wait behind the epilogue's 128 stores waits for the stores.
+        // (a): the activation waves issued their last refill one and a half k-steps ago (the one of the last step was
+        // deferred), the weight refill is an L2 hit — this wait is short; after it every issued step has landed, which makes
+        // the first waits of the next tile (steps issued before this point) unnecessary: landed_upto.  The deferred refill goes
+        // out now, before the stores; the waits that follow it come one k-step or more after the last store.
+        bt_wait_vm<0>();
+        landed_upto = issued;
+        if (is_a && issued < total_steps) issue();
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            pnp[j] = NeuronP{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) {
+                pnp[j].decay = clampf(praw[j][0], 0.1f, 0.99f);
+                pnp[j].adapt = clampf(praw[j][1], 0.001f, 0.1f);
+                pnp[j].rdecay = clampf(praw[j][2], 0.1f, 0.95f);
+                pnp[j].theta0 = praw[j][3];
+            }
+        }
+        // interior tile and a format the fast path has (wave-uniform): everything the models launch; else the generic path
+        const bool interior = tm * TBM + TBM <= g.r;
+        if (interior && EPI == EPI_LIF_ATTN && !g.c_split && g.c2_split) {
+            bt_epilogue_fast<EPI, CT, false, true>(g, acc, row0, col0, r32, h, pbias, pnp);
+        } else if (interior && EPI == EPI_LIF && g.c_split) {
+            bt_epilogue_fast<EPI, CT, true, false>(g, acc, row0, col0, r32, h, pbias, pnp);
+        } else if (interior && EPI != EPI_LIF_ATTN && !g.c_split) {
+            bt_epilogue_fast<EPI, CT, false, false>(g, acc, row0, col0, r32, h, pbias, pnp);
+        } else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 const int64_t row = row0 + i * 32 + 8 * q4 + 4 * h;
                 if (row >= g.r) continue;
+#ifdef SAPCU_ABL_BT_QUARTER_EPI   // diagnostic: a quarter of the epilogue (is its cost per store or per tile?)
+                if (q4 != 0) continue;
+#endif
                 int2 t4[4];                                  // (point row, neighbour row) of this group's 4 edge rows: once for both column blocks
                 if (EPI == EPI_LIF_ATTN) {
 #pragma unroll
@@ -339,7 +418,6 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
                 __builtin_amdgcn_sched_barrier(0);          // keep the groups apart (128 accumulators live)
             }
         }
-#endif
         tm += step_tm;
         tn += step_tn;
         if (tn >= ntn) { tn -= ntn; ++tm; }

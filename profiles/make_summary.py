@@ -21,7 +21,7 @@ def main(d, title):
         print("| `%s` | %d | %.2f | %.1f | %.1f |" % (k, len(v), sum(v) / 1e3, sum(v) / len(v), 100 * sum(v) / tot))
     print("\ntotal kernel time %.1f ms over %d dispatches\n" % (tot / 1e3, len(rows)))
     # per-launch durations of the GEMM kernels in dispatch order (the three fn blocks alternate: d = 128, 256, 512)
-    seq = {k: [round(x, 1) for x in v] for k, v in agg.items() if k.startswith("gemm_ring_kernel")}
+    seq = {k: [round(x, 1) for x in v] for k, v in agg.items() if k.startswith(("gemm_ring_kernel", "gemm_bt_kernel"))}
     if len(sys.argv) > 3:
         import json
         json.dump(seq, open(sys.argv[3], "w"))
