@@ -56,6 +56,15 @@ __device__ __forceinline__ float bt_load_f32(const float* p) {
 // — no per-element row masks, no run-time format branches, no overflow counter (the generic epilogue_group4 path costs about
 // 40 instructions and 3 scalar branches per stored element, 128 elements per lane and tile).  Same arithmetic, bit for bit.
 //   C_SPLIT / C2_SPLIT: c / c2 (attn_in) leave as split rows instead of f32.
+#ifdef SAPCU_BT_STAMPS      // diagnostic build (profiles/ablate.sh BT_STAMPS): where the time of a tile goes, waves 0 (A) and 4 (W)
+__device__ unsigned long long g_bt_stamps[256][2][12];
+#define BT_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define BT_SEG(i, t0, t1) do { seg[i] += (t1) - (t0); } while (0)
+#else
+#define BT_STAMP(t) do { } while (0)
+#define BT_SEG(i, t0, t1) do { } while (0)
+#endif
+
 template <int EPI, int CT, bool C_SPLIT, bool C2_SPLIT>
 __device__ __forceinline__ void bt_epilogue_fast(const GemmArgs& g, const f32x16 (&acc)[4][CT], int64_t row0, int col0, int r32, int h,
                                                  const float (&pbias)[CT], const NeuronP (&pnp)[CT]) {
@@ -71,6 +80,9 @@ __device__ __forceinline__ void bt_epilogue_fast(const GemmArgs& g, const f32x16
 #pragma unroll
     for (int gi = 0; gi < 16; ++gi) {
         const int i = gi >> 2, q4 = gi & 3;
+#ifdef SAPCU_ABL_BT_QUARTER_EPI   // diagnostic: a quarter of the epilogue (is its cost per store or per tile?)
+        if (q4 != 0) continue;
+#endif
         const int64_t row = row0 + i * 32 + 8 * q4 + 4 * h;
         float qv[CT][4], kv[CT][4];
         if (ATTN) {
@@ -307,6 +319,9 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
     int64_t gstep = 0;
     int64_t tm = first_tm;
     int tn = first_tn;
+#ifdef SAPCU_BT_STAMPS
+    unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#endif
     for (int64_t ti = 0; ti < my_tiles; ++ti) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -316,11 +331,17 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         read_frags(ca, cw, 0, f0);          // (not prefetched across the tile boundary: the epilogue needs those 48 registers)
         for (int kt = 0; kt < nk; ++kt, ++gstep) {
+            BT_STAMP(s0);
             read_frags(ca, cw, 1, f1);
             mfma_all(f0);
+            BT_STAMP(s1);
             if (gstep + 1 < total_steps) {
                 wait_landed(gstep + 1);
+                BT_STAMP(s2);
                 lds_barrier();                                        // step gstep+1 is in for everyone; this step's slots fully read
+                BT_STAMP(s3);
+                BT_SEG(kt == 0 ? 3 : (kt == 1 ? 4 : 5), s1, s2);      // wait for own DMAs: first / second / later k-steps of a tile
+                BT_SEG(kt == 0 ? 6 : (kt == 1 ? 7 : 8), s2, s3);      // barrier
                 // the activation waves defer the refill of a tile's LAST step to the start of the epilogue (see there)
                 if (issued < total_steps && !(is_a && kt + 1 == nk)) issue();
                 if (kt + 1 < nk) read_frags(na, nw, 0, f0);
@@ -332,7 +353,10 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
             cw = nw;
             if (++na == TA_SLOTS) na = 0;
             if (++nw == TW_SLOTS) nw = 0;
+            BT_STAMP(s1);
+            BT_SEG(kt == 0 ? 0 : (kt == 1 ? 1 : 2), s0, s1);          // whole k-step: first / second / later
         }
+        BT_STAMP(s0);
         // ---- epilogue in the accumulator layout: lane = column, register quad q = rows 8q + 4h + 0..3 of the 32x32 block
 #ifdef SAPCU_ABL_BT_NO_EPI    // k-loop only (diagnostic build: one store per tile keeps the accumulators alive)
         if (acc[0][0][0] == 12345.678f) g.c[0] = acc[3][CT - 1][15] + acc[1][0][7] + acc[2][0][3];
@@ -364,6 +388,8 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
         // the first waits of the next tile (steps issued before this point) unnecessary: landed_upto.  The deferred refill goes
         // out now, before the stores; the waits that follow it come one k-step or more after the last store.
         bt_wait_vm<0>();
+        BT_STAMP(s1);
+        BT_SEG(9, s0, s1);                                            // parameter loads + their wait
         landed_upto = issued;
         if (is_a && issued < total_steps) issue();
         __builtin_amdgcn_sched_barrier(0);
@@ -418,10 +444,18 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
                 __builtin_amdgcn_sched_barrier(0);          // keep the groups apart (128 accumulators live)
             }
         }
+        BT_STAMP(s2);
+        BT_SEG(10, s1, s2);                                           // epilogue arithmetic + store issue
         tm += step_tm;
         tn += step_tn;
         if (tn >= ntn) { tn -= ntn; ++tm; }
     }
+#ifdef SAPCU_BT_STAMPS
+    if ((wave == 0 || wave == 4) && lane == 0 && blockIdx.x < 256) {
+        seg[11] = (unsigned long long)my_tiles;
+        for (int i = 0; i < 12; ++i) g_bt_stamps[blockIdx.x][wave >> 2][i] = seg[i];
+    }
+#endif
 }
 
 static int g_num_cus_bt = 0;
@@ -475,5 +509,13 @@ int launch_gemm_sf16_bt(const GemmArgs& g, hipStream_t st) {
         default: return wide ? launch_bt_t<EPI_LIF_ATTN, 256>(g, st) : launch_bt_t<EPI_LIF_ATTN, 128>(g, st);
     }
 }
+
+#ifdef SAPCU_BT_STAMPS
+}  // namespace sapcu
+extern "C" int sapcu_debug_bt_stamps(unsigned long long* out_host) {
+    return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(sapcu::g_bt_stamps), sizeof(sapcu::g_bt_stamps));
+}
+namespace sapcu {
+#endif
 
 }  // namespace sapcu

@@ -28,6 +28,7 @@ for v in ${@:-NO_GATHER NO_C2 NO_LIF NO_MFMA NO_DMA A_HOT CONTIG STAMPS}; do
   case $v in
     CONTIG) build $v -DSAPCU_RING_TILES_CONTIGUOUS ;;
     STAMPS) build $v -DSAPCU_RING_STAMPS ;;
+    BT_STAMPS) build_bt $v -DSAPCU_BT_STAMPS ;;
     BT_STAGGER*) build_bt $v -DSAPCU_BT_STAGGER=${v#BT_STAGGER} ;;
     BT_*) build_bt $v -DSAPCU_ABL_$v ;;
     A_CONTIG_NO_MFMA) build $v "-DSAPCU_ABL_A_CONTIG -DSAPCU_ABL_NO_MFMA" ;;
