@@ -68,7 +68,7 @@ def roofline_leg(dev, reps=3):
     is the HBM one; the MFMA-side figures are reported next to it."""
     from sapcu_amd import _lib
     lib = _lib.load()
-    chunk = min(int(os.environ.get("SAPCU_CHUNK", "2048")), B_PER_GPU)
+    chunk = min(int(os.environ.get("SAPCU_CHUNK", "4096")), B_PER_GPU)
     torch.manual_seed(0)
     shapes = []
     for l, kk in enumerate(FN_KW["k_values"]):

@@ -619,7 +619,7 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
     const char* fe = getenv("SAPCU_FUSED_SOFTMAX");
     m->fused_softmax = fe && strcmp(fe, "1") == 0;
     const char* ce = getenv("SAPCU_CHUNK");
-    m->chunk = ce ? atoll(ce) : 2048;
+    m->chunk = ce ? atoll(ce) : 4096;
     if (m->chunk < 1) m->chunk = 1;
     int rc = SAPCU_OK;
     if (kind == SAPCU_KIND_FN) {
