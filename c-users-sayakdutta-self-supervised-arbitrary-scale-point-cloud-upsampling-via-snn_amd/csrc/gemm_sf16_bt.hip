@@ -65,6 +65,23 @@ __device__ unsigned long long g_bt_stamps[256][2][12];
 #define BT_SEG(i, t0, t1) do { } while (0)
 #endif
 
+// Epilogue stores.  SAPCU_BT_STORE_POLICY = 1 / 2 / 3 (diagnostic builds): "nt" / "sc1" / "sc0 sc1" cache-policy bits through inline asm
+// (hipcc's __builtin_nontemporal_store emits a plain store here).
+#ifdef SAPCU_BT_STORE_POLICY
+#if SAPCU_BT_STORE_POLICY == 1
+#define BT_POLICY_STR "nt"
+#elif SAPCU_BT_STORE_POLICY == 2
+#define BT_POLICY_STR "sc1"
+#else
+#define BT_POLICY_STR "sc0 sc1"
+#endif
+__device__ __forceinline__ void bt_store(float* p, float v) { asm volatile("global_store_dword %0, %1, off " BT_POLICY_STR :: "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void bt_store(_Float16* p, _Float16 v) { asm volatile("global_store_short %0, %1, off " BT_POLICY_STR :: "v"(p), "v"(v) : "memory"); }
+#define BT_STORE(p, v) bt_store((p), (v))
+#else
+#define BT_STORE(p, v) (*(p) = (v))
+#endif
+
 template <int EPI, int CT, bool C_SPLIT, bool C2_SPLIT>
 __device__ __forceinline__ void bt_epilogue_fast(const GemmArgs& g, const f32x16 (&acc)[4][CT], int64_t row0, int col0, int r32, int h,
                                                  const float (&pbias)[CT], const NeuronP (&pnp)[CT]) {
@@ -119,13 +136,15 @@ __device__ __forceinline__ void bt_epilogue_fast(const GemmArgs& g, const f32x16
             float* cp = g.c + row * g.ldc + col;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+                // non-temporal (streaming) stores: a tile round writes 8 MiB per XCD through a 4 MiB L2 that the k-loop needs for
+                // the weight tile and the shared activation panel; nobody re-reads these lines before they leave the cache
                 if (C_SPLIT) {
                     _Float16* rp = reinterpret_cast<_Float16*>(g.c + (row + u) * g.ldc);
                     const _Float16 hi = (_Float16)v[j][u];
-                    rp[col] = hi;
-                    rp[g.ldc + col] = (_Float16)(v[j][u] - (float)hi);
+                    BT_STORE(rp + col, hi);
+                    BT_STORE(rp + g.ldc + col, (_Float16)(v[j][u] - (float)hi));
                 } else {
-                    cp[(int64_t)u * g.ldc] = v[j][u];
+                    BT_STORE(cp + (int64_t)u * g.ldc, v[j][u]);
                 }
             }
             if (ATTN) {
@@ -135,10 +154,10 @@ __device__ __forceinline__ void bt_epilogue_fast(const GemmArgs& g, const f32x16
                     if (C2_SPLIT) {
                         _Float16* rp = reinterpret_cast<_Float16*>(g.c2 + (row + u) * g.ldc);
                         const _Float16 hi = (_Float16)ai;
-                        rp[col] = hi;
-                        rp[g.ldc + col] = (_Float16)(ai - (float)hi);
+                        BT_STORE(rp + col, hi);
+                        BT_STORE(rp + g.ldc + col, (_Float16)(ai - (float)hi));
                     } else {
-                        g.c2[(row + u) * g.ldc + col] = ai;
+                        BT_STORE(g.c2 + (row + u) * g.ldc + col, ai);
                     }
                 }
             }

@@ -28,6 +28,9 @@ for v in ${@:-NO_GATHER NO_C2 NO_LIF NO_MFMA NO_DMA A_HOT CONTIG STAMPS}; do
   case $v in
     CONTIG) build $v -DSAPCU_RING_TILES_CONTIGUOUS ;;
     STAMPS) build $v -DSAPCU_RING_STAMPS ;;
+    BT_ST_NT) build_bt $v -DSAPCU_BT_STORE_POLICY=1 ;;
+    BT_ST_SC1) build_bt $v -DSAPCU_BT_STORE_POLICY=2 ;;
+    BT_ST_SC01) build_bt $v -DSAPCU_BT_STORE_POLICY=3 ;;
     BT_STAMPS) build_bt $v -DSAPCU_BT_STAMPS ;;
     BT_STAGGER*) build_bt $v -DSAPCU_BT_STAGGER=${v#BT_STAGGER} ;;
     BT_*) build_bt $v -DSAPCU_ABL_$v ;;
