@@ -1036,3 +1036,18 @@ def test_big_tile_posenc_attention_gemm_is_bit_identical_to_the_ring_kernel(b, m
         outs.append((pe.cpu().view(torch.int32), att.cpu().view(torch.int32)))
     assert not bool(torch.isnan(outs[1][0].view(torch.float32)).any())
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_models_on_the_big_tile_kernel_equal_the_ring_kernel_bit_for_bit(weights, monkeypatch):
+    """Whole fn and fd forwards with the split-row GEMMs on the big-tile kernel (default) against the ring kernel only
+    (SAPCU_BT=0, read per launch): identical normals and distances, bit for bit — including a batch whose last row tile is
+    ragged (37 patches) and one below the big-tile threshold."""
+    fn, fd, _, _ = U.build_gpu_models(weights)
+    fn.knn_cache_mode = "fresh"
+    for nq in (64, 37, 1):
+        patch = U.sphere_patches(nq, 48, skip=500).to(U.dev())
+        monkeypatch.setenv("SAPCU_BT", "1")
+        n1, d1 = fn(patch), fd(patch)
+        monkeypatch.setenv("SAPCU_BT", "0")
+        n0, d0 = fn(patch), fd(patch)
+        assert torch.equal(n0, n1) and torch.equal(d0, d1), nq
