@@ -380,6 +380,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st);        // f32 MFMA (exact f3
 int launch_gemm_sf16(const GemmArgs& g, hipStream_t st);   // 3 x f16 MFMA, f32-quality (needs w16_hi/lo); f32 A
 int launch_gemm_sf16_ring(const GemmArgs& g, hipStream_t st);   // same arithmetic, A in split rows, 4-slot LDS-DMA ring
 int launch_gemm_sf16_bt(const GemmArgs& g, hipStream_t st);     // same arithmetic and results, 256 x 256/128 tiles (gemm_sf16_bt.hip)
+int launch_gemm_sf16_bt2(const GemmArgs& g, hipStream_t st);    // ... two workgroups per CU, 256 x 128 tiles, k-steps of 16 (SAPCU_BT=2)
 bool gemm_sf16_bt_ok(const GemmArgs& g);                        // ... for the shapes / epilogues it takes
 int launch_gemm_split_rows(const GemmArgs& g, hipStream_t st);  // picks between the two (model.hip; SAPCU_BT=0/1)
 int launch_split_weights(const float* w, int64_t count, void* hi, void* lo, int* ovf, hipStream_t st);

@@ -116,7 +116,7 @@ static inline int imin(int a, int b) { return a < b ? a : b; }
 int launch_gemm_split_rows(const GemmArgs& g, hipStream_t st) {
     const char* e = getenv("SAPCU_BT");                 // read per call: the parity test flips it inside one process
     const bool use_bt = !(e && strcmp(e, "0") == 0);
-    if (use_bt && gemm_sf16_bt_ok(g)) return launch_gemm_sf16_bt(g, st);
+    if (use_bt && gemm_sf16_bt_ok(g)) return (e && strcmp(e, "2") == 0) ? launch_gemm_sf16_bt2(g, st) : launch_gemm_sf16_bt(g, st);
     return launch_gemm_sf16_ring(g, st);
 }
 

@@ -997,7 +997,7 @@ def test_big_tile_gemm_is_bit_identical_to_the_ring_kernel(r, k, n, lif, csplit,
     As = torch.empty_like(A)
     _lib.check(lib.sapcu_to_split_rows(_lib.ptr(A), r, k, k, _lib.ptr(As), k, _lib.current_stream()))
     outs = []
-    for bt in ("0", "1"):
+    for bt in ("0", "1", "2"):                   # ring / big tile / big tile, two workgroups per CU
         monkeypatch.setenv("SAPCU_BT", bt)
         C = torch.full((r, n), float("nan"), device=U.dev())
         ws = torch.zeros(4 * n * k + 16, dtype=torch.uint8, device=U.dev())
@@ -1006,7 +1006,7 @@ def test_big_tile_gemm_is_bit_identical_to_the_ring_kernel(r, k, n, lif, csplit,
         torch.cuda.synchronize()
         outs.append(C.cpu().view(torch.int32))
     assert not bool(torch.isnan(outs[1].view(torch.float32)).any()) or csplit
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 @pytest.mark.parametrize("b,m,kk,d", [(4, 48, 12, 512), (3, 48, 18, 256), (5, 48, 24, 128), (37, 48, 12, 512)])
@@ -1024,7 +1024,7 @@ def test_big_tile_posenc_attention_gemm_is_bit_identical_to_the_ring_kernel(b, m
     P1s = torch.empty_like(P1)
     _lib.check(lib.sapcu_to_split_rows(_lib.ptr(P1), r, d, d, _lib.ptr(P1s), d, _lib.current_stream()))
     outs = []
-    for bt in ("0", "1"):
+    for bt in ("0", "1", "2"):
         monkeypatch.setenv("SAPCU_BT", bt)
         pe = torch.full((r, d), float("nan"), device=U.dev())
         att = torch.full((r, d), float("nan"), device=U.dev())
@@ -1036,6 +1036,7 @@ def test_big_tile_posenc_attention_gemm_is_bit_identical_to_the_ring_kernel(b, m
         outs.append((pe.cpu().view(torch.int32), att.cpu().view(torch.int32)))
     assert not bool(torch.isnan(outs[1][0].view(torch.float32)).any())
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
 
 
 def test_models_on_the_big_tile_kernel_equal_the_ring_kernel_bit_for_bit(weights, monkeypatch):
