@@ -897,7 +897,6 @@ def test_training_step_of_whole_fn_model_against_reference_run():
     unit normals, loss and the gradient of every parameter against the reference's own run (tests/golden/fn_train.npz).
     The in-patch kNN tables come from sapcu_patch_knn and must equal the reference's."""
     from sapcu_amd import train
-    from oracle import train_path as TP
     from test_oracle_golden import _fn_train_params, check_fn_train_grads
     g = golden("fn_train.npz")
     p, names = _fn_train_params(g, "cuda")
@@ -907,7 +906,7 @@ def test_training_step_of_whole_fn_model_against_reference_run():
         assert np.array_equal(np.sort(idx, axis=2), np.sort(g["knn%d" % i], axis=2))
     normals = train.fn_train_forward(p, pts)
     assert (normals.detach().cpu() - torch.from_numpy(g["normals"])).abs().max() <= 2e-4
-    loss = TP.angular_loss(normals, _dev(g["gt"]))                      # a dozen torch ops on [B, 3]: the checker's copy
+    loss, _ = train.angular_loss_with_consistency(normals, _dev(g["gt"]), None)      # the product's loss (no consistency term: [B, 3])
     assert abs(float(loss.detach()) - float(g["loss"])) <= 2e-4
     loss.backward()
     check_fn_train_grads(g, p, names, 2e-2, 5e-5)
