@@ -57,7 +57,7 @@ __device__ __forceinline__ float bt_load_f32(const float* p) {
 // 40 instructions and 3 scalar branches per stored element, 128 elements per lane and tile).  Same arithmetic, bit for bit.
 //   C_SPLIT / C2_SPLIT: c / c2 (attn_in) leave as split rows instead of f32.
 #ifdef SAPCU_BT_STAMPS      // diagnostic build (profiles/ablate.sh BT_STAMPS): where the time of a tile goes, waves 0 (A) and 4 (W)
-__device__ unsigned long long g_bt_stamps[256][2][12];
+__device__ unsigned long long g_bt_stamps[256][2][12 + 32];
 #define BT_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define BT_SEG(i, t0, t1) do { seg[i] += (t1) - (t0); } while (0)
 #else
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
     int64_t tm = first_tm;
     int tn = first_tn;
 #ifdef SAPCU_BT_STAMPS
-    unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    unsigned long long seg[12 + 32] = {0}, s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #endif
     for (int64_t ti = 0; ti < my_tiles; ++ti) {
 #pragma unroll
@@ -374,6 +374,7 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
             if (++nw == TW_SLOTS) nw = 0;
             BT_STAMP(s1);
             BT_SEG(kt == 0 ? 0 : (kt == 1 ? 1 : 2), s0, s1);          // whole k-step: first / second / later
+            BT_SEG(12 + (kt < 31 ? kt : 31), s0, s1);                 // ... and per k-step index
         }
         BT_STAMP(s0);
         // ---- epilogue in the accumulator layout: lane = column, register quad q = rows 8q + 4h + 0..3 of the 32x32 block
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
 #ifdef SAPCU_BT_STAMPS
     if ((wave == 0 || wave == 4) && lane == 0 && blockIdx.x < 256) {
         seg[11] = (unsigned long long)my_tiles;
-        for (int i = 0; i < 12; ++i) g_bt_stamps[blockIdx.x][wave >> 2][i] = seg[i];
+        for (int i = 0; i < 12 + 32; ++i) g_bt_stamps[blockIdx.x][wave >> 2][i] = seg[i];
     }
 #endif
 }

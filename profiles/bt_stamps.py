@@ -37,7 +37,7 @@ def main():
         _lib.check(lib.sapcu_gemm_f32(_lib.ptr(a2), r, k, k, _lib.ptr(w), n, _lib.ptr(b), _lib.ptr(lif) if lif_on else None, 4,
                                       _lib.ptr(c), n, _lib.ptr(ws), 1, 0, _lib.current_stream()))
     torch.cuda.synchronize()
-    out = np.zeros((256, 2, 12), dtype=np.uint64)
+    out = np.zeros((256, 2, 44), dtype=np.uint64)
     assert raw.sapcu_debug_bt_stamps(ctypes.c_void_p(out.ctypes.data)) == 0
     out = out[out[:, 0, 11] > 0].astype(np.float64)
     print("r=%d k=%d n=%d %s: %d workgroups, %.0f tiles each; s_memtime ticks PER TILE (median over workgroups)" %
@@ -48,6 +48,7 @@ def main():
         print(" %s: %.0f ticks per tile" % (nm, np.median(tot)))
         for i, name in enumerate(NAMES):
             print("   %-40s %8.0f   %5.1f %%" % (name, np.median(out[:, wv, i] / tiles), 100 * np.median(out[:, wv, i] / tiles / tot)))
+        print("   whole k-step by index in the tile: " + " ".join("%.0f" % np.median(out[:, wv, 12 + j] / tiles) for j in range(min(k // 32, 32))))
 
 
 if __name__ == "__main__":
