@@ -24,13 +24,22 @@ __device__ __forceinline__ float settle(float x) {
 __device__ __forceinline__ void settle4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 
 // "Split rows": a [rows, K] activation tensor whose producer already split every value for the split-f16
-// GEMM (gemm_sf16_ring.hip).  A row keeps the f32 row's footprint (pitch = ld floats = 4*ld bytes): the first
-// K halves are hi = f16_rn(x), the halves starting at half-index ld (byte 2*ld) are lo = f16_rn(x - hi).
+// GEMM (gemm_sf16_ring.hip, gemm_sf16_bt.hip): hi = f16_rn(x), lo = f16_rn(x - hi).  A row keeps the f32 row's footprint
+// (pitch = ld floats = 4*ld bytes = 2*ld halves).  Layout inside the row:
+//   ld % 32 == 0 (every tensor of the models): INTERLEAVED by groups of 32 elements — group q occupies one 128-byte line,
+//                hi halves of elements 32q..32q+31 at half-index 64q, their lo halves at 64q + 32.  One k-step of the GEMMs
+//                (32 elements) is then ONE line per row: with separate planes two consecutive k-steps shared every line (the
+//                first missed to HBM, the second waited behind it), and an epilogue's 32 lanes fill a whole line.
+//   otherwise:   hi halves at half-index col, lo halves at ld + col (two planes).
+__device__ __forceinline__ bool split_interleaved(int ld) { return (ld & 31) == 0; }
+__device__ __forceinline__ int split_hi_index(int ld, int col) { return split_interleaved(ld) ? ((col >> 5) << 6) + (col & 31) : col; }
+__device__ __forceinline__ int split_lo_index(int ld, int col) { return split_interleaved(ld) ? ((col >> 5) << 6) + 32 + (col & 31) : ld + col; }
+
 __device__ __forceinline__ void store_split(float* base, int64_t row, int ld, int col, float v) {
     _Float16* rp = reinterpret_cast<_Float16*>(base + row * ld);
     const _Float16 hi = (_Float16)v;
-    rp[col] = hi;
-    rp[ld + col] = (_Float16)(v - (float)hi);
+    rp[split_hi_index(ld, col)] = hi;
+    rp[split_lo_index(ld, col)] = (_Float16)(v - (float)hi);
 }
 
 // Epilogue of W accumulator elements of one lane: same column, rows row..row+W-1.  The W neuron chains
@@ -140,7 +149,7 @@ __device__ __forceinline__ void store_f32x4(float* base, int64_t row, int ld, in
     }
 }
 
-// ... of a split row: hi halves at half-index col, lo halves at ld + col (8-byte stores)
+// ... of a split row (8-byte stores)
 template <bool VEC>
 __device__ __forceinline__ void store_split4(float* base, int64_t row, int ld, int col, int n, const float (&v)[4]) {
     if (!VEC) {
@@ -156,8 +165,8 @@ __device__ __forceinline__ void store_split4(float* base, int64_t row, int ld, i
         hi[u] = (_Float16)v[u];
         lo[u] = (_Float16)(v[u] - (float)hi[u]);
     }
-    *reinterpret_cast<half4*>(rp + col) = hi;
-    *reinterpret_cast<half4*>(rp + ld + col) = lo;
+    *reinterpret_cast<half4*>(rp + split_hi_index(ld, col)) = hi;      // col % 4 == 0: the 4 columns stay inside one group
+    *reinterpret_cast<half4*>(rp + split_lo_index(ld, col)) = lo;
 }
 
 // acc = columns col..col+3 of `row` (row < g.r and col < g.n checked by the caller; n % 4 == 0).

@@ -141,8 +141,8 @@ __device__ __forceinline__ void bt_epilogue_fast(const GemmArgs& g, const f32x16
                 if (C_SPLIT) {
                     _Float16* rp = reinterpret_cast<_Float16*>(g.c + (row + u) * g.ldc);
                     const _Float16 hi = (_Float16)v[j][u];
-                    BT_STORE(rp + col, hi);
-                    BT_STORE(rp + g.ldc + col, (_Float16)(v[j][u] - (float)hi));
+                    BT_STORE(rp + split_hi_index(g.ldc, col), hi);
+                    BT_STORE(rp + split_lo_index(g.ldc, col), (_Float16)(v[j][u] - (float)hi));
                 } else {
                     BT_STORE(cp + (int64_t)u * g.ldc, v[j][u]);
                 }
@@ -154,8 +154,8 @@ __device__ __forceinline__ void bt_epilogue_fast(const GemmArgs& g, const f32x16
                     if (C2_SPLIT) {
                         _Float16* rp = reinterpret_cast<_Float16*>(g.c2 + (row + u) * g.ldc);
                         const _Float16 hi = (_Float16)ai;
-                        BT_STORE(rp + col, hi);
-                        BT_STORE(rp + g.ldc + col, (_Float16)(ai - (float)hi));
+                        BT_STORE(rp + split_hi_index(g.ldc, col), hi);
+                        BT_STORE(rp + split_lo_index(g.ldc, col), (_Float16)(ai - (float)hi));
                     } else {
                         BT_STORE(g.c2 + (row + u) * g.ldc + col, ai);
                     }
@@ -218,8 +218,10 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
     const int sub = wave & 3;
     const int dsb = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;         // source byte offset of this lane's (swizzled) LDS chunk
     const int64_t pitch_b = is_a ? 4 * (int64_t)g.lda : 2 * (int64_t)g.k;
-    const int64_t lo_delta = is_a ? 2 * (int64_t)g.lda
+    const bool a_il = is_a && (g.lda & 31) == 0;                    // interleaved split rows (gemm_epi.h): one line per row and k-step
+    const int64_t lo_delta = is_a ? (a_il ? 64 : 2 * (int64_t)g.lda)
                                   : reinterpret_cast<const char*>(g.w16_lo) - reinterpret_cast<const char*>(g.w16_hi);
+    const int kstep_bytes = a_il ? 128 : TBK * 2;
     const char* const op_base = is_a ? reinterpret_cast<const char*>(g.a) : reinterpret_cast<const char*>(g.w16_hi);
     const int pieces = is_a ? 4 : W_PIECES;                         // wave-uniform
     const int rows_per_wave = 16 * pieces;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
     int64_t issued = 0;
     auto issue = [&]() {
         lds_byte* sb = ring0 + issue_slot * slot_bytes;
-        const char* src = pf_base + pf_kt * (TBK * 2);
+        const char* src = pf_base + pf_kt * kstep_bytes;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             if (p < pieces) {
@@ -544,7 +546,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bt2_kernel(const GemmArgs g) {
     const int sub = wave & 1;
     const int dsb = ((lane & 1) ^ ((lane >> 4) & 1)) * 16;
     const int64_t pitch_b = is_a ? 4 * (int64_t)g.lda : 2 * (int64_t)g.k;
-    const int64_t lo_delta = is_a ? 2 * (int64_t)g.lda
+    const bool a_il = is_a && (g.lda & 31) == 0;                    // interleaved split rows (gemm_epi.h)
+    const int64_t lo_delta = is_a ? (a_il ? 64 : 2 * (int64_t)g.lda)
                                   : reinterpret_cast<const char*>(g.w16_lo) - reinterpret_cast<const char*>(g.w16_hi);
     const char* const op_base = is_a ? reinterpret_cast<const char*>(g.a) : reinterpret_cast<const char*>(g.w16_hi);
     const int pieces = is_a ? 4 : 2;
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bt2_kernel(const GemmArgs g) {
     int64_t issued = 0;
     auto issue = [&]() {
         lds_byte* sb = ring0 + issue_slot * slot_bytes;
-        const char* src = pf_base + pf_kt * (T2K * 2);
+        const char* src = pf_base + (a_il ? (pf_kt >> 1) * 128 + (pf_kt & 1) * 32 : pf_kt * (T2K * 2));
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             if (p < pieces) {

@@ -150,7 +150,9 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
         // DMA sources = wave-uniform base of the tile (scalar registers, all per-step arithmetic on the scalar unit)
         // + two 32-bit per-lane byte offsets (first / second 16-row piece) that only change with the tile (edge clamps)
         const int64_t pitch_b = is_a ? 4 * (int64_t)g.lda : 2 * (int64_t)g.k;     // bytes per operand row (hi plane)
-        const int64_t lo_delta = is_a ? 2 * (int64_t)g.lda
+        const bool a_il = is_a && (g.lda & 31) == 0;                // interleaved split rows (gemm_epi.h): one line per row and k-step
+        const int kstep_bytes = a_il ? 128 : RBK * 2;
+        const int64_t lo_delta = is_a ? (a_il ? 64 : 2 * (int64_t)g.lda)
                                       : reinterpret_cast<const char*>(g.w16_lo) - reinterpret_cast<const char*>(g.w16_hi);
         const char* const op_base = is_a ? reinterpret_cast<const char*>(g.a) : reinterpret_cast<const char*>(g.w16_hi);
         const int64_t total_steps = my_tiles * nk;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
         auto issue = [&]() {                                       // the 4 DMAs of this wave's next step
 #ifndef SAPCU_ABL_NO_DMA       // (compute-only experiment: the rings are never refilled)
             lds_byte* sb = ring0 + issue_slot * ROPSLOT;
-            const char* src = pf_base + pf_kt * (RBK * 2);
+            const char* src = pf_base + pf_kt * kstep_bytes;
 #ifdef SAPCU_ABL_A_CONTIG   // DRAM-locality experiment (garbage results): a k-step's activation slot is read as ONE contiguous
                             // 16 KiB run of the tile's region (what a tiled activation layout would give) instead of 128 x 2 x 64 B
             if (is_a) {

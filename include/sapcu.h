@@ -249,8 +249,10 @@ int sapcu_gemm_f32(const float* a, int64_t r, int k, int lda, const float* w, in
                    int c_split_rows, void* stream);
 
 /* f32 [rows,k] (row pitch ld_in floats) -> "split rows" (row pitch ld_out floats): each value x becomes two
- * f16 halves hi = f16_rn(x) at half-index c and lo = f16_rn(x - hi) at half-index ld_out + c of its row — the
- * operand format of the split-f16 ring GEMM.  Inside the models the producing kernels write it directly. */
+ * f16 halves hi = f16_rn(x) and lo = f16_rn(x - hi) inside its row — the operand format of the split-f16 DMA GEMMs.
+ * ld_out % 32 == 0: interleaved by groups of 32 elements, group q = one 128-byte line: hi halves of elements
+ * 32q..32q+31 at half-index 64q, their lo halves at 64q + 32.  Otherwise: hi at half-index c, lo at ld_out + c.
+ * Inside the models the producing kernels write it directly. */
 int sapcu_to_split_rows(const float* in, int64_t rows, int k, int ld_in, float* out, int ld_out, void* stream);
 
 /* The positional-encoding GEMM of one fn block — the heaviest single launch shape of the path:

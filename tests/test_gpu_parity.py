@@ -31,6 +31,17 @@ def _dev(a, dtype=None):
     return t.to(dtype) if dtype is not None else t
 
 
+def _decode_split_rows(t, n):
+    """[rows, n] f32 container holding split rows (csrc/gemm_epi.h) -> f32 values hi + lo.  n % 32 == 0: groups of 32 elements,
+    each one 128-byte line = 32 hi halves then 32 lo halves; otherwise hi halves at [0, n), lo halves at [n, 2n)."""
+    rows = t.shape[0]
+    halves = t.contiguous().view(torch.float16).view(rows, 2 * n).float()
+    if n % 32 == 0:
+        g = halves.view(rows, n // 32, 2, 32)
+        return (g[:, :, 0, :] + g[:, :, 1, :]).reshape(rows, n)
+    return halves[:, :n] + halves[:, n:]
+
+
 # ------------------------------------------------------------------------------- outer kNN
 def test_outer_knn_bit_exact_golden_and_patches():
     from sapcu_amd import testing as T
@@ -206,9 +217,8 @@ def test_ring_gemm_neuron_epilogue_and_split_row_output(r, k, n, csplit):
                                   _lib.ptr(ws), 1, csplit, _lib.current_stream()))
     torch.cuda.synchronize()
     got = C.cpu()
-    if csplit:                                   # decode split rows: hi halves at [0, n), lo halves at [n, 2n) of each row
-        halves = got.view(torch.float16).view(r, 2 * n).float()
-        got = halves[:, :n] + halves[:, n:]
+    if csplit:
+        got = _decode_split_rows(got, n)
     pre = torch.from_numpy((a.astype(np.float64) @ w.astype(np.float64).T + bias).astype(np.float32))
     names = ["membrane_decay", "threshold_adapt", "refractory_decay", "threshold_base"]
     prm = O.neuron_params({"n." + names[i]: torch.from_numpy(raw[i]) for i in range(4)}, "n")
@@ -250,8 +260,7 @@ def test_posenc_gemm_attention_epilogue(mode, b, m, kk, d):
     torch.cuda.synchronize()
     pe, att = pe.cpu(), att.cpu()
     if split:                                    # attn_in leaves as split rows (pe stays f32)
-        halves = att.view(torch.float16).view(r, 2 * d).float()
-        att = halves[:, :d] + halves[:, d:]
+        att = _decode_split_rows(att, d)
     pre = torch.from_numpy((pe1.astype(np.float64) @ w.astype(np.float64).T + bias).astype(np.float32))
     names = ["membrane_decay", "threshold_adapt", "refractory_decay", "threshold_base"]
     prm = O.neuron_params({"n." + names[i]: torch.from_numpy(raw[i]) for i in range(4)}, "n")
