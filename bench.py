@@ -276,6 +276,8 @@ def main():
                        "queries_per_gpu_per_step": B_PER_GPU, "cloud_points": N_CLOUD, "neighbours": M_PTS,
                        "time_steps": T_STEPS, "outer_knn": "f64 brute force", "parallelism": "query shards x%d" % world},
             "per_gpu": round(total / dt / world, 2),
+            # canonical (dead-stage-eliminated, EdgeConv-factored) algorithmic work = 1.850 GFLOP per query
+            "algorithmic_tflops": round(total / dt * 1.850e9 / 1e12, 2),
         }
         log("timed %d steps: %.1f ms/step" % (args.steps, dt / args.steps * 1e3))
         if not args.no_roofline:
