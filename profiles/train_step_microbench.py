@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batches", default="4,32")
+    ap.add_argument("--graph", action="store_true", help="replay the step as a HIP graph (fn_trainer.GraphedTrainStep)")
     args = ap.parse_args()
     out = []
     for B in [int(b) for b in args.batches.split(",")]:
@@ -28,7 +29,7 @@ def main():
                                                       use_snn_decoder=False, decoder_dropout=0.1)
         model.load_state_dict(T.training_state_dict(model.state_dict(), 3), strict=True)
         model.cuda()
-        opt = torch.optim.AdamW(model.parameters(), lr=1.8e-4, weight_decay=1e-4, betas=(0.9, 0.999))
+        opt = torch.optim.AdamW(model.parameters(), lr=1.8e-4, weight_decay=1e-4, betas=(0.9, 0.999), capturable=args.graph)
         tr = fn_trainer.Trainer(model, opt, device=torch.device("cuda"), grad_clip=0.15, grad_clip_type="norm")
         rng = np.random.default_rng(0)
         NP, M = 64, 12
@@ -36,18 +37,19 @@ def main():
         pts = torch.tensor((centres + rng.normal(size=(B, NP, M, 3)) * np.array([0.08, 0.08, 0.01])).astype(np.float32)).cuda()
         gt = torch.tensor(rng.normal(size=(B, NP, 3)).astype(np.float32)).cuda()
         data = {"input": pts, "normal": gt}
+        step = fn_trainer.GraphedTrainStep(tr, data, warmup=args.warmup) if args.graph else tr.train_step
         for _ in range(args.warmup):
-            tr.train_step(data)
+            step(data)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         done = 0
         for _ in range(args.steps):
-            loss, _ = tr.train_step(data)
+            loss, _ = step(data)
             done += loss is not None
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
         out.append({"batch_clouds": B, "patches": B * NP, "points_per_patch": M, "ms_per_step": round(dt * 1e3, 3),
-                    "clouds_per_s": round(B / dt, 1), "patches_per_s": round(B * NP / dt, 1), "steps_ok": done, "last_loss": loss})
+                    "graph": bool(args.graph), "clouds_per_s": round(B / dt, 1), "patches_per_s": round(B * NP / dt, 1), "steps_ok": done, "last_loss": loss})
         print(json.dumps(out[-1]), flush=True)
 
 

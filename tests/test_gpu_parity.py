@@ -1060,3 +1060,4 @@ def test_models_on_the_big_tile_kernel_equal_the_ring_kernel_bit_for_bit(weights
         monkeypatch.setenv("SAPCU_BT", "0")
         n0, d0 = fn(patch), fd(patch)
         assert torch.equal(n0, n1) and torch.equal(d0, d1), nq
+
