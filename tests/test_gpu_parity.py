@@ -1061,3 +1061,33 @@ def test_models_on_the_big_tile_kernel_equal_the_ring_kernel_bit_for_bit(weights
         n0, d0 = fn(patch), fd(patch)
         assert torch.equal(n0, n1) and torch.equal(d0, d1), nq
 
+
+def test_graph_captured_training_step_equals_the_eager_step():
+    """fn_trainer.GraphedTrainStep (one optimisation step replayed as a HIP graph) against Trainer.train_step from the same
+    initial state, dropout off: same first loss, finite losses and gradient norms on every replay (the scatter-add targets
+    must be re-zeroed inside the graph), and parameters that stay close to the eager run's after four AdamW steps."""
+    import copy
+    import sapcu_amd
+    from sapcu_amd import fn_trainer, testing as T
+    g = golden("fn_trainer.npz")
+    kw = dict(k_values=[24, 18, 12], emb_dims=640, time_steps_enc=4, time_steps_dec=12, num_heads=8, use_snn_decoder=False, decoder_dropout=0.1)
+    sd = T.training_state_dict(sapcu_amd.ImprovedSNNNormalEstimation(**kw).state_dict(), int(g["seed"]))
+    data = {"input": torch.from_numpy(g["points"]), "normal": torch.from_numpy(g["gt"])}
+    results = []
+    for graphed in (False, True):
+        model = sapcu_amd.ImprovedSNNNormalEstimation(**kw)
+        model.load_state_dict(copy.deepcopy(sd), strict=True)
+        model.attn_dropout = model.decoder_dropout = 0.0
+        model.cuda()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=True)
+        tr = fn_trainer.Trainer(model, opt, device=torch.device("cuda"), grad_clip=0.15, grad_clip_type="norm")
+        step = fn_trainer.GraphedTrainStep(tr, data, warmup=0) if graphed else tr.train_step     # (capturing runs no kernels)
+        losses = [step(data)[0] for _ in range(4)]
+        assert all(l is not None and np.isfinite(l) for l in losses), losses
+        results.append((losses, {n: p.detach().cpu().clone() for n, p in model.named_parameters()}))
+    (le, pe), (lg, pg) = results
+    # the first steps agree; later ones drift apart the way two eager runs do (float atomics in the scatter-adds reorder sums,
+    # a hard spike flips, and the loss of a 16-patch batch moves by 0.1)
+    assert abs(le[0] - lg[0]) <= 1e-5 and max(abs(a - b) for a, b in zip(le, lg)) <= 0.3, (le, lg)
+    worst = max(float((pe[n] - pg[n]).abs().max()) for n in pe)
+    assert worst <= 1.2e-3, worst           # four AdamW steps of lr 1e-4: each moves a weight by at most ~lr, in either direction
