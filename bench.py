@@ -2,12 +2,21 @@
 """Headline benchmark: upsampled query-points/s on the BASELINE.json config
 "Synthetic sphere 5000 pts, 4x upsample, M=48 T=4, 1xMI355X".
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
+
+N > 1: one process per GPU over RCCL.  Started by ``torch.distributed.run`` (RANK / WORLD_SIZE in the environment) the
+ranks run directly; started as a plain command, this process spawns ``python -m torch.distributed.run --nproc-per-node N``
+of itself BEFORE touching the GPU and exits with the child's code.  On a box with fewer than N GPUs the run is a
+REHEARSAL (every rank on cuda:0, gloo): it exercises sharding, barriers, the all-gather and the max-over-ranks timing;
+the line says "rehearsal": true and its numbers mean nothing.
 
 A step = ONE pass of the hot path over one resident batch of B=4096 query points per GPU:
 outer kNN + gather/centre -> fn forward -> normalise -> gather/rotate -> fd forward -> displace
 (+ for N > 1 the all-gather of the refined points).  Inputs (cloud, queries, weights) are in HBM
-before the timed region.  Weak scaling: every rank refines its own 4096 queries per step.
+before the timed region.  Weak scaling (default, the BASELINE workload): every rank refines its own 4096 queries per
+step.  --scaling strong: a step = the whole 385 582-seed cloud of the same sphere (its real dense-grid seeds), sharded
+contiguously over the ranks, one all-gather of the refined cloud per step; the default run also times one such pass as
+the extra object "strong_scaling" so that the driver's N = 1, 2, 4, 8 runs give a strong-scaling curve too.
 
 Extra objects on the JSON line:
   roofline      the dominant kernel (the positional-encoding GEMM gemm_bt_kernel<EPI_LIF_ATTN, .>,
@@ -138,9 +147,10 @@ def roofline_leg(dev, reps=3):
 
 
 def knn_leg(dev, cloud, seeds, reps=20):
-    """The outer kNN kernel alone on the bench workload, in the north-star's accounting: every query streams the whole
-    f64 cloud (B * N * 24 bytes) against the HBM peak.  (The kernel tiles the cloud through LDS, so its real HBM traffic
-    is far smaller; DESIGN.md section 4 discusses the model.)"""
+    """The outer kNN kernel alone on the bench workload against SURVEY.md 8(d)'s streamed-bytes model: every query streams
+    the cloud once at 12 B per point (fp32-equivalent), B * N * 12 bytes per launch against the 8 TB/s HBM peak.  The
+    kernel tiles the f64 cloud (120 KB) through LDS, so its real HBM traffic is ~5 MB per launch; its physical bound is
+    f64 VALU issue.  `frac_24B` is the same with the 24 B per point the kernel really reads."""
     from sapcu_amd import generation as gen
     gen.knn_gather(cloud, seeds, M_PTS)
     torch.cuda.synchronize()
@@ -151,12 +161,12 @@ def knn_leg(dev, cloud, seeds, reps=20):
     e1.record()
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) * 1e-3 / reps
-    streamed = float(seeds.shape[0]) * cloud.shape[0] * 24.0
+    streamed = float(seeds.shape[0]) * cloud.shape[0] * 12.0
     return {"kernel": "knn_outer_kernel", "us": round(t * 1e6, 1),
-            "model": "B*N*24 bytes streamed per launch (the f64 coordinates the kernel reads; SURVEY.md 8d also names an "
-                     "fp32-equivalent B*N*12 model: frac_12B)",
+            "model": "SURVEY.md 8(d): B*N*12 bytes streamed per launch (fp32-equivalent cloud per query)",
             "achieved": round(streamed / t / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(streamed / t / 1e9 / PEAK_HBM_GBS, 4), "frac_12B": round(streamed / 2 / t / 1e9 / PEAK_HBM_GBS, 4)}
+            "frac": round(streamed / t / 1e9 / PEAK_HBM_GBS, 4), "frac_24B": round(2 * streamed / t / 1e9 / PEAK_HBM_GBS, 4),
+            "pair_distances_per_s": round(float(seeds.shape[0]) * cloud.shape[0] / t, 0)}
 
 
 def cpu_baseline(sdn, sdd, sample=64):
@@ -185,21 +195,47 @@ def cpu_baseline(sdn, sdd, sample=64):
             "sample": "%d of the %d queries, one chunk, oracle (torch-CPU restatement), %.1f s" % (sample, B_PER_GPU, dt)}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` as a plain command: start one rank per GPU through torch.distributed.run as a CHILD
+    process (this process has not touched the GPU: device_count() does not initialise it) and return its exit code."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if n_dev < args.gpus:
+        if args.gpus > 6:
+            raise SystemExit("--gpus %d on a box with %d GPU(s): a rehearsal keeps every rank on cuda:0 and at most 6 "
+                             "processes may share it" % (args.gpus, n_dev))
+        env["SAPCU_BENCH_REHEARSE"] = "1"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+STRONG_CLOUD_SPACING = 0.004        # generation.py:69 default dense_spacing -> 385 582 seeds on the N=5000 sphere
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-strong-leg", action="store_true", help="skip the extra whole-cloud pass of the weak mode")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            raise SystemExit(spawn_ranks(args))
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     # SAPCU_BENCH_REHEARSE=1: every rank on cuda:0 with the gloo backend — exercises the N > 1 code path (sharding, barriers,
     # all-gather, max-over-ranks timing) on a one-GPU box; the numbers of such a run mean nothing.
@@ -217,17 +253,35 @@ def main():
     import sapcu_amd
     from sapcu_amd import testing as T
     from sapcu_amd import dist as sdist
+    from sapcu_amd import generation as sgen
     fn, fd, sdn, sdd = build_models(dev)
     gen = sapcu_amd.Generator3D6(fn, fd, dev, k_neighbors=M_PTS, batch_size=B_PER_GPU)
-    cloud = torch.as_tensor(T.sphere_cloud(N_CLOUD, 0), device=dev)
+    cloud_host = T.sphere_cloud(N_CLOUD, 0)
+    cloud = torch.as_tensor(cloud_host, device=dev)
     seeds = torch.as_tensor(T.grid_queries(B_PER_GPU * world, 0)[rank * B_PER_GPU:(rank + 1) * B_PER_GPU], device=dev)
+    strong = args.scaling == "strong"
+    want_strong_leg = strong or not args.no_strong_leg
+    all_seeds = None
+    if want_strong_leg:       # the cloud's real seeds (in-process dense grid flood, same on every rank), resident before timing
+        all_seeds = torch.as_tensor(sgen.dense_seeds(cloud_host, STRONG_CLOUD_SPACING), device=dev)
 
-    def step():
+    def weak_step():
         with torch.no_grad():
             refined, _, _ = gen.refine(cloud, seeds)
             if world > 1:
-                refined = sdist.gather_refined(refined, B_PER_GPU * world)
+                refined = sdist.gather_refined(refined, B_PER_GPU * world)   # the one collective of the path
         return refined
+
+    def strong_step():
+        n = all_seeds.shape[0]
+        s, e = sdist.shard_range(n, rank, world)
+        with torch.no_grad():
+            refined, _, _ = gen.refine(cloud, all_seeds[s:e])
+            if world > 1:
+                refined = sdist.gather_refined(refined, n)
+        return refined
+
+    step = strong_step if strong else weak_step
 
     def barrier():
         if world > 1:
@@ -238,48 +292,73 @@ def main():
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
+    def timed(fn_step, k):
+        """k steps between barrier + synchronize on both sides; MAX over ranks (seconds)"""
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            out = fn_step()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        assert torch.isfinite(out).all()
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([dt], dtype=torch.float64, device=torch.device("cpu") if rehearse else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, out
+
     log("models and inputs resident; warmup x%d" % args.warmup)
     for i in range(args.warmup):
         tw = time.perf_counter()
         step()
         torch.cuda.synchronize()
         log("warmup step %d: %.1f ms" % (i, (time.perf_counter() - tw) * 1e3))
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    assert torch.isfinite(out).all()
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, out = timed(step, args.steps)
+    per_step = all_seeds.shape[0] if strong else B_PER_GPU * world
+    log("timed %d steps: %.1f ms/step" % (args.steps, dt / args.steps * 1e3))
+
+    strong_leg = None
+    if want_strong_leg and not strong:
+        # one whole-cloud pass (385 582 seeds sharded over the ranks + the all-gather), after one untimed pass at N > 1 so
+        # that RCCL's buffers for this message size exist
+        if world > 1:
+            strong_step()
+        dts, outs = timed(strong_step, 1)
+        strong_leg = {"seeds": int(all_seeds.shape[0]), "n_gpus": world, "ms_per_pass": round(dts * 1e3, 2),
+                      "value": round(all_seeds.shape[0] / dts, 2), "unit": "query-points/s", "scaling": "strong",
+                      "collective": "one all-gather of the refined [n,3] f64 cloud per pass"}
+        log("strong-scaling leg: %s" % strong_leg)
 
     line = None
     if rank == 0:
-        total = B_PER_GPU * world * args.steps
+        total = per_step * args.steps
         line = {
             "metric": "upsampled query-points/sec (kNN + fn fwd + rotate + fd fwd + displace), 4x scale, M=48 T=4",
             "value": round(total / dt, 2), "unit": "query-points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
+            "scaling": args.scaling, "vs_baseline": None,
             "dtype": ("f32 (GEMMs on the exact-f32 MFMA kernels, SAPCU_GEMM=f32; outer kNN f64)" if os.environ.get("SAPCU_GEMM") == "f32"
                       else "f32 (GEMMs as 3 x f16 MFMA with f32 accumulation; outer kNN f64)"), "data": "synthetic",
-            "config": {"workload": "synthetic sphere N=%d (seed 0), B=%d grid queries per GPU per step, M=%d, T=%d, "
-                                   "fn k=[24,18,12] emb 640, fd k=32 scales [8,16,32,48] emb 768, conditioned-random "
-                                   "weights seed 0, in-patch kNN recomputed every batch" % (N_CLOUD, B_PER_GPU, M_PTS, T_STEPS),
-                       "queries_per_gpu_per_step": B_PER_GPU, "cloud_points": N_CLOUD, "neighbours": M_PTS,
+            "config": {"workload": ("synthetic sphere N=%d (seed 0), %s, M=%d, T=%d, "
+                                    "fn k=[24,18,12] emb 640, fd k=32 scales [8,16,32,48] emb 768, conditioned-random "
+                                    "weights seed 0, in-patch kNN recomputed every batch"
+                                    % (N_CLOUD, ("all %d dense-grid seeds of the cloud (spacing %.3f) sharded over the GPUs per step"
+                                                 % (per_step, STRONG_CLOUD_SPACING)) if strong else
+                                       "B=%d grid queries per GPU per step" % B_PER_GPU, M_PTS, T_STEPS)),
+                       "queries_per_step": per_step, "cloud_points": N_CLOUD, "neighbours": M_PTS,
                        "time_steps": T_STEPS, "outer_knn": "f64 brute force", "parallelism": "query shards x%d" % world},
             "per_gpu": round(total / dt / world, 2),
             # SURVEY.md 8d: canonical (dead-stage-eliminated, EdgeConv-factored) algorithmic work = 1.850 GFLOP per query
             "algorithmic_tflops": round(total / dt * 1.850e9 / 1e12, 2),
         }
-        log("timed %d steps: %.1f ms/step" % (args.steps, dt / args.steps * 1e3))
+        if rehearse:
+            line["rehearsal"] = True
+        if strong_leg:
+            line["strong_scaling"] = strong_leg
         if not args.no_roofline:
             line["roofline"] = roofline_leg(dev)
             log("roofline leg done: %s" % line["roofline"])

@@ -335,8 +335,7 @@ __device__ __forceinline__ float lrelu02(float x) { return x >= 0.f ? x : 0.2f *
 // ---------------------------------------------------------------------------------------------
 // GEMM (gemm_f32.hip):  C[r,n] = epi( pro(A)[r,k] * W[n,k]^T + bias[n] )
 // ---------------------------------------------------------------------------------------------
-enum GemmEpi { EPI_BIAS = 0, EPI_LIF = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_LRELU = 4, EPI_RESID_GELU = 5, EPI_LIF_ATTN = 6,
-               EPI_SOFTMAX_AGG = 7 };   // ring kernel only: C is never stored (see the sm_* fields)
+enum GemmEpi { EPI_BIAS = 0, EPI_LIF = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_LRELU = 4, EPI_RESID_GELU = 5, EPI_LIF_ATTN = 6 };
 
 struct GemmArgs {
     const float* a;      // [r, lda]
@@ -366,21 +365,11 @@ struct GemmArgs {
     int* ovf;            // device counter raised when an activation tile exceeds the f16 range (may be null)
     // "split rows" (gemm_epi.h): A already split by its producer -> all-DMA ring kernel; outputs to be split
     int a_split, c_split, c2_split;
-    // EPI_SOFTMAX_AGG (fn/snn_coder.py:378-389 fused into fc_gamma2): rows are (point, neighbour slot) edges, sm_kk per
-    // point; per (point, column): w_j = softmax_j((acc_j + bias) / sm_sqrt_hd), c[point, col] = sum_j w_j * (sm_v[nbr_j] + sm_pe[row_j]).
-    // c / ldc / c_split describe the [points, n] result.  Requires a_split and sm_kk <= 64.
-    int sm_kk, sm_m;              // neighbours per point, points per patch
-    const int32_t* sm_idx;        // [r] neighbour index inside the patch of every edge row
-    const float* sm_pe;           // [r, sm_ldpe] f32
-    const float* sm_v;            // [points, sm_ldv] f32
-    int sm_ldpe, sm_ldv;
-    float sm_sqrt_hd;
 };
 int launch_gemm(const GemmArgs& g, hipStream_t st);        // f32 MFMA (exact f32 products)
 int launch_gemm_sf16(const GemmArgs& g, hipStream_t st);   // 3 x f16 MFMA, f32-quality (needs w16_hi/lo); f32 A
 int launch_gemm_sf16_ring(const GemmArgs& g, hipStream_t st);   // same arithmetic, A in split rows, 4-slot LDS-DMA ring
 int launch_gemm_sf16_bt(const GemmArgs& g, hipStream_t st);     // same arithmetic and results, 256 x 256/128 tiles (gemm_sf16_bt.hip)
-int launch_gemm_sf16_bt2(const GemmArgs& g, hipStream_t st);    // ... two workgroups per CU, 256 x 128 tiles, k-steps of 16 (SAPCU_BT=2)
 bool gemm_sf16_bt_ok(const GemmArgs& g);                        // ... for the shapes / epilogues it takes
 int launch_gemm_split_rows(const GemmArgs& g, hipStream_t st);  // picks between the two (model.hip; SAPCU_BT=0/1)
 int launch_split_weights(const float* w, int64_t count, void* hi, void* lo, int* ovf, hipStream_t st);

@@ -181,7 +181,6 @@ __device__ __forceinline__ void epilogue_row4_compute(const GemmArgs& g, const f
     v[3] = __fmaf_rn(acc.w, 0.0625f, cp.bias.w);
     float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
     if (EPI == EPI_RESID || EPI == EPI_RESID_GELU) res = ld4_cols<VEC>(g.resid + row * g.ldr, col, g.n);
-#ifndef SAPCU_ABL_NO_LIF          // (profiling ablations: profiles/ablate.sh)
     if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) {
         f32x2 pv[2] = {f32x2{v[0], v[1]}, f32x2{v[2], v[3]}};
         NeuronP2 np[2];
@@ -189,7 +188,6 @@ __device__ __forceinline__ void epilogue_row4_compute(const GemmArgs& g, const f
         lif_selfloop_pairs<2>(pv, np, g.lif_T);
         v[0] = pv[0].x; v[1] = pv[0].y; v[2] = pv[1].x; v[3] = pv[1].y;
     }
-#endif
     const float rs[4] = {res.x, res.y, res.z, res.w};
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -227,12 +225,10 @@ __device__ __forceinline__ void epilogue_row4_store(const GemmArgs& g, const flo
     } else {
         store_f32x4<VEC>(g.c, row, g.ldc, col, g.n, v);
     }
-#ifndef SAPCU_ABL_NO_C2
     if (EPI == EPI_LIF_ATTN) {
         if (g.c2_split) store_split4<VEC>(g.c2, row, g.ldc, col, g.n, ai);
         else store_f32x4<VEC>(g.c2, row, g.ldc, col, g.n, ai);
     }
-#endif
 }
 
 template <int EPI>

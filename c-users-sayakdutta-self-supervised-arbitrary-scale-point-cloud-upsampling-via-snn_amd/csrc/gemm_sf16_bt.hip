@@ -56,31 +56,7 @@ __device__ __forceinline__ float bt_load_f32(const float* p) {
 // — no per-element row masks, no run-time format branches, no overflow counter (the generic epilogue_group4 path costs about
 // 40 instructions and 3 scalar branches per stored element, 128 elements per lane and tile).  Same arithmetic, bit for bit.
 //   C_SPLIT / C2_SPLIT: c / c2 (attn_in) leave as split rows instead of f32.
-#ifdef SAPCU_BT_STAMPS      // diagnostic build (profiles/ablate.sh BT_STAMPS): where the time of a tile goes, waves 0 (A) and 4 (W)
-__device__ unsigned long long g_bt_stamps[256][2][12 + 32];
-#define BT_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define BT_SEG(i, t0, t1) do { seg[i] += (t1) - (t0); } while (0)
-#else
-#define BT_STAMP(t) do { } while (0)
-#define BT_SEG(i, t0, t1) do { } while (0)
-#endif
 
-// Epilogue stores.  SAPCU_BT_STORE_POLICY = 1 / 2 / 3 (diagnostic builds): "nt" / "sc1" / "sc0 sc1" cache-policy bits through inline asm
-// (hipcc's __builtin_nontemporal_store emits a plain store here).
-#ifdef SAPCU_BT_STORE_POLICY
-#if SAPCU_BT_STORE_POLICY == 1
-#define BT_POLICY_STR "nt"
-#elif SAPCU_BT_STORE_POLICY == 2
-#define BT_POLICY_STR "sc1"
-#else
-#define BT_POLICY_STR "sc0 sc1"
-#endif
-__device__ __forceinline__ void bt_store(float* p, float v) { asm volatile("global_store_dword %0, %1, off " BT_POLICY_STR :: "v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void bt_store(_Float16* p, _Float16 v) { asm volatile("global_store_short %0, %1, off " BT_POLICY_STR :: "v"(p), "v"(v) : "memory"); }
-#define BT_STORE(p, v) bt_store((p), (v))
-#else
-#define BT_STORE(p, v) (*(p) = (v))
-#endif
 
 template <int EPI, int CT, bool C_SPLIT, bool C2_SPLIT>
 __device__ __forceinline__ void bt_epilogue_fast(const GemmArgs& g, const f32x16 (&acc)[4][CT], int64_t row0, int col0, int r32, int h,
@@ -97,9 +73,6 @@ __device__ __forceinline__ void bt_epilogue_fast(const GemmArgs& g, const f32x16
 #pragma unroll
     for (int gi = 0; gi < 16; ++gi) {
         const int i = gi >> 2, q4 = gi & 3;
-#ifdef SAPCU_ABL_BT_QUARTER_EPI   // diagnostic: a quarter of the epilogue (is its cost per store or per tile?)
-        if (q4 != 0) continue;
-#endif
         const int64_t row = row0 + i * 32 + 8 * q4 + 4 * h;
         float qv[CT][4], kv[CT][4];
         if (ATTN) {
@@ -136,15 +109,13 @@ __device__ __forceinline__ void bt_epilogue_fast(const GemmArgs& g, const f32x16
             float* cp = g.c + row * g.ldc + col;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                // non-temporal (streaming) stores: a tile round writes 8 MiB per XCD through a 4 MiB L2 that the k-loop needs for
-                // the weight tile and the shared activation panel; nobody re-reads these lines before they leave the cache
                 if (C_SPLIT) {
                     _Float16* rp = reinterpret_cast<_Float16*>(g.c + (row + u) * g.ldc);
                     const _Float16 hi = (_Float16)v[j][u];
-                    BT_STORE(rp + split_hi_index(g.ldc, col), hi);
-                    BT_STORE(rp + split_lo_index(g.ldc, col), (_Float16)(v[j][u] - (float)hi));
+                    rp[split_hi_index(g.ldc, col)] = hi;
+                    rp[split_lo_index(g.ldc, col)] = (_Float16)(v[j][u] - (float)hi);
                 } else {
-                    BT_STORE(cp + (int64_t)u * g.ldc, v[j][u]);
+                    cp[(int64_t)u * g.ldc] = v[j][u];
                 }
             }
             if (ATTN) {
@@ -154,10 +125,10 @@ __device__ __forceinline__ void bt_epilogue_fast(const GemmArgs& g, const f32x16
                     if (C2_SPLIT) {
                         _Float16* rp = reinterpret_cast<_Float16*>(g.c2 + (row + u) * g.ldc);
                         const _Float16 hi = (_Float16)ai;
-                        BT_STORE(rp + split_hi_index(g.ldc, col), hi);
-                        BT_STORE(rp + split_lo_index(g.ldc, col), (_Float16)(ai - (float)hi));
+                        rp[split_hi_index(g.ldc, col)] = hi;
+                        rp[split_lo_index(g.ldc, col)] = (_Float16)(ai - (float)hi);
                     } else {
-                        BT_STORE(g.c2 + (row + u) * g.ldc + col, ai);
+                        g.c2[(row + u) * g.ldc + col] = ai;
                     }
                 }
             }
@@ -202,14 +173,6 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
         step_tn = wgs_per_x - (int)step_tm * ntn;
     }
     if (my_tiles == 0) return;
-#ifdef SAPCU_BT_STAGGER
-    // Epilogues are write bursts (256 KiB per workgroup): started together, all 256 workgroups hit them together and the
-    // burst drains at the HBM write rate while nobody computes.  Start the workgroup pairs of an XCD in 8 phases.
-    {
-        const int phase = ((blockIdx.x >> 3) >> (ntn > 1 ? 1 : 0)) & 7;
-        for (int i = 0; i < phase * SAPCU_BT_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     const int64_t first_tm = first_logical / ntn;
     const int first_tn = (int)(first_logical - first_tm * ntn);
 
@@ -313,9 +276,6 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
     };
     f32x16 acc[4][CT];
     auto mfma_all = [&](const Frags& f) {
-#ifdef SAPCU_ABL_BT_NO_MFMA   // delivery + epilogue only (diagnostic build, garbage results)
-        return;
-#endif
         // same product order per accumulator as the ring kernel (a_lo.w_hi, a_hi.w_lo, a_hi.w_hi); consecutive MFMAs go to
         // different accumulators.  (Tried: the weight fragment as the first operand, which transposes the block into the row
         // layout of gemm_epi.h — 16-byte stores, but only 32 contiguous bytes per row and instruction: 10 % slower.)
@@ -340,9 +300,6 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
     int64_t gstep = 0;
     int64_t tm = first_tm;
     int tn = first_tn;
-#ifdef SAPCU_BT_STAMPS
-    unsigned long long seg[12 + 32] = {0}, s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-#endif
     for (int64_t ti = 0; ti < my_tiles; ++ti) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -352,17 +309,11 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         read_frags(ca, cw, 0, f0);          // (not prefetched across the tile boundary: the epilogue needs those 48 registers)
         for (int kt = 0; kt < nk; ++kt, ++gstep) {
-            BT_STAMP(s0);
             read_frags(ca, cw, 1, f1);
             mfma_all(f0);
-            BT_STAMP(s1);
             if (gstep + 1 < total_steps) {
                 wait_landed(gstep + 1);
-                BT_STAMP(s2);
                 lds_barrier();                                        // step gstep+1 is in for everyone; this step's slots fully read
-                BT_STAMP(s3);
-                BT_SEG(kt == 0 ? 3 : (kt == 1 ? 4 : 5), s1, s2);      // wait for own DMAs: first / second / later k-steps of a tile
-                BT_SEG(kt == 0 ? 6 : (kt == 1 ? 7 : 8), s2, s3);      // barrier
                 // the activation waves defer the refill of a tile's LAST step to the start of the epilogue (see there)
                 if (issued < total_steps && !(is_a && kt + 1 == nk)) issue();
                 if (kt + 1 < nk) read_frags(na, nw, 0, f0);
@@ -374,19 +325,8 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
             cw = nw;
             if (++na == TA_SLOTS) na = 0;
             if (++nw == TW_SLOTS) nw = 0;
-            BT_STAMP(s1);
-            BT_SEG(kt == 0 ? 0 : (kt == 1 ? 1 : 2), s0, s1);          // whole k-step: first / second / later
-            BT_SEG(12 + (kt < 31 ? kt : 31), s0, s1);                 // ... and per k-step index
         }
-        BT_STAMP(s0);
         // ---- epilogue in the accumulator layout: lane = column, register quad q = rows 8q + 4h + 0..3 of the 32x32 block
-#ifdef SAPCU_ABL_BT_NO_EPI    // k-loop only (diagnostic build: one store per tile keeps the accumulators alive)
-        if (acc[0][0][0] == 12345.678f) g.c[0] = acc[3][CT - 1][15] + acc[1][0][7] + acc[2][0][3];
-        tm += step_tm;
-        tn += step_tn;
-        if (tn >= ntn) { tn -= ntn; ++tm; }
-        continue;
-#endif
         const int64_t row0 = tm * TBM + wm * 128;
         const int col0 = tn * BN + wn * 32 * CT;
         // column parameters of this lane for BOTH column blocks up front: a load waited for in the middle of the epilogue would
@@ -410,8 +350,6 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
         // the first waits of the next tile (steps issued before this point) unnecessary: landed_upto.  The deferred refill goes
         // out now, before the stores; the waits that follow it come one k-step or more after the last store.
         bt_wait_vm<0>();
-        BT_STAMP(s1);
-        BT_SEG(9, s0, s1);                                            // parameter loads + their wait
         landed_upto = issued;
         if (is_a && issued < total_steps) issue();
         __builtin_amdgcn_sched_barrier(0);
@@ -440,9 +378,6 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
             for (int q4 = 0; q4 < 4; ++q4) {
                 const int64_t row = row0 + i * 32 + 8 * q4 + 4 * h;
                 if (row >= g.r) continue;
-#ifdef SAPCU_ABL_BT_QUARTER_EPI   // diagnostic: a quarter of the epilogue (is its cost per store or per tile?)
-                if (q4 != 0) continue;
-#endif
                 int2 t4[4];                                  // (point row, neighbour row) of this group's 4 edge rows: once for both column blocks
                 if (EPI == EPI_LIF_ATTN) {
 #pragma unroll
@@ -464,293 +399,6 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
                     epilogue_group4<EPI>(g, a4, row, col, pbias[j], pnp[j], cq, ckf);
                 }
                 __builtin_amdgcn_sched_barrier(0);          // keep the groups apart (128 accumulators live)
-            }
-        }
-        BT_STAMP(s2);
-        BT_SEG(10, s1, s2);                                           // epilogue arithmetic + store issue
-        tm += step_tm;
-        tn += step_tn;
-        if (tn >= ntn) { tn -= ntn; ++tm; }
-    }
-#ifdef SAPCU_BT_STAMPS
-    if ((wave == 0 || wave == 4) && lane == 0 && blockIdx.x < 256) {
-        seg[11] = (unsigned long long)my_tiles;
-        for (int i = 0; i < 12 + 32; ++i) g_bt_stamps[blockIdx.x][wave >> 2][i] = seg[i];
-    }
-#endif
-}
-
-// =============================================================================================
-// Two-workgroups-per-CU variant (SAPCU_BT=2, experimental): 256 x 128 tile per 256-thread workgroup (4 waves of 256 registers,
-// wave tile 128 x 64 as above), k-step = 16, rings 4 x 16 KiB (activations, 3 steps ahead) + 2 x 8 KiB (weights) = 80 KiB, so
-// TWO workgroups share a CU and run out of phase: one's epilogue (neuron arithmetic, stores) under the other's k-loop.
-// LDS rows are 32 bytes (16 halves); the two 16-byte chunks of a row are swapped for rows with bit 3 set, which makes the
-// fragment reads (ds_read_b128, lane -> row l&31, chunk l>>5) conflict-free.  Costs: 1.5x the operand bytes per flop of the
-// 256 x 256 tile, a barrier every 24 MFMAs per wave.
-// =============================================================================================
-constexpr int T2K = 16, T2BN = 128;
-constexpr int T2A_PLANE = TBM * T2K * 2;         // 8 KiB
-constexpr int T2A_SLOT = 2 * T2A_PLANE;
-constexpr int T2A_SLOTS = 3;
-constexpr int T2W_PLANE = T2BN * T2K * 2;        // 4 KiB
-constexpr int T2W_SLOT = 2 * T2W_PLANE;
-constexpr int T2W_SLOTS = 2;
-constexpr int T2_LDS = T2A_SLOTS * T2A_SLOT + T2W_SLOTS * T2W_SLOT;     // 80 KiB
-
-template <int N>
-__device__ __forceinline__ void bt2_wait_vm() {
-    if (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bt2_kernel(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
-    constexpr int CT = 2;
-    constexpr int A_BYTES = T2A_SLOTS * T2A_SLOT;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int r32 = lane & 31, h = lane >> 5;
-
-    const int ntn = g.n / T2BN;
-    const int64_t ntm = (g.r + TBM - 1) / TBM;
-    const int64_t ntiles = ntm * ntn;
-    const int nk = g.k / T2K;
-    int64_t first_logical, my_tiles, step_tm;
-    int step_tn;
-    {
-        const int nx = gridDim.x < 8 ? 1 : 8;
-        const int xcd = nx == 1 ? 0 : (int)(blockIdx.x & 7);
-        const int wg_in_x = nx == 1 ? (int)blockIdx.x : (int)(blockIdx.x >> 3);
-        const int wgs_per_x = nx == 1 ? (int)gridDim.x : (int)((gridDim.x - xcd + 7) >> 3);
-        const int64_t qd = ntiles / nx, rem = ntiles % nx;
-        const int64_t x_begin = xcd * qd + (xcd < rem ? xcd : rem);
-        const int64_t x_count = qd + (xcd < rem ? 1 : 0);
-        my_tiles = x_count > wg_in_x ? (x_count - wg_in_x + wgs_per_x - 1) / wgs_per_x : 0;
-        first_logical = x_begin + wg_in_x;
-        step_tm = wgs_per_x / ntn;
-        step_tn = wgs_per_x - (int)step_tm * ntn;
-    }
-    if (my_tiles == 0) return;
-    const int64_t first_tm = first_logical / ntn;
-    const int first_tn = (int)(first_logical - first_tm * ntn);
-
-    // ---- DMA role: waves 0-1 activations (128 rows each), waves 2-3 weights (64 rows each); a 1 KiB piece = 32 rows x 32 B,
-    // lane -> (row = lane >> 1, chunk = lane & 1); source chunk = LDS chunk ^ bit 3 of the row
-    const bool is_a = wave < 2;
-    const int sub = wave & 1;
-    const int dsb = ((lane & 1) ^ ((lane >> 4) & 1)) * 16;
-    const int64_t pitch_b = is_a ? 4 * (int64_t)g.lda : 2 * (int64_t)g.k;
-    const bool a_il = is_a && (g.lda & 31) == 0;                    // interleaved split rows (gemm_epi.h)
-    const int64_t lo_delta = is_a ? (a_il ? 64 : 2 * (int64_t)g.lda)
-                                  : reinterpret_cast<const char*>(g.w16_lo) - reinterpret_cast<const char*>(g.w16_hi);
-    const char* const op_base = is_a ? reinterpret_cast<const char*>(g.a) : reinterpret_cast<const char*>(g.w16_hi);
-    const int pieces = is_a ? 4 : 2;
-    const int rows_per_wave = 32 * pieces;
-    const int depth = is_a ? T2A_SLOTS : T2W_SLOTS;
-    const int slot_bytes = is_a ? T2A_SLOT : T2W_SLOT;
-    const int plane_bytes = is_a ? T2A_PLANE : T2W_PLANE;
-    const int64_t total_steps = my_tiles * nk;
-    int64_t pf_tile = 0, pf_tm = first_tm;
-    int pf_kt = 0, pf_tn = first_tn;
-    const char* pf_base = nullptr;
-    unsigned pf_off[4] = {0, 0, 0, 0};
-    const int lrow = rows_per_wave * sub + (lane >> 1);
-    auto pf_setup = [&]() {
-        const int64_t first = is_a ? pf_tm * TBM : (int64_t)pf_tn * T2BN;
-        const int64_t left = (is_a ? g.r : (int64_t)g.n) - first;
-        pf_base = op_base + first * pitch_b;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            int rr = lrow + 32 * p;
-            if (rr >= left) rr = (int)(left - 1);
-            pf_off[p] = (unsigned)(rr * (int)pitch_b + dsb);
-        }
-    };
-    lds_byte* const ring0 = (lds_byte*)(smem_raw + (is_a ? 0 : A_BYTES) + sub * rows_per_wave * 32);
-    int issue_slot = 0;
-    int64_t issued = 0;
-    auto issue = [&]() {
-        lds_byte* sb = ring0 + issue_slot * slot_bytes;
-        const char* src = pf_base + (a_il ? (pf_kt >> 1) * 128 + (pf_kt & 1) * 32 : pf_kt * (T2K * 2));
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            if (p < pieces) {
-                __builtin_amdgcn_global_load_lds((gptr_t)(src + pf_off[p]), sb + p * 1024, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)(src + lo_delta + pf_off[p]), sb + plane_bytes + p * 1024, 16, 0, 0);
-            }
-        }
-        ++issued;
-        if (++issue_slot == depth) issue_slot = 0;
-        if (++pf_kt == nk) {
-            pf_kt = 0;
-            ++pf_tile;
-            pf_tm += step_tm;
-            pf_tn += step_tn;
-            if (pf_tn >= ntn) { pf_tn -= ntn; ++pf_tm; }
-            if (pf_tile < my_tiles) pf_setup();
-        }
-    };
-    pf_setup();
-    while (issued < depth && issued < total_steps) issue();
-    int64_t landed_upto = 0;
-    auto wait_landed = [&](int64_t step) {      // 8 (activations) or 4 (weights) DMAs per step, in order
-        if (step < landed_upto) return;
-        const int64_t ahead = issued - step - 1;
-        if (is_a) {
-            if (ahead >= 3) bt2_wait_vm<24>();                        // (only with a 4-slot activation ring)
-            else if (ahead == 2) bt2_wait_vm<16>();
-            else if (ahead == 1) bt2_wait_vm<8>();
-            else bt2_wait_vm<0>();
-        } else {
-            if (ahead >= 1) bt2_wait_vm<4>();
-            else bt2_wait_vm<0>();
-        }
-    };
-
-    // ---- MFMA role
-    const int sw = (r32 >> 3) & 1;
-    const unsigned a_frag0 = (unsigned)((wm * 128 + r32) * (T2K * 2) + ((h ^ sw) * 16));
-    const unsigned w_frag0 = (unsigned)(A_BYTES + (wn * 64 + r32) * (T2K * 2) + ((h ^ sw) * 16));
-    struct Frags {
-        half8 ah[4], al[4], wh[CT], wl[CT];
-    };
-    auto read_frags = [&](int a_slot, int w_slot, Frags& f) {
-        const unsigned char* sA = smem_raw + a_slot * T2A_SLOT + a_frag0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f.ah[i] = *reinterpret_cast<const half8*>(sA + i * 32 * (T2K * 2));
-            f.al[i] = *reinterpret_cast<const half8*>(sA + i * 32 * (T2K * 2) + T2A_PLANE);
-        }
-        const unsigned char* sW = smem_raw + w_slot * T2W_SLOT + w_frag0;
-#pragma unroll
-        for (int j = 0; j < CT; ++j) {
-            f.wh[j] = *reinterpret_cast<const half8*>(sW + j * 32 * (T2K * 2));
-            f.wl[j] = *reinterpret_cast<const half8*>(sW + j * 32 * (T2K * 2) + T2W_PLANE);
-        }
-    };
-    f32x16 acc[4][CT];
-    auto mfma_all = [&](const Frags& f) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.wh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.wl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.wh[j], acc[i][j], 0, 0, 0);
-    };
-
-    wait_landed(0);
-    lds_barrier();
-    int ca = 0, cw = 0, na = 1, nw = 1;
-    Frags f0, f1;
-    int64_t gstep = 0;
-    int64_t tm = first_tm;
-    int tn = first_tn;
-    for (int64_t ti = 0; ti < my_tiles; ++ti) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < CT; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        read_frags(ca, cw, f0);
-        // two k-steps per trip so that the fragment buffers alternate with static names (f0: even steps, f1: odd; nk is even)
-        for (int kt = 0; kt < nk; kt += 2) {
-#pragma unroll
-            for (int half = 0; half < 2; ++half, ++gstep) {
-                Frags& cur = half ? f1 : f0;
-                Frags& nxt = half ? f0 : f1;
-                const bool last = kt + half + 1 == nk;
-                if (gstep + 1 < total_steps) {
-                    wait_landed(gstep + 1);
-                    lds_barrier();                                    // step gstep+1 is in for everyone; slot gstep fully read
-                    if (issued < total_steps && !(is_a && last)) issue();
-                    if (!last) read_frags(na, nw, nxt);
-                } else {
-                    lds_barrier();
-                }
-                mfma_all(cur);
-                ca = na;
-                cw = nw;
-                if (++na == T2A_SLOTS) na = 0;
-                if (++nw == T2W_SLOTS) nw = 0;
-            }
-        }
-        // ---- epilogue (as in gemm_bt_kernel)
-        const int64_t row0 = tm * TBM + wm * 128;
-        const int col0 = tn * T2BN + wn * 64;
-        float pbias[CT], praw[CT][4];
-        NeuronP pnp[CT];
-#pragma unroll
-        for (int j = 0; j < CT; ++j) {
-            const int col = col0 + j * 32 + r32;
-            pbias[j] = 0.f;
-            if (g.bias) pbias[j] = bt_load_f32(g.bias + col);
-            if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) praw[j][q] = bt_load_f32(g.lif + (int64_t)q * g.n + col);
-            }
-        }
-        bt2_wait_vm<0>();
-        landed_upto = issued;
-        if (is_a && issued < total_steps) issue();
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < CT; ++j) {
-            pnp[j] = NeuronP{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) {
-                pnp[j].decay = clampf(praw[j][0], 0.1f, 0.99f);
-                pnp[j].adapt = clampf(praw[j][1], 0.001f, 0.1f);
-                pnp[j].rdecay = clampf(praw[j][2], 0.1f, 0.95f);
-                pnp[j].theta0 = praw[j][3];
-            }
-        }
-        const bool interior = tm * TBM + TBM <= g.r;
-        if (interior && EPI == EPI_LIF_ATTN && !g.c_split && g.c2_split) {
-            bt_epilogue_fast<EPI, CT, false, true>(g, acc, row0, col0, r32, h, pbias, pnp);
-        } else if (interior && EPI == EPI_LIF && g.c_split) {
-            bt_epilogue_fast<EPI, CT, true, false>(g, acc, row0, col0, r32, h, pbias, pnp);
-        } else if (interior && EPI != EPI_LIF_ATTN && !g.c_split) {
-            bt_epilogue_fast<EPI, CT, false, false>(g, acc, row0, col0, r32, h, pbias, pnp);
-        } else
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int64_t row = row0 + i * 32 + 8 * q4 + 4 * h;
-                if (row >= g.r) continue;
-                int2 t4[4];
-                if (EPI == EPI_LIF_ATTN) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) t4[u] = row + u < g.r ? g.tab[row + u] : make_int2(0, 0);
-                }
-#pragma unroll
-                for (int j = 0; j < CT; ++j) {
-                    const int col = col0 + j * 32 + r32;
-                    float a4[4], cq[4] = {0.f, 0.f, 0.f, 0.f}, ckf[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) a4[u] = __fmul_rn(acc[i][j][q4 * 4 + u], 0.0625f);
-                    if (EPI == EPI_LIF_ATTN) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            cq[u] = g.q[(int64_t)t4[u].x * g.ldq + col];
-                            ckf[u] = g.kf[(int64_t)t4[u].y * g.ldq + col];
-                        }
-                    }
-                    epilogue_group4<EPI>(g, a4, row, col, pbias[j], pnp[j], cq, ckf);
-                }
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
         tm += step_tm;
@@ -798,41 +446,6 @@ bool gemm_sf16_bt_ok(const GemmArgs& g) {
     return g.epi == EPI_BIAS || g.epi == EPI_LIF || g.epi == EPI_LIF_ATTN;
 }
 
-template <int EPI>
-static int launch_bt2_t(const GemmArgs& g, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        SAPCU_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bt2_kernel<EPI>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS));
-        attr_set = true;
-    }
-    if (g_num_cus_bt == 0) {
-        int dev = 0;
-        SAPCU_CHECK_HIP(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        SAPCU_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        g_num_cus_bt = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    const int64_t tiles = ((g.r + TBM - 1) / TBM) * (g.n / T2BN);
-    const int64_t grid = tiles < 2 * g_num_cus_bt ? tiles : 2 * g_num_cus_bt;
-    hipLaunchKernelGGL((gemm_bt2_kernel<EPI>), dim3((unsigned)grid), dim3(256), T2_LDS, st, g);
-    SAPCU_CHECK_LAUNCH();
-    return SAPCU_OK;
-}
-
-// the two-workgroups-per-CU variant takes the same shapes (k-steps of 16: k % 32 == 0 keeps the trip count even)
-int launch_gemm_sf16_bt2(const GemmArgs& g, hipStream_t st) {
-    if (g.r == 0 || g.n == 0) return SAPCU_OK;
-    SAPCU_CHECK_ARG(gemm_sf16_bt_ok(g), "gemm_bt2: unsupported shape or epilogue");
-    if (g.epi == EPI_LIF || g.epi == EPI_LIF_ATTN) SAPCU_CHECK_ARG(g.lif, "gemm_bt2: missing neuron parameters");
-    if (g.epi == EPI_LIF_ATTN) SAPCU_CHECK_ARG(g.ldq > 0 && g.tab && g.q && g.kf && g.c2, "gemm_bt2: bad attn operands");
-    switch (g.epi) {
-        case EPI_BIAS: return launch_bt2_t<EPI_BIAS>(g, st);
-        case EPI_LIF: return launch_bt2_t<EPI_LIF>(g, st);
-        default: return launch_bt2_t<EPI_LIF_ATTN>(g, st);
-    }
-}
-
 int launch_gemm_sf16_bt(const GemmArgs& g, hipStream_t st) {
     if (g.r == 0 || g.n == 0) return SAPCU_OK;
     SAPCU_CHECK_ARG(gemm_sf16_bt_ok(g), "gemm_bt: unsupported shape or epilogue");
@@ -846,12 +459,5 @@ int launch_gemm_sf16_bt(const GemmArgs& g, hipStream_t st) {
     }
 }
 
-#ifdef SAPCU_BT_STAMPS
-}  // namespace sapcu
-extern "C" int sapcu_debug_bt_stamps(unsigned long long* out_host) {
-    return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(sapcu::g_bt_stamps), sizeof(sapcu::g_bt_stamps));
-}
-namespace sapcu {
-#endif
 
 }  // namespace sapcu

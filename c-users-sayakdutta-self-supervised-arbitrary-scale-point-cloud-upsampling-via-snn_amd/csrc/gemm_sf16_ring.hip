@@ -43,11 +43,7 @@ constexpr int RBM = 128, RBN = 128, RBK = 32;
 // the A panel leaves HBM once and its other readers hit that XCD's L2.  Contiguous (-DSAPCU_RING_TILES_CONTIGUOUS): each
 // workgroup walks a contiguous run of tiles; measured the same speed (+-2 %) but 3.8x the HBM fetch traffic
 // (FETCH_SIZE 10.1 GB vs 2.7 GB per launch at r=1179648, k=n=512), because 32 workgroups stream 16 MiB through a 4 MiB L2.
-#ifdef SAPCU_RING_TILES_CONTIGUOUS
-constexpr bool RING_TILES_INTERLEAVED = false;
-#else
 constexpr bool RING_TILES_INTERLEAVED = true;
-#endif
 constexpr int RPLANE = RBM * RBK * 2;            // 8 KiB
 constexpr int ROPSLOT = 2 * RPLANE;              // 16 KiB: one operand's hi | lo planes of one k-step
 // ring depths (8 operand slots = 128 KiB in all): activations 5 + weights 3; for k <= 128 activations 6 + weights 2
@@ -68,25 +64,13 @@ __device__ __forceinline__ void wait_vm() {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-#ifdef SAPCU_RING_STAMPS   // diagnostic build only (profiles/ablate.sh): where a producer wave's k-step goes
-__device__ unsigned long long g_ring_stamps[256][8];
-#define RING_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define RING_SEG(i, t0, t1) do { seg[i] += (t1) - (t0); } while (0)
-#else
-#define RING_STAMP(t) do { } while (0)
-#define RING_SEG(i, t0, t1) do { } while (0)
-#endif
-
 template <int EPI, bool VEC>
 __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
-    // EPI_SOFTMAX_AGG keeps the WHOLE tile's accumulators in LDS (the epilogue reduces over rows): 64 KiB hand-off area,
-    // 6 operand slots (activations 4, weights 2); its row tiles hold whole points: floor(128 / kk) * kk valid rows.
-    constexpr bool SMX = EPI == EPI_SOFTMAX_AGG;
-    const int RA_SLOTS = SMX ? 4 : (g.k <= 128 ? 6 : 5), RW_SLOTS = (SMX ? 6 : RING_SLOTS) - RA_SLOTS;     // wave-uniform
+    const int RA_SLOTS = g.k <= 128 ? 6 : 5, RW_SLOTS = RING_SLOTS - RA_SLOTS;     // wave-uniform
     const int RA_BYTES = RA_SLOTS * ROPSLOT;
-    float* hand = reinterpret_cast<float*>(smem_raw + (SMX ? 6 * ROPSLOT : RING_BYTES));
-    const int row_step = SMX ? (RBM / g.sm_kk) * g.sm_kk : RBM;
+    float* hand = reinterpret_cast<float*>(smem_raw + RING_BYTES);
+    constexpr int row_step = RBM;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform: keep it (and all it feeds) in scalar registers
@@ -170,11 +154,7 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
         auto pf_setup = [&]() {
             const int64_t first = is_a ? pf_tm * row_step : (int64_t)pf_tn * RBN;   // first operand row of the tile
             const int64_t left = (is_a ? g.r : (int64_t)g.n) - first;             // >= 1
-#ifdef SAPCU_ABL_A_HOT      // latency experiment (garbage results): every tile reads the FIRST row panel -> all A reads hit L2
-            pf_base = op_base + (is_a ? 0 : first * pitch_b);
-#else
             pf_base = op_base + first * pitch_b;
-#endif
             pf_off0 = off0_full;
             pf_off1 = off1_full;
             if (left < 128) {                                      // edge tile (uniform, rare): clamped rows only feed masked outputs
@@ -188,26 +168,14 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
         int issue_slot = 0;                                        // slot the next issued step goes to (wraps at depth)
         int64_t issued = 0;                                        // steps issued by this wave
         auto issue = [&]() {                                       // the 4 DMAs of this wave's next step
-#ifndef SAPCU_ABL_NO_DMA       // (compute-only experiment: the rings are never refilled)
             lds_byte* sb = ring0 + issue_slot * ROPSLOT;
             const char* src = pf_base + pf_kt * kstep_bytes;
-#ifdef SAPCU_ABL_A_CONTIG   // DRAM-locality experiment (garbage results): a k-step's activation slot is read as ONE contiguous
-                            // 16 KiB run of the tile's region (what a tiled activation layout would give) instead of 128 x 2 x 64 B
-            if (is_a) {
-                const char* s0 = pf_base + (int64_t)pf_kt * ROPSLOT + sub * 2048 + lane * 16;
-                __builtin_amdgcn_global_load_lds((gptr_t)(s0), sb, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)(s0 + 1024), sb + 1024, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)(s0 + RPLANE), sb + RPLANE, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)(s0 + RPLANE + 1024), sb + RPLANE + 1024, 16, 0, 0);
-            } else
-#endif
             {
             __builtin_amdgcn_global_load_lds((gptr_t)(src + pf_off0), sb, 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(src + pf_off1), sb + 1024, 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(src + lo_delta + pf_off0), sb + RPLANE, 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(src + lo_delta + pf_off1), sb + RPLANE + 1024, 16, 0, 0);
             }
-#endif
             ++issued;
             if (++issue_slot == depth) issue_slot = 0;
             if (++pf_kt == nk) {
@@ -229,9 +197,6 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
             half8 ah, al, wh[2], wl[2];
         };
         auto read_frags = [&](int a_slot, int w_slot, int k16, Frags& f) {
-#ifdef SAPCU_ABL_NO_MFMA      // delivery-only experiment: DMAs, waits and barriers, no LDS reads, no MFMAs
-            return;
-#endif
             const unsigned char* sA = smem_raw + a_slot * ROPSLOT + arow_l * (RBK * 2) + (((k16 * 2 + h) ^ asw) * 16);
             f.ah = *reinterpret_cast<const half8*>(sA);
             f.al = *reinterpret_cast<const half8*>(sA + RPLANE);
@@ -244,9 +209,6 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
         };
         f32x16 acc[2];
         auto mfma6 = [&](const Frags& f) {
-#ifdef SAPCU_ABL_NO_MFMA
-            return;
-#endif
             // alternate the two accumulators so consecutive MFMAs never depend on each other
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.wh[0], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.wh[1], acc[1], 0, 0, 0);
@@ -273,30 +235,18 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
         Frags f0, f1;
         read_frags(ca, cw, 0, f0);
         int64_t gstep = 0;
-#ifdef SAPCU_RING_STAMPS
-        unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0, tb = 0, tc = 0, td = 0, te = 0, tf = 0;
-#endif
         for (int64_t ti = 0; ti < my_tiles; ++ti) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
             for (int kt = 0; kt < nk; ++kt, ++gstep) {
-                RING_STAMP(ta);
                 read_frags(ca, cw, 1, f1);                          // second half of this step: lands behind mfma6(f0)
                 mfma6(f0);
-                RING_STAMP(tb);
-                RING_SEG(0, ta, tb);                                // reads(f1) + 6 MFMAs issued (+ drain of the reads)
                 if (gstep + 1 < total_steps) {
                     wait_landed(gstep + 1);
-                    RING_STAMP(tc);
-                    RING_SEG(1, tb, tc);                            // own DMAs of the next step landed
                     lds_barrier();                                  // step gstep+1 is in for everyone; this step's slots fully read
-                    RING_STAMP(td);
-                    RING_SEG(2, tc, td);                            // barrier
                     if (issued < total_steps) issue();              // step gstep+depth -> the slot just read
-                    RING_STAMP(te);
-                    RING_SEG(3, td, te);                            // DMA issue
                     read_frags(na, nw, 0, f0);                      // first half of the next step: lands behind mfma6(f1)
                 } else {
                     lds_barrier();                                  // keep the barrier count per step uniform
@@ -306,22 +256,8 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
                 cw = nw;
                 if (++na == RA_SLOTS) na = 0;
                 if (++nw == RW_SLOTS) nw = 0;
-                RING_STAMP(tf);
-                RING_SEG(4, te, tf);                                // reads(f0') + 6 MFMAs issued
             }
-            RING_STAMP(ta);
             // hand-off in two halves through the 32 KiB area (the ring keeps streaming underneath)
-            if constexpr (SMX) {                                    // whole tile at once: block (pw, j) at (pw*2 + j) * 1024 floats
-                lds_barrier();                                      // consumers are done with the previous tile
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        float* hb = (e & 1) ? hand_odd : hand_even;
-                        hb[pw * 1024 + j * 1024 + ((e & 3) + 8 * (e >> 2)) * 32] = acc[j][e];
-                    }
-                lds_barrier();                                      // tile is ready
-            } else
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 1 - jj;                               // column tile 1 first (goes to registers), then 0 (stays)
@@ -335,124 +271,6 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
                 }
                 lds_barrier();                                      // half j is ready
             }
-            RING_STAMP(tb);
-            RING_SEG(5, ta, tb);                                    // hand-off (waits for the MFMAs, 4 barriers, 32 ds_write)
-        }
-#ifdef SAPCU_RING_STAMPS
-        if (wave == 0 && lane == 0 && blockIdx.x < 256) {
-            seg[6] = (unsigned long long)total_steps;
-            seg[7] = (unsigned long long)my_tiles;
-            for (int i = 0; i < 8; ++i) g_ring_stamps[blockIdx.x][i] = seg[i];
-        }
-#endif
-    } else if constexpr (SMX) {
-        // ---- fused softmax + aggregation (fn:378-389).  Consumer wave cw owns point cw (and cw+8, ...) of the tile; lane =
-        // one of the 64 columns of a column half jh (lanes 0-31: column block wn = 0, lanes 32-63: wn = 1).  A pair =
-        // (point, half): pass A turns the point's kk logits in the hand-off area into softmax numerators in place
-        // (max, exp, sum: same operation order as fn_softmax_agg_kernel), pass B walks the kk rows: weight from LDS,
-        // v[neighbour] and pe[row] from memory (row addresses are wave-uniform), one FMA.  The row walk is cut into
-        // slices between the k-step barriers; loads of a slice are issued together.
-        const int kk = g.sm_kk;
-        const int npt = row_step / kk;                             // points per tile
-        const int rounds = (npt + 7) >> 3;
-        const int npairs = 2 * rounds;
-        const int upk = (npairs * kk + nk - 1) / nk;               // row units per k-step
-        const int cwn = lane >> 5, cc = lane & 31;
-        const float inv_sqrt_hd = __fdiv_rn(1.0f, g.sm_sqrt_hd);
-        auto hand_idx = [&](int row_local, int jh) {               // accumulator (row_local, column lane) of half jh
-            const int rr = row_local & 31;
-            return (((row_local >> 5) * 2 + cwn) * 2 + jh) * 1024 + ((rr ^ ((rr >> 2) & 1)) * 32) + cc;
-        };
-        int64_t prev_row0 = -1;
-        int prev_col0 = 0;
-        int64_t cur_tm = first_tm;
-        int cur_tn = first_tn;
-        lds_barrier();                                             // pairs with the producers' "step 0 has landed"
-        for (int64_t ti = 0; ti <= my_tiles; ++ti) {               // last round = drain
-            const bool have = ti < my_tiles;
-            const bool cons_work = prev_row0 >= 0;
-            int p = 0, j = 0;                                      // cursor: pair, row inside the pair
-            float inv_den = 1.f, accv = 0.f;
-            int idxreg = 0;
-            for (int kt = 0; kt < nk; ++kt) {
-                int budget = cons_work ? upk : 0;
-                while (budget > 0 && p < npairs) {
-                    const int rnd = p >> 1, jh = p & 1;
-                    const int pt_local = pw + 8 * rnd;
-                    const int64_t row_first = prev_row0 + (int64_t)pt_local * kk;        // first edge row of the point
-                    const bool pt_ok = pt_local < npt && row_first < g.r;                // wave-uniform
-                    const int col = prev_col0 + cwn * 64 + jh * 32 + cc;
-                    const bool ok = pt_ok && col < g.n;
-                    const int64_t pt_global = row_first / kk;
-                    // rows of this slice: up to 12 per batch of loads, issued BEFORE pass A so that the logit pass covers them
-                    int cnt = kk - j;
-                    if (cnt > budget) cnt = budget;
-                    if (cnt > 12) cnt = 12;
-                    float vb[12], pb[12];
-                    if (j == 0 && pt_ok) idxreg = lane < kk ? g.sm_idx[row_first + lane] : 0;
-                    if (pt_ok) {
-                        const int64_t patch_row0 = (pt_global / g.sm_m) * g.sm_m;
-#pragma unroll
-                        for (int u = 0; u < 12; ++u) {
-                            vb[u] = 0.f;
-                            pb[u] = 0.f;
-                            if (u < cnt) {
-                                const int nbr = __builtin_amdgcn_readlane(idxreg, j + u);
-                                if (ok) {
-                                    vb[u] = g.sm_v[(patch_row0 + nbr) * g.sm_ldv + col];
-                                    pb[u] = g.sm_pe[(row_first + j + u) * g.sm_ldpe + col];
-                                }
-                            }
-                        }
-                    }
-                    if (j == 0 && pt_ok) {                         // pass A
-                        const float biasv = (ok && g.bias) ? g.bias[col] : 0.f;
-                        float mx = -__builtin_huge_valf();
-                        for (int jj = 0; jj < kk; ++jj) {
-                            float* hp = hand + hand_idx(pt_local * kk + jj, jh);
-                            const float x = __fmul_rn(__fmaf_rn(*hp, 0.0625f, biasv), inv_sqrt_hd);
-                            *hp = x;
-                            mx = fmaxf(mx, x);
-                        }
-                        float den = 0.f;
-                        for (int jj = 0; jj < kk; ++jj) {
-                            float* hp = hand + hand_idx(pt_local * kk + jj, jh);
-                            const float e = fast_exp(__fsub_rn(*hp, mx));
-                            *hp = e;
-                            den = __fadd_rn(den, e);
-                        }
-                        inv_den = __fdiv_rn(1.0f, den);
-                        accv = 0.f;
-                    }
-                    if (pt_ok) {
-#pragma unroll
-                        for (int u = 0; u < 12; ++u)
-                            if (u < cnt) {
-                                const float w = hand[hand_idx(pt_local * kk + j + u, jh)];
-                                accv = __fmaf_rn(__fmul_rn(w, inv_den), __fadd_rn(vb[u], pb[u]), accv);
-                            }
-                    }
-                    j += cnt;
-                    budget -= cnt;
-                    if (j == kk) {
-                        if (ok) {
-                            if (g.c_split) store_split(g.c, pt_global, g.ldc, col, accv);
-                            else g.c[pt_global * g.ldc + col] = accv;
-                        }
-                        j = 0;
-                        ++p;
-                    }
-                }
-                if (have) lds_barrier();                            // the producers' mid-step barrier of this k-step
-            }
-            if (!have) break;
-            lds_barrier();                                          // (we are done with the area: producers may overwrite)
-            lds_barrier();                                          // the tile is in
-            prev_row0 = cur_tm * row_step;
-            prev_col0 = cur_tn * RBN;
-            cur_tm += step_tm;
-            cur_tn += step_tn;
-            if (cur_tn >= ntn) { cur_tn -= ntn; ++cur_tm; }
         }
     } else {
         // row layout of this wave's 32x64 sub-tile: lane = (row slot s = lane>>3, column group c4 = lane&7);
@@ -511,14 +329,10 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
                     if (EPI == EPI_LIF_ATTN) {
                         const int qr = __shfl(tabrow.x, rr);
                         const int kr = __shfl(tabrow.y, rr);
-#ifndef SAPCU_ABL_NO_GATHER
                         if (active) {
                             cq = ld4_cols<VEC>(g.q + (int64_t)qr * g.ldq, col, g.n);
                             ckf = ld4_cols<VEC>(g.kf + (int64_t)kr * g.ldq, col, g.n);
                         }
-#else
-                        cq.x = __int_as_float(qr & 1); ckf.x = __int_as_float(kr & 1);
-#endif
                     }
                     if (!active) continue;
                     float4 a;
@@ -569,7 +383,7 @@ static int launch_ring_tv(const GemmArgs& g, hipStream_t st) {
         SAPCU_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
         g_num_cus_ring = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const int row_step = EPI == EPI_SOFTMAX_AGG ? (RBM / g.sm_kk) * g.sm_kk : RBM;
+    const int row_step = RBM;
     const int64_t tiles = ((g.r + row_step - 1) / row_step) * ((g.n + RBN - 1) / RBN);
     const int64_t grid = tiles < g_num_cus_ring ? tiles : g_num_cus_ring;
     hipLaunchKernelGGL((gemm_ring_kernel<EPI, VEC>), dim3((unsigned)grid), dim3(1024), RING_LDS_BYTES, st, g);
@@ -608,11 +422,6 @@ int launch_gemm_sf16_ring(const GemmArgs& g, hipStream_t st) {
         case EPI_RESID: return launch_ring_t<EPI_RESID>(g, st);
         case EPI_LRELU: return launch_ring_t<EPI_LRELU>(g, st);
         case EPI_RESID_GELU: return launch_ring_t<EPI_RESID_GELU>(g, st);
-        case EPI_SOFTMAX_AGG:
-            SAPCU_CHECK_ARG(g.sm_kk >= 1 && g.sm_kk <= 64 && g.sm_m >= 1 && g.r % g.sm_kk == 0 && g.sm_idx && g.sm_pe && g.sm_v &&
-                                g.sm_ldpe >= g.n && g.sm_ldv >= g.n && g.sm_sqrt_hd > 0.f && g.c,
-                            "gemm_ring: bad softmax-aggregate operands (kk=%d)", g.sm_kk);
-            return launch_ring_tv<EPI_SOFTMAX_AGG, true>(g, st);
         case EPI_LIF_ATTN:
             SAPCU_CHECK_ARG(g.ldq > 0 && g.tab && g.q && g.kf && g.c2, "gemm_ring: bad attn operands");
             return launch_ring_t<EPI_LIF_ATTN>(g, st);
@@ -620,12 +429,5 @@ int launch_gemm_sf16_ring(const GemmArgs& g, hipStream_t st) {
     }
 }
 
-#ifdef SAPCU_RING_STAMPS
-}  // namespace sapcu
-extern "C" int sapcu_debug_ring_stamps(unsigned long long* out_host) {
-    return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(sapcu::g_ring_stamps), sizeof(sapcu::g_ring_stamps));
-}
-namespace sapcu {
-#endif
 
 }  // namespace sapcu

@@ -81,7 +81,6 @@ struct sapcu_model {
     int* gate_dev;
     // split-f16 GEMM path: the whole blob pre-split (same indexing), activation-range overflow counter
     bool sf16;
-    bool fused_softmax;        // SAPCU_FUSED_SOFTMAX=1: fc_gamma2 + softmax-aggregate in one kernel (bit-identical; slower so far)
     void* w16_hi;
     void* w16_lo;
     int* ovf_dev;
@@ -116,7 +115,7 @@ static inline int imin(int a, int b) { return a < b ? a : b; }
 int launch_gemm_split_rows(const GemmArgs& g, hipStream_t st) {
     const char* e = getenv("SAPCU_BT");                 // read per call: the parity test flips it inside one process
     const bool use_bt = !(e && strcmp(e, "0") == 0);
-    if (use_bt && gemm_sf16_bt_ok(g)) return (e && strcmp(e, "2") == 0) ? launch_gemm_sf16_bt2(g, st) : launch_gemm_sf16_bt(g, st);
+    if (use_bt && gemm_sf16_bt_ok(g)) return launch_gemm_sf16_bt(g, st);
     return launch_gemm_sf16_ring(g, st);
 }
 
@@ -286,20 +285,7 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
             SAPCU_TRY(gemm(m, B3, R, d, d, m->p(sb + B_GAMMA_W), d, m->p(sb + B_GAMMA_B), B1, d, EPI_LIF, st,
                            m->p(sb + B_GAMMA_LIF), 4, nullptr, 0, SP | (SP << 1)));
             const float sqrt_hd = (float)sqrt((double)(d / m->heads));
-            if (SP && kk <= 64 && m->fused_softmax) {
-                // a = fc_gamma2(g) and res = sum_j softmax_j(a / sqrt(hd)) * (v_j + pe) in ONE kernel: the logits `a`
-                // stay in LDS (gemm_sf16_ring.hip, EPI_SOFTMAX_AGG)                  fn:378-389
-                // Opt-in: results are bit-identical to the two-kernel form, but the two consumer waves per SIMD walk
-                // the neighbour rows with too few loads in flight (3.4 ms per launch against 1.5 + 0.65 ms).
-                GemmArgs g;
-                memset(&g, 0, sizeof(g));
-                g.a = B1; g.r = R; g.k = d; g.lda = d; g.w = m->p(sb + B_GAMMA2_W); g.n = d;
-                g.bias = m->p(sb + B_GAMMA2_B); g.c = RES; g.ldc = d; g.epi = EPI_SOFTMAX_AGG;
-                g.a_split = 1; g.c_split = 1;
-                g.sm_kk = kk; g.sm_m = mp; g.sm_idx = idx[l]; g.sm_pe = B2; g.sm_ldpe = d;
-                g.sm_v = QKV + 2 * d; g.sm_ldv = 3 * d; g.sm_sqrt_hd = sqrt_hd;
-                SAPCU_TRY(run_gemm(m, g, st));
-            } else {
+            {
                 // a = fc_gamma2(g) -> B3                                            fn:378
                 SAPCU_TRY(gemm(m, B1, R, d, d, m->p(sb + B_GAMMA2_W), d, m->p(sb + B_GAMMA2_B), B3, d, EPI_BIAS, st, nullptr, 0,
                                nullptr, 0, SP));
@@ -616,8 +602,6 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
     m->ovf_dev = nullptr;
     const char* ge = getenv("SAPCU_GEMM");
     m->sf16 = !(ge && strcmp(ge, "f32") == 0);
-    const char* fe = getenv("SAPCU_FUSED_SOFTMAX");
-    m->fused_softmax = fe && strcmp(fe, "1") == 0;
     const char* ce = getenv("SAPCU_CHUNK");
     m->chunk = ce ? atoll(ce) : 4096;
     if (m->chunk < 1) m->chunk = 1;

@@ -27,11 +27,14 @@ def gather_refined(local, n_total, group=None):
     """All-gather row slabs of a [n_local, C] tensor sharded by ``shard_range`` -> [n_total, C] on every rank."""
     world = dist.get_world_size(group)
     per = -(-n_total // world)
+    dev = local.device
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        local = local.cpu()               # rehearsals of the N > 1 path on one GPU: gloo moves host memory
     padded = local.new_zeros((per,) + tuple(local.shape[1:]))
     padded[: local.shape[0]] = local
     out = local.new_empty((world * per,) + tuple(local.shape[1:]))
     dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
-    return out[:n_total]
+    return out[:n_total].to(dev)
 
 
 def upsample_sharded(generator, cloud_dev, seeds_dev, group=None):

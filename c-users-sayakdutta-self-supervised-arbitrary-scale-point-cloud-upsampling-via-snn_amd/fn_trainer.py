@@ -189,6 +189,9 @@ class GraphedTrainStep:
         self.pts.copy_(pts)
         self.gt.copy_(gt)
         self.graph.replay()
+        # a replay changes parameters and BatchNorm statistics without running any Python in-place op, so the tensors' version
+        # counters (what _HipModel._state_key watches) do not move: drop the packed inference blob explicitly
+        self.trainer.model._packed_key = None
         vals = torch.stack([self.loss, self.conf, self.total.to(self.loss.dtype)]).tolist()      # one sync
         if not all(np.isfinite(vals)):
             print("WARNING: NaN/Inf in loss or gradients (batch applied with zero gradients): loss %r, gradient norm %r" % (vals[0], vals[2]))

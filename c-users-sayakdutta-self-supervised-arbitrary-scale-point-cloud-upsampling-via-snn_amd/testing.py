@@ -152,9 +152,48 @@ def analytic_cloud(kind, n=2048, seed=0):
     elif kind == "cylinder":
         u = rng.uniform(0, 2 * np.pi, n)
         p = np.stack([0.3 * np.cos(u), 0.3 * np.sin(u), rng.uniform(-0.45, 0.45, n)], 1)
+    elif kind == "two_spheres":
+        # union of two overlapping spheres (radius 0.3, centres +-0.18 on x): the outer surface only — a concave crease
+        v = rng.normal(size=(4 * n, 3))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        side = np.where(rng.random(4 * n) < 0.5, -1.0, 1.0)
+        p = v * 0.3
+        p[:, 0] += 0.18 * side
+        other = p.copy()
+        other[:, 0] += 0.18 * side                      # coordinates relative to the OTHER sphere's centre (at -0.18*side)
+        p = p[np.linalg.norm(other, axis=1) >= 0.3][:n]
+        assert p.shape[0] == n
     else:
         raise ValueError(kind)
     return np.round(p, 6).astype(np.float64)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs 3 / 4 stand-ins: six shapes, N = 2048, run through the reference's
+# Generator3D6.upsample by tests/golden/make_fixtures.py (shape_suite.npz); one 16x case through its generate.py body.
+# (name, kind, cloud seed, dense_spacing).  "icosahedron" is the reference tree's one real cloud
+# (external/SPU-PMD/evaluation_code/Icosahedron.xyz, 8192 points), subsampled — that cloud is stored in the fixture.
+# ---------------------------------------------------------------------------------------------
+SHAPE_SUITE = (("sphere", "sphere", 4, 0.032), ("torus", "torus", 1, 0.026), ("cube", "cube", 2, 0.030),
+               ("cylinder", "cylinder", 5, 0.026), ("two_spheres", "two_spheres", 6, 0.028),
+               ("icosahedron", None, 7, 0.034))
+SHAPE_SUITE_N = 2048
+SCALE16_CASE = dict(n=256, seed=8, spacing=0.0175, ratio=16, scale=37.5, loc=(3.0, -8.0, 0.25))
+
+
+def suite_cloud(name, stored=None):
+    """Cloud [2048,3] float64 of a SHAPE_SUITE entry (``stored``: the fixture file, needed for "icosahedron")."""
+    for nm, kind, seed, _ in SHAPE_SUITE:
+        if nm == name:
+            if kind is None:
+                return np.asarray(stored["%s_cloud" % name], dtype=np.float64)
+            return analytic_cloud(kind, SHAPE_SUITE_N, seed)
+    raise KeyError(name)
+
+
+def scale16_cloud():
+    c = SCALE16_CASE
+    return sphere_cloud(c["n"], c["seed"]) * c["scale"] + np.array(c["loc"])
 
 
 # ---------------------------------------------------------------------------------------------

@@ -65,8 +65,9 @@ int sapcu_displace_f64(const double* queries, const float* normals, const float*
 /* Farthest-point sampling of the refined cloud down to the target count — generate.py:56-74
  * (`farthest_point_sample`): f32 points, start index n/2, running minimum of the squared distance
  * ((dx^2+dy^2)+dz^2, separately rounded) to the chosen set, arg-max with ties to the smallest index.
- * One persistent launch (one workgroup per CU, points and distances in registers, one 64-bit atomicMax
- * and one counter barrier per step).  xyz [n,3] f32 device, idx_out [npoint] int64 device; the
+ * One persistent launch (one workgroup per CU, points and running distances in registers; per step every
+ * workgroup publishes its best candidate in a step-tagged mailbox and polls the others' — no atomics, no
+ * separate barrier; csrc/fps.hip).  xyz [n,3] f32 device, idx_out [npoint] int64 device; the
  * workspace holds sapcu_fps_workspace_bytes(npoint) bytes.  n <= #CU * 8192 (2,097,152 on MI355X).
  * Synchronises `stream` before returning (the indices go to the host next, generate.py:74). */
 int64_t sapcu_fps_workspace_bytes(int64_t npoint);

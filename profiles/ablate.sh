@@ -1,4 +1,9 @@
 #!/bin/bash
+# NOTE (round 2): the diagnostic variants this script builds (-DSAPCU_ABL_*, -DSAPCU_RING_STAMPS, -DSAPCU_BT_STAMPS,
+# -DSAPCU_BT_STORE_POLICY, -DSAPCU_BT_STAGGER), the two-workgroups-per-CU kernel (SAPCU_BT=2) and the ring kernel's fused
+# softmax epilogue (EPI_SOFTMAX_AGG) were removed from the shipped sources after round 1; they live in git history at
+# commit 61ec3ff.  To rebuild one: `git worktree add /tmp/abl 61ec3ff` and run this script there.  The measurements taken
+# with them are recorded in DESIGN.md section 4.1 / 4.1b.
 # Diagnostic builds of the ring GEMM (profiles/abl/*.so, git-ignored) — run here before gpurun, then point a
 # microbenchmark at one with SAPCU_LIB=profiles/abl/libsapcu_<NAME>.so.
 #   epilogue ablations   NO_GATHER  NO_C2  NO_LIF          one piece of the attention/LIF epilogue compiled out

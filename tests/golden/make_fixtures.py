@@ -392,6 +392,139 @@ def fn_trainer_fixture():
     save("fn_trainer.npz", **out)
 
 
+def patch_knn_fixture(test):
+    """Reference knn() (fn/snn_coder.py:31-39 == fd/snn_coder.py:25-32) on xyz patches and on soft-spike-like features:
+    the neighbour indices AND the score matrix the reference ranked (captured from inside its own call: the tensor it hands to
+    topk), for C in {3, 64, 128, 256} (SURVEY.md 8c fixture 2)."""
+    out = {}
+    feats = {3: test[:4].permute(0, 2, 1).contiguous()}
+    for c in (64, 128, 256):
+        feats[c] = torch.from_numpy(np.random.default_rng(c).random((4, c, 48)).astype(np.float32))
+    real_topk = torch.Tensor.topk
+    seen = []
+
+    def rec_topk(self, *a, **kw):
+        seen.append(self.detach().clone())
+        return real_topk(self, *a, **kw)
+
+    for c, f in feats.items():
+        out["feat_c%d" % c] = npy(f)
+        with torch.no_grad():
+            for k in (8, 12, 16, 18, 24, 32, 48):
+                torch.Tensor.topk = rec_topk
+                try:
+                    idx = ref_fn.knn(f, k)
+                finally:
+                    torch.Tensor.topk = real_topk
+                out["idx_c%d_k%d" % (c, k)] = npy(idx).astype(np.int8)
+                assert torch.equal(idx, ref_fd.knn(f, k))
+            assert all(torch.equal(seen[-1], t) for t in seen[-7:])          # one score matrix per feature set, whatever k
+            out["score_c%d" % c] = npy(seen[-1])
+    save("patch_knn.npz", **out)
+
+
+def _reference_upsample(fn, fd, cloud, spacing, batch_size=64, k=48):
+    """The reference's own Generator3D6.upsample on `cloud` [N,3] (run in a scratch directory beside its own compiled
+    dense, which reads test.xyz — generate.py never writes that file): (seeds, unfiltered, filtered)."""
+    dense = os.path.join(ROOT, "oracle", "_ref", "dense")
+    if not os.path.exists(dense):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    work = tempfile.mkdtemp(prefix="sapcu_suite_")
+    shutil.copy(dense, os.path.join(work, "dense"))
+    cwd = os.getcwd()
+    os.chdir(work)
+    RealTree = ref_gen.KDTree
+    try:
+        np.savetxt("test.xyz", cloud, fmt="%.6f")
+        captured = []
+
+        class RecTree(RealTree):                          # records the array each KDTree is built on
+            def __init__(self, data, *a, **kw):
+                captured.append(np.array(data, copy=True))
+                super().__init__(data, *a, **kw)
+
+        ref_gen.KDTree = RecTree
+        for b in (fn.encoder.trans1, fn.encoder.trans2, fn.encoder.trans3):
+            b.knn_cache.cache.clear()
+        gen = ref_gen.Generator3D6(fn, fd, torch.device("cpu"), k_neighbors=k, dense_spacing=spacing, batch_size=batch_size)
+        result = np.asarray(gen.upsample(cloud[None]))
+        seeds = np.loadtxt("target.xyz", ndmin=2)[:, 0:3]
+        return seeds, captured[1], result
+    finally:
+        ref_gen.KDTree = RealTree
+        os.chdir(cwd)
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def _calibrated_models():
+    bn_fn = dict(np.load(os.path.join(HERE, "bn_calib_fn.npz")))
+    bn_fd = dict(np.load(os.path.join(HERE, "bn_calib_fd.npz")))
+    return build_models(bn_fn, bn_fd)
+
+
+def shape_suite_fixture(only=None):
+    """BASELINE config 3 stand-in: the reference's Generator3D6.upsample on six shapes of 2048 points
+    (sphere, torus, cube with sharp edges, cylinder, union of two spheres, the tree's own Icosahedron.xyz subsampled),
+    k_neighbors 48, T 4, batch 64, seeds from its own dense.cpp: seeds / unfiltered / filtered clouds per shape."""
+    import time
+    torch.set_num_threads(8)
+    fn, fd = _calibrated_models()
+    out = {"names": np.array([s[0] for s in T.SHAPE_SUITE])}
+    if only:                                              # redo one shape, keep the others as committed
+        out.update(dict(np.load(os.path.join(HERE, "shape_suite.npz"))))
+    ico = np.loadtxt(os.path.join(REF, "external", "SPU-PMD", "evaluation_code", "Icosahedron.xyz"))[:, :3]
+    for name, kind, seed, spacing in T.SHAPE_SUITE:
+        if only and name != only:
+            continue
+        if kind is None:
+            pick = np.sort(np.random.default_rng(seed).permutation(ico.shape[0])[:T.SHAPE_SUITE_N])
+            sub = ico[pick]
+            lo, hi = sub.min(0), sub.max(0)
+            cloud = np.round((sub - (lo + hi) / 2) / (hi - lo).max(), 6)          # bbox-normalised like generate.py:43-54
+            out["%s_cloud" % name] = cloud
+        else:
+            cloud = T.suite_cloud(name)
+        t0 = time.time()
+        seeds, unf, filt = _reference_upsample(fn, fd, cloud, spacing)
+        print("suite %-12s spacing %.3f: %d seeds -> %d kept  (%.0f s)" % (name, spacing, seeds.shape[0], filt.shape[0], time.time() - t0),
+              flush=True)
+        out["%s_seeds" % name], out["%s_unfiltered" % name], out["%s_filtered" % name] = seeds, unf, filt
+        out["%s_spacing" % name] = np.float64(spacing)
+    save("shape_suite.npz", **out)
+
+
+def scale16_fixture():
+    """BASELINE config 4 stand-in: arbitrary scale 16x = the body of generate.py:81-99 on a 256-point cloud with a
+    non-trivial bounding box: normalize_pointcloud -> Generator3D6.upsample -> denormalise -> farthest_point_sample(16 N)."""
+    import time
+    torch.set_num_threads(8)
+    sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+    import generate as ref_generate
+    fn, fd = _calibrated_models()
+    c = T.SCALE16_CASE
+    raw = T.scale16_cloud()
+    cloud, loc, scale = ref_generate.normalize_pointcloud(raw)
+    t0 = time.time()
+    seeds, unf, filt = _reference_upsample(fn, fd, cloud, c["spacing"])
+    print("16x: %d seeds -> %d kept (%.0f s)" % (seeds.shape[0], filt.shape[0], time.time() - t0), flush=True)
+    target = c["ratio"] * c["n"]
+    assert filt.shape[0] >= target, "the 16x case needs >= %d refined points, got %d: lower SCALE16_CASE spacing" % (target, filt.shape[0])
+    up = filt * scale + loc
+    real_to = torch.Tensor.to
+
+    def to_cpu(self, *a, **kw):
+        a = tuple("cpu" if (isinstance(x, str) and x.startswith("cuda")) else x for x in a)
+        return real_to(self, *a, **kw)
+
+    torch.Tensor.to = to_cpu
+    try:
+        idx = ref_generate.farthest_point_sample(up, target)
+    finally:
+        torch.Tensor.to = real_to
+    save("scale16.npz", seeds=seeds, unfiltered=unf, filtered=filt, norm_cloud=cloud, loc=loc, scale=np.float64(scale),
+         fps_idx=idx.astype(np.int64), output=up[idx])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-e2e", action="store_true")
@@ -399,7 +532,20 @@ def main():
     ap.add_argument("--only-train", action="store_true", help="only (re)generate neuron_train.npz")
     ap.add_argument("--only-fn-train", action="store_true", help="only (re)generate fn_train.npz")
     ap.add_argument("--only-seeds", action="store_true", help="only (re)generate dense_seeds.npz")
+    ap.add_argument("--only-patch-knn", action="store_true", help="only (re)generate patch_knn.npz")
+    ap.add_argument("--suite-shape", default=None, help="(re)generate ONE shape of shape_suite.npz")
+    ap.add_argument("--only-suite", action="store_true", help="only (re)generate shape_suite.npz (BASELINE config 3 stand-in)")
+    ap.add_argument("--only-scale16", action="store_true", help="only (re)generate scale16.npz (BASELINE config 4 stand-in)")
     args = ap.parse_args()
+    if args.only_suite or args.suite_shape:
+        shape_suite_fixture(args.suite_shape)
+        return
+    if args.only_patch_knn:
+        patch_knn_fixture(sphere_patches(64 + 16, 48)[64:])
+        return
+    if args.only_scale16:
+        scale16_fixture()
+        return
     if args.only_seeds:
         seed_fixture()
         return
@@ -465,17 +611,7 @@ def main():
     save("neuron_unit.npz", **out)
 
     # ---- 3. in-patch kNN: reference knn() on xyz patches and on soft-spike-like features
-    out = {}
-    feats = {3: test[:4].permute(0, 2, 1).contiguous()}
-    for c in (64, 128, 256):
-        feats[c] = torch.from_numpy(np.random.default_rng(c).random((4, c, 48)).astype(np.float32))
-    for c, f in feats.items():
-        out["feat_c%d" % c] = npy(f)
-        with torch.no_grad():
-            for k in (8, 12, 16, 18, 24, 32, 48):
-                out["idx_c%d_k%d" % (c, k)] = npy(ref_fn.knn(f, k)).astype(np.int8)
-                assert torch.equal(ref_fn.knn(f, k), ref_fd.knn(f, k))
-    save("patch_knn.npz", **out)
+    patch_knn_fixture(test)
 
     # ---- 4. fn stage taps (b = 4)
     xin = test[:4]
@@ -586,6 +722,9 @@ def main():
     neuron_train_fixture()
     fn_train_fixture()
     fn_trainer_fixture()
+    if not args.skip_e2e:
+        shape_suite_fixture()
+        scale16_fixture()
 
     # ---- 10. end-to-end Generator3D6.upsample on sphere N=2048, dense_spacing 0.03 (~900 seeds)
     if not args.skip_e2e:

@@ -8,6 +8,8 @@ correct fp32 implementations.  Protocol (DESIGN.md "kNN flips"): read back the n
 device chose, evaluate the ORACLE on exactly those tables -> 1e-4 for every patch; separately count
 rows whose table differs from the oracle's own and require them rare and genuine near-ties.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -139,14 +141,22 @@ def test_neuron_unit_against_reference_vectors():
 
 # ------------------------------------------------------------------------------- in-patch kNN
 def test_patch_knn_xyz_exact_and_feature_space_flips():
+    """In-patch kNN against the reference's own knn() run (indices AND the score matrix it ranked, patch_knn.npz).  xyz
+    (c = 3) tables are exact.  In feature space two correct fp32 evaluations of -|a|^2 + 2ab - |b|^2 may order a near-tie
+    differently: rows whose neighbour SET differs must be rare (<= 1 % of rows per case) and each must be a tie of the
+    REFERENCE's scores to within a few ulps of the score magnitude at the k-th / (k+1)-th boundary."""
     from sapcu_amd import _lib
     g = golden("patch_knn.npz")
     lib = _lib.load()
+    total_rows = total_flips = 0
+    worst_ulps = 0.0
     for c in (3, 64, 128, 256):
         f = g["feat_c%d" % c]                                    # [b,c,m]
         feat = _dev(np.ascontiguousarray(f.transpose(0, 2, 1)))  # [b,m,c]
         b, m = feat.shape[0], feat.shape[1]
-        scores = O.inpatch_knn_scores(torch.from_numpy(f)).numpy()
+        scores = g["score_c%d" % c]                              # the matrix the reference handed to topk
+        assert np.array_equal(scores, O.inpatch_knn_scores(torch.from_numpy(f)).numpy())
+        ulp = float(np.spacing(np.float32(np.abs(scores).max())))
         for k in (8, 12, 16, 18, 24, 32, 48):
             out = torch.empty((b, m, k), dtype=torch.int32, device=U.dev())
             _lib.check(lib.sapcu_patch_knn(_lib.ptr(feat), b, m, c, c, k, _lib.ptr(out), _lib.current_stream()))
@@ -156,11 +166,17 @@ def test_patch_knn_xyz_exact_and_feature_space_flips():
                 continue
             same = np.sort(got, -1) == np.sort(ref, -1)
             bad_rows = np.argwhere(~same.all(-1))
-            assert len(bad_rows) <= max(1, (b * m) // 50), "too many neighbour-set flips: %d" % len(bad_rows)
-            for bi, ri in bad_rows:                              # each flip must be a genuine near-tie
-                s = scores[bi, ri]
+            total_rows += b * m
+            total_flips += len(bad_rows)
+            assert len(bad_rows) <= max(1, (b * m) // 100), "too many neighbour-set flips: %d of %d rows (c=%d k=%d)" % (len(bad_rows), b * m, c, k)
+            for bi, ri in bad_rows:                              # each flip must be a genuine near-tie of the reference's scores
+                srow = scores[bi, ri]
                 sym = np.setxor1d(got[bi, ri], ref[bi, ri])
-                assert np.ptp(s[sym]) <= 1e-4 * max(1.0, np.abs(s).max())
+                gap_ulps = float(np.ptp(srow[sym])) / ulp
+                worst_ulps = max(worst_ulps, gap_ulps)
+                assert gap_ulps <= 16.0, "row (%d,%d) c=%d k=%d: swapped neighbours differ by %.1f ulp of the score" % (bi, ri, c, k, gap_ulps)
+    print("in-patch kNN (feature space): %d of %d rows with a different neighbour set; widest swapped gap %.1f ulp of the score magnitude"
+          % (total_flips, total_rows, worst_ulps))
 
 
 # ------------------------------------------------------------------------------- GEMM
@@ -399,7 +415,10 @@ def test_fd_forward_256_patches_forced_neighbour_protocol(models):
            (d_gpu - d_free).abs()[~flip_patches].max()))
     assert err.max() <= TOL
     assert (d_gpu - d_free).abs()[~flip_patches].max() <= TOL
-    assert int(flip_patches.sum()) <= 256 // 10
+    assert int(flip_patches.sum()) <= 16            # measured 9-10 of 256 (round 1); a 2x regression fails
+    flip_rows = sum(int(f.sum()) for f in flips)
+    print("fd: rows with a flipped neighbour set %d of %d" % (flip_rows, 3 * 256 * 48))
+    assert flip_rows <= 3 * 256 * 48 // 100
     assert d_free.std() > 1e-2
 
 
@@ -419,22 +438,6 @@ def test_gemm_modes_agree_and_stay_in_range(weights, monkeypatch):
     d16 = fd16(patch, knn_force=knn)
     assert fd16.gemm_mode() == (True, 0)
     assert (d16 - d32).abs().max() <= TOL
-
-
-def test_fused_softmax_aggregate_is_bit_identical_to_the_two_kernel_form(weights, monkeypatch):
-    """fc_gamma2 + per-point softmax + aggregation in one kernel (EPI_SOFTMAX_AGG: the logits never leave LDS) against
-    the bias GEMM followed by fn_softmax_agg_kernel: same operations in the same order -> identical normals, for full
-    48-point patches (kk = 24/18/12: 5/7/10 points per row tile, ragged last tile) and for 5-point patches (kk = 5)."""
-    fn_b, _, _, _ = U.build_gpu_models(weights)          # default: two kernels
-    fn_b._engine()
-    monkeypatch.setenv("SAPCU_FUSED_SOFTMAX", "1")
-    fn_a, _, _, _ = U.build_gpu_models(weights)
-    fn_a._engine()
-    fn_a.knn_cache_mode = fn_b.knn_cache_mode = "fresh"
-    for nq, mpts in ((37, 48), (3, 5), (1, 48), (64, 20)):
-        patch = U.sphere_patches(nq, mpts, skip=300).to(U.dev())
-        assert torch.equal(fn_a(patch), fn_b(patch)), (nq, mpts)
-    assert fn_a.gemm_mode() == (True, 0)
 
 
 def test_chunking_and_tiny_shapes(weights, monkeypatch):
@@ -536,7 +539,7 @@ def test_upsample_end_to_end_against_reference_run(models):
     ok = err <= 2 * TOL
     print("e2e: %.1f%% of %d refined points within 2e-4 of the reference run; median %.3g, p90 %.3g (rest: fd neighbour flips)"
           % (100 * ok.mean(), err.size, np.median(err), np.quantile(err, 0.9)))
-    assert ok.mean() >= 0.80 and np.median(err) <= 5e-5
+    assert ok.mean() >= 0.90 and np.median(err) <= 5e-5       # measured 0.93 / 1.2e-5 (round 1)
     # (3) outlier filter on the reference's own unfiltered cloud reproduces its keep set exactly
     keep = gen.outlier_filter(_dev(g["unfiltered"]))
     assert np.array_equal(g["unfiltered"][keep], g["filtered"])
@@ -547,6 +550,101 @@ def test_upsample_end_to_end_against_reference_run(models):
     full = gen.upsample(cloud[None])
     fn._knn_cache.clear()
     assert np.array_equal(full, gen.upsample_seeds(cloud, seeds))
+
+
+def _check_upsample_against_reference_run(models, cloud, seeds, unfiltered, filtered, spacing, tag, min_ok):
+    """Staged protocol of test_upsample_end_to_end_against_reference_run for any cloud: k 48, batch 64, reference cache mode.
+    Returns the fraction of refined points within 2e-4 of the reference run."""
+    import sapcu_amd
+    from sapcu_amd import generation as gen_mod
+    fn, fd, sdn, sdd = models
+    fn.knn_cache_mode = "reference"
+    fn._knn_cache.clear()
+    gen = sapcu_amd.Generator3D6(fn, fd, U.dev(), k_neighbors=48, dense_spacing=spacing, batch_size=64)
+    c_dev, s_dev = _dev(cloud), _dev(seeds)
+    with torch.no_grad():
+        refined, normals, dists = gen.refine(c_dev, s_dev)
+    refined, normals, dists = refined.cpu().numpy(), normals.cpu(), dists.cpu()
+    # (1) stages on the first two batches, teacher-forced (a second batch of the same size replays the first one's tables)
+    chunks = G.split_batches(seeds.shape[0], 64)
+    cache = {}
+    for (s0, e0) in chunks[:2]:
+        q = seeds[s0:e0]
+        idx = G.knn_bruteforce(cloud, q, 48)
+        patch = torch.from_numpy(G.gather_centre(cloud, q, idx)).float()
+        taps = {}
+        with torch.no_grad():
+            n_ref = torch.nn.functional.normalize(O.fn_forward(sdn, patch, U.FN_HP, knn_idx=cache.get(e0 - s0), taps=taps), dim=-1)
+        cache.setdefault(e0 - s0, taps["knn_idx"])
+        assert (normals[s0:e0] - n_ref).abs().max() <= TOL, tag
+        rot_gpu = gen_mod.gather_rotate(c_dev, _dev(q), _dev(idx), normals[s0:e0].to(U.dev())).cpu()
+        rot_ref = torch.from_numpy(G.rotate_patches(G.gather_centre(cloud, q, idx), normals[s0:e0].numpy())).float()
+        assert (rot_gpu - rot_ref).abs().max() <= 1e-9, tag
+        d_gpu, d_forced, _, _, _ = U.fd_forward_forced(fd, sdd, rot_gpu)
+        assert torch.equal(d_gpu, dists[s0:e0]), tag
+        assert (d_gpu - d_forced).abs().max() <= TOL, tag
+        assert np.array_equal(refined[s0:e0], G.displace(q, normals[s0:e0].numpy(), dists[s0:e0].numpy())), tag
+    # (2) the whole refined cloud against the reference run, as a distribution (the tail = fd neighbour flips)
+    err = np.abs(refined - unfiltered).max(axis=1)
+    ok = err <= 2 * TOL
+    print("%s: %d seeds, %.1f%% of the refined points within 2e-4 of the reference run; median %.3g, p90 %.3g"
+          % (tag, err.size, 100 * ok.mean(), np.median(err), np.quantile(err, 0.9)))
+    assert ok.mean() >= min_ok and np.median(err) <= 5e-5, tag
+    # (3) the outlier filter on the reference's own unfiltered cloud reproduces its keep set exactly
+    keep = gen.outlier_filter(_dev(unfiltered))
+    assert np.array_equal(unfiltered[keep], filtered), tag
+    # (4) the drop-in entry point generates the same seeds in process and refines them to the same cloud
+    fn._knn_cache.clear()
+    full = gen.upsample(cloud[None])
+    fn._knn_cache.clear()
+    assert np.array_equal(full, gen.upsample_seeds(cloud, seeds)), tag
+    assert abs(full.shape[0] - filtered.shape[0]) <= max(8, filtered.shape[0] // 12), tag
+    gen.check_numeric_guards()
+    return float(ok.mean())
+
+
+@pytest.mark.parametrize("shape", ["sphere", "torus", "cube", "cylinder", "two_spheres", "icosahedron"])
+def test_shape_suite_upsample_against_reference_runs(models, shape):
+    """BASELINE config 3 stand-in: six shapes of 2048 points — smooth, sharp-edged (cube), open
+    (cylinder), creased (two-sphere union), a real scan-like cloud (the reference tree's Icosahedron.xyz) — against the
+    reference's own Generator3D6.upsample runs (tests/golden/shape_suite.npz)."""
+    from sapcu_amd import testing as T
+    g = golden("shape_suite.npz")
+    cloud = T.suite_cloud(shape, g)
+    _check_upsample_against_reference_run(models, cloud, g[shape + "_seeds"], g[shape + "_unfiltered"], g[shape + "_filtered"],
+                                          float(g[shape + "_spacing"]), "suite/" + shape, 0.85)
+
+
+def test_arbitrary_scale_16x_against_reference_run(models):
+    """BASELINE config 4 stand-in: 16x arbitrary scale = the body of generate.py:81-99 (normalise -> upsample -> denormalise ->
+    farthest-point-sample to 16 N) on a 256-point cloud with a non-trivial bounding box, against the reference's own run
+    (tests/golden/scale16.npz): staged refine parity, FPS indices exact on the reference's refined cloud, 16 N points out."""
+    import sapcu_amd
+    from sapcu_amd import pipeline, testing as T
+    fn, fd, _, _ = models
+    g = golden("scale16.npz")
+    c = T.SCALE16_CASE
+    raw = T.scale16_cloud()
+    target = c["ratio"] * c["n"]
+    cloud, loc, scale = pipeline.normalize_pointcloud(raw)
+    assert np.array_equal(cloud, g["norm_cloud"]) and np.array_equal(loc, g["loc"]) and scale == float(g["scale"])
+    _check_upsample_against_reference_run(models, cloud, g["seeds"], g["unfiltered"], g["filtered"], c["spacing"], "16x", 0.85)
+    # FPS to 16 N on the reference's own refined, denormalised cloud: the index sequence is exact
+    up = g["filtered"] * scale + loc
+    idx = pipeline.farthest_point_sample(up, target, device=U.dev())
+    assert np.array_equal(idx, g["fps_idx"])
+    assert np.array_equal(up[idx], g["output"])
+    # the whole driver body on the device path: 16 N points, every one a point of our own refined cloud
+    fn.knn_cache_mode = "reference"
+    fn._knn_cache.clear()
+    gen = sapcu_amd.Generator3D6(fn, fd, U.dev(), k_neighbors=48, dense_spacing=c["spacing"], batch_size=64)
+    out = pipeline.process_cloud(raw, gen, target)
+    assert out.shape == (target, 3) and out.dtype == np.float64 and np.isfinite(out).all()
+    fn._knn_cache.clear()
+    mine = gen.upsample(cloud[None]) * scale + loc
+    assert len({tuple(r) for r in out} - {tuple(r) for r in mine}) == 0
+    d_ref = np.abs(np.linalg.norm((out - loc) / scale, axis=1) - 0.5)
+    assert d_ref.max() < 0.1                      # refined points stay near the sphere the cloud samples
 
 
 def test_full_batch_4096_properties(models):
@@ -1005,7 +1103,7 @@ def test_big_tile_gemm_is_bit_identical_to_the_ring_kernel(r, k, n, lif, csplit,
     As = torch.empty_like(A)
     _lib.check(lib.sapcu_to_split_rows(_lib.ptr(A), r, k, k, _lib.ptr(As), k, _lib.current_stream()))
     outs = []
-    for bt in ("0", "1", "2"):                   # ring / big tile / big tile, two workgroups per CU
+    for bt in ("0", "1"):                        # ring / big tile
         monkeypatch.setenv("SAPCU_BT", bt)
         C = torch.full((r, n), float("nan"), device=U.dev())
         ws = torch.zeros(4 * n * k + 16, dtype=torch.uint8, device=U.dev())
@@ -1032,7 +1130,7 @@ def test_big_tile_posenc_attention_gemm_is_bit_identical_to_the_ring_kernel(b, m
     P1s = torch.empty_like(P1)
     _lib.check(lib.sapcu_to_split_rows(_lib.ptr(P1), r, d, d, _lib.ptr(P1s), d, _lib.current_stream()))
     outs = []
-    for bt in ("0", "1", "2"):
+    for bt in ("0", "1"):
         monkeypatch.setenv("SAPCU_BT", bt)
         pe = torch.full((r, d), float("nan"), device=U.dev())
         att = torch.full((r, d), float("nan"), device=U.dev())
@@ -1082,8 +1180,22 @@ def test_graph_captured_training_step_equals_the_eager_step():
         opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=True)
         tr = fn_trainer.Trainer(model, opt, device=torch.device("cuda"), grad_clip=0.15, grad_clip_type="norm")
         step = fn_trainer.GraphedTrainStep(tr, data, warmup=0) if graphed else tr.train_step     # (capturing runs no kernels)
+        probe = torch.from_numpy(g["points"]).reshape(-1, g["points"].shape[-2], 3)[:8].cuda()
+        model.eval()
+        before = model(probe).clone()                    # packs the inference blob from the initial weights
+        model.train()
         losses = [step(data)[0] for _ in range(4)]
         assert all(l is not None and np.isfinite(l) for l in losses), losses
+        # eval after the steps must see the updated weights (a graph replay moves no version counter: the packed blob has to
+        # be invalidated by the replay itself) = what a fresh model loaded from the current state_dict computes
+        model.eval()
+        after = model(probe).clone()
+        twin = sapcu_amd.ImprovedSNNNormalEstimation(**kw)
+        twin.load_state_dict(copy.deepcopy(model.state_dict()), strict=True)
+        twin.attn_dropout = twin.decoder_dropout = 0.0
+        twin.cuda().eval()
+        assert torch.equal(after, twin(probe)) and not torch.equal(after, before), graphed
+        model.train()
         results.append((losses, {n: p.detach().cpu().clone() for n, p in model.named_parameters()}))
     (le, pe), (lg, pg) = results
     # the first steps agree; later ones drift apart the way two eager runs do (float atomics in the scatter-adds reorder sums,
@@ -1091,3 +1203,45 @@ def test_graph_captured_training_step_equals_the_eager_step():
     assert abs(le[0] - lg[0]) <= 1e-5 and max(abs(a - b) for a, b in zip(le, lg)) <= 0.3, (le, lg)
     worst = max(float((pe[n] - pg[n]).abs().max()) for n in pe)
     assert worst <= 1.2e-3, worst           # four AdamW steps of lr 1e-4: each moves a weight by at most ~lr, in either direction
+
+
+# ---------------------------------------------------------------------------------------------
+# N > 1 path on a one-GPU box: two ranks, both on cuda:0, gloo — the real Generator3D6.refine +
+# upsample_sharded + gather_refined, and bench.py's own rank spawning.  (RCCL itself needs one GPU per rank: the driver's
+# 8-GPU run.)  Child processes are started with subprocess (never an exec from this GPU-initialised process).
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+@pytest.mark.gpu
+def test_sharded_upsample_two_ranks_on_one_gpu():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "tests", "dist_rehearsal.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "REHEARSAL_OK ranks=2" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_as_a_plain_command_rehearsal():
+    """`python bench.py --gpus 2` (no launcher around it) spawns its two ranks itself; on this one-GPU box that is a
+    rehearsal (both ranks on cuda:0, gloo) — exit code 0 and ONE JSON line with n_gpus 2 and the strong-scaling leg."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SAPCU_BENCH_REHEARSE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rehearsal"] is True and line["scaling"] == "weak" and line["value"] > 0
+    assert line["strong_scaling"]["seeds"] == 385582 and line["strong_scaling"]["n_gpus"] == 2

@@ -192,3 +192,124 @@ def test_pipeline_normalisation_and_fps_argument_checks():
     assert lib.sapcu_fps_f32(None, 10, 11, None, None, 0, None) == -1       # npoint > n
     assert lib.sapcu_fps_f32(None, 10, 4, None, None, 0, None) == -1        # null pointers
     assert lib.sapcu_fps_f32(None, 10, 0, None, None, 0, None) == 0         # nothing to sample
+
+
+# ---------------------------------------------------------------------------------------------
+# Multi-rank path on the CPU: the REAL Generator3D6.refine batching / fusing logic and the real upsample_sharded +
+# gather_refined under a gloo process group.  Only the per-pass device work is stood in for: numpy geometry from the
+# oracle and two deterministic per-patch stand-in "models" (no GPU in this container).
+# ---------------------------------------------------------------------------------------------
+class _StubModel(object):
+    def __init__(self):
+        self.knn_cache_mode = "reference"
+        self._knn_cache = {}
+        self.calls = []
+
+    def tiled_knn_tables(self, size, k, times):      # presence enables the fused passes of refine()
+        raise AssertionError("sharded runs are 'fresh': no cached tables may be replayed")
+
+
+def _host_generator(batch_size, fuse):
+    from oracle import geom_path as G
+
+    class HostGen(gen.Generator3D6):
+        def __init__(self):                            # the real constructor insists on a ROCm device
+            self.model1, self.model2 = _StubModel(), _StubModel()
+            self.k_neighbors, self.batch_size, self.fuse_queries = 8, batch_size, fuse
+            self.passes = []
+
+        def _refine_pass(self, cloud, q, knn_in=None):
+            assert knn_in is None
+            self.passes.append(int(q.shape[0]))
+            c, qq = cloud.numpy(), q.numpy()
+            idx = G.knn_bruteforce(c, qq, self.k_neighbors)
+            patch = G.gather_centre(c, qq, idx)
+            n = patch.mean(axis=1) + np.array([0.3, -0.2, 0.9])          # stand-in for fn: any per-patch function
+            n = (n / np.linalg.norm(n, axis=1, keepdims=True)).astype(np.float32)
+            rot = G.rotate_patches(patch, n)
+            d = np.abs(rot[:, :, 0]).mean(axis=1).astype(np.float32)     # stand-in for fd
+            out = G.displace(qq, n, d)
+            return torch.from_numpy(out), torch.from_numpy(n), torch.from_numpy(d)
+
+    return HostGen()
+
+
+def _gloo_refine_worker(rank, world, port, n, batch_size, fuse, q):
+    import torch.distributed as dist
+    from sapcu_amd import testing as T
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cloud = torch.from_numpy(T.sphere_cloud(200, 1))
+        seeds = torch.from_numpy(T.grid_queries(n, 3))
+        g = _host_generator(batch_size, fuse)
+        out, (s, e) = sdist.upsample_sharded(g, cloud, seeds)
+        assert g.model1.knn_cache_mode == "reference"          # restored
+        shard_passes = list(g.passes)
+        single = _host_generator(batch_size, fuse)
+        single.model1.knn_cache_mode = "fresh"
+        ref, _, _ = single.refine(cloud, seeds)
+        q.put((rank, bool(torch.equal(out, ref)), (s, e), shard_passes))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,batch_size,fuse", [(301, 64, 0), (301, 64, 200), (37, 400, 4096), (2, 64, 4096)])
+def test_sharded_refine_with_real_batching_logic_gloo_world2(n, batch_size, fuse):
+    """world_size 2: each rank refines its contiguous shard through Generator3D6.refine (reference batch boundaries inside
+    the shard, fused passes when enabled) and the all-gathered cloud equals a single-process refine of all seeds bit for bit."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_refine_worker, args=(r, 2, port, n, batch_size, fuse, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _, _ in res), res
+    assert res[0][2][0] == 0 and res[1][2][1] == n and res[0][2][1] == res[1][2][0]
+    for _, _, (s0, e0), passes in res:
+        assert sum(passes) == e0 - s0
+        if fuse == 0 and e0 - s0 >= batch_size:                 # one pass per reference batch of the shard
+            assert passes == [b - a for a, b in gen.split_batches(e0 - s0, batch_size)]
+
+
+def test_bench_spawns_its_own_ranks_before_touching_the_gpu():
+    """`python bench.py --gpus N` as a plain command re-launches itself through torch.distributed.run as a child process;
+    the parent must not initialise the GPU first (checked statically here: spawn_ranks only counts devices)."""
+    import ast
+    import inspect
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    src = inspect.getsource(bench.spawn_ranks)
+    assert "torch.distributed.run" in src and "subprocess.call" in src and "device_count" in src
+    for forbidden in ("is_available", "set_device", "os.exec", "execv"):
+        assert forbidden not in src, forbidden
+    tree = ast.parse(inspect.getsource(bench.main))
+    calls = [n.lineno for n in ast.walk(tree) if isinstance(n, ast.Call) and getattr(n.func, "id", "") == "spawn_ranks"]
+    sets = [n.lineno for n in ast.walk(tree) if isinstance(n, ast.Attribute) and n.attr == "set_device"]
+    assert calls and sets and max(calls) < min(sets)
+
+
+def test_shape_suite_seeds_match_the_reference_runs():
+    """BASELINE config 3 / 4 stand-ins: the in-process seed generator reproduces the seeds the reference's dense.cpp gave its
+    own Generator3D6.upsample runs (tests/golden/shape_suite.npz, scale16.npz) — same seeds, same order."""
+    from sapcu_amd import pipeline
+    g = golden("shape_suite.npz")
+    for name, _, _, spacing in testing.SHAPE_SUITE:
+        assert float(g[name + "_spacing"]) == spacing
+        cloud = testing.suite_cloud(name, g)
+        assert cloud.shape == (testing.SHAPE_SUITE_N, 3)
+        assert np.array_equal(gen.dense_seeds(cloud, spacing), g[name + "_seeds"]), name
+        assert 150 <= g[name + "_seeds"].shape[0] <= 1000
+        assert g[name + "_unfiltered"].shape == g[name + "_seeds"].shape
+    s16 = golden("scale16.npz")
+    cloud, loc, scale = pipeline.normalize_pointcloud(testing.scale16_cloud())
+    assert np.array_equal(cloud, s16["norm_cloud"])
+    assert np.array_equal(gen.dense_seeds(cloud, testing.SCALE16_CASE["spacing"]), s16["seeds"])
+    assert s16["filtered"].shape[0] >= testing.SCALE16_CASE["ratio"] * testing.SCALE16_CASE["n"] == s16["fps_idx"].shape[0]
