@@ -1,0 +1,400 @@
+// fn transformer block: the whole per-edge chain of MultiHeadSNNTransformerBlock.forward (fn/snn_coder.py:355-389) in ONE
+// kernel, for the blocks whose row panel fits the CU (d = 128, 256):
+//
+//     pe1 = LIF(fc_delta(x_i - x_j))          VALU                       fn:310,355-358
+//     pe  = LIF(fc_delta2(pe1))               GEMM 1 + neuron epilogue   fn:360-363
+//     ain = q_i - k_j + pe                    (same epilogue)            fn:368
+//     g   = LIF(fc_gamma(ain))                GEMM 2 + neuron epilogue   fn:373-376
+//     a   = fc_gamma2(g)                      GEMM 3                     fn:378
+//     res = sum_j softmax_j(a / sqrt(hd)) * (v_j + pe)                   fn:379-389
+//
+// The unfused form (model.hip: fn_pe1 -> gemm<EPI_LIF_ATTN> -> gemm<EPI_LIF> -> gemm<EPI_BIAS> -> fn_softmax_agg) moves every
+// [rows, d] tensor through HBM: ten passes of rows*d*4 bytes per block.  Here a workgroup owns a GROUP of whole points
+// (floor(128 / kk) points = up to 128 edge rows) and keeps the group's activation panel in LDS between the GEMMs, as the
+// split-f16 A operand (hi | lo planes, [k32 step][plane][128 rows][32 halves], 16-byte chunks XOR-swizzled by (row>>2)&3 —
+// the operand-slot layout of gemm_sf16_bt.hip, so the fragment reads are the same conflict-free ds_read_b128).  Nothing of
+// the chain reaches HBM: the kernel reads xyz differences + neighbour rows (24 B per edge row), the q / k / v rows of the
+// patch (L2) and the pre-packed weights (L2), and writes res [points, d].
+//
+// Shape of the work.  d/32 waves per workgroup; wave w owns output columns 32w .. 32w+31 of all three GEMMs and all 128 rows:
+// wave tile 128 x 32 = 4 MFMA blocks of 32x32 (64 accumulator registers).  A wave's weight fragments are not shared with any
+// other wave, so they bypass LDS: pre-packed at model build in fragment order (one contiguous KiB per (column block, k16,
+// plane)), streamed L2 -> registers four k16 steps ahead.  No barrier inside a GEMM; five workgroup barriers per group.
+// The epilogues run in the accumulator layout (lane = column: bias and neuron parameters are per-lane constants; register
+// e of block i = row 32i + 8(e>>2) + 4h + (e&3)), pe stays in registers until the aggregation, the per-point softmax gets
+// its rows from the two lane halves with v_permlane32_swap and sums them in neighbour order — every value equals the
+// unfused chain's bit for bit (same split-f16 products in the same order, same neuron arithmetic, same softmax order).
+// d = 128: 256-thread workgroups, 67 KiB of LDS -> two per CU, whose phases (MFMA / VALU) drift apart and overlap.
+// d = 256: 512 threads, 131 KiB, one per CU.   d = 512 does not fit (a 128-row panel is 256 KiB) and stays unfused.
+#include "common.h"
+#include "gemm_epi.h"
+#include "ops.h"
+
+namespace sapcu {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr int CH_ROWS = 128;                      // MFMA rows per group
+constexpr int CH_PLANE = CH_ROWS * 64;            // one plane of one k32 step: [128 rows][32 halves]
+constexpr int CH_KSTEP = 2 * CH_PLANE;            // hi | lo
+
+// ---------------------------------------------------------------------------------------------
+// edge preparation: per edge row (point i, neighbour slot j) the rows of point i and of its neighbour in the [points, .]
+// tensors, and the position difference x_i - x_j (fn:310) — one coalesced 24-byte record per row for the chain kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_prep_kernel(const float* __restrict__ patch, const int32_t* __restrict__ idx,
+                                                        int64_t rows, int m, int kk, int2* __restrict__ tab,
+                                                        float4* __restrict__ pd) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const int64_t pt = r / kk;
+    const int64_t nrow = (pt / m) * m + idx[r];
+    tab[r] = make_int2((int)pt, (int)nrow);
+    const float* pi = patch + pt * 3;
+    const float* pj = patch + nrow * 3;
+    pd[r] = make_float4(__fsub_rn(pi[0], pj[0]), __fsub_rn(pi[1], pj[1]), __fsub_rn(pi[2], pj[2]), 0.f);
+}
+
+// weights in fragment order: out[((cb * nk16 + s) * 2 + plane) * 64 + lane][j] = w16_plane[32 cb + (lane & 31)][16 s + 8 (lane >> 5) + j]
+__global__ __launch_bounds__(256) void pack_chain_weights_kernel(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo,
+                                                                 int d, _Float16* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one 8-half fragment piece per thread
+    const int nk16 = d / 16;
+    const int64_t total = (int64_t)(d / 32) * nk16 * 2 * 64;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    const int plane = (int)((t >> 6) & 1);
+    const int64_t cs = t >> 7;
+    const int s = (int)(cs % nk16), cb = (int)(cs / nk16);
+    const _Float16* src = (plane ? lo : hi) + (int64_t)(32 * cb + (lane & 31)) * d + 16 * s + 8 * (lane >> 5);
+    *reinterpret_cast<half8*>(out + t * 8) = *reinterpret_cast<const half8*>(src);
+}
+
+// value of the lane half `hr` (0: lanes 0-31, 1: lanes 32-63) of x, in BOTH halves (lane c and lane 32+c get lane (32 hr + c)'s)
+__device__ __forceinline__ float half_bcast(float x, int hr) {
+    const unsigned a = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    return __uint_as_float(hr ? r[1] : r[0]);
+}
+
+struct ChainLane {       // per-lane constants of the epilogues
+    int r32, h, col;
+    unsigned xw[2];      // LDS byte offset of (row 4h + .., this lane's column as k) for rows with ((row>>3)&1) = 0 / 1
+};
+
+template <int D>
+__device__ __forceinline__ void chain_gemm(const unsigned char* X, const half8* __restrict__ wp, int lane, f32x16 (&acc)[4]) {
+    constexpr int NK16 = D / 16;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int sw = (r32 >> 2) & 3;                         // (row >> 2) & 3 of rows 32 i + r32
+    const unsigned char* xa = X + r32 * 64;
+    half8 wh[4], wl[4];                                     // weight fragments, four k16 steps ahead
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        wh[s] = wp[(s * 2) * 64 + lane];
+        wl[s] = wp[(s * 2 + 1) * 64 + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NK16; ++s) {
+        const unsigned ko = (unsigned)((s >> 1) * CH_KSTEP + ((((s & 1) * 2 + h) ^ sw) * 16));
+        half8 ah[4], al[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ah[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048);
+            al[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048 + CH_PLANE);
+        }
+        const half8 cwh = wh[s & 3], cwl = wl[s & 3];
+        if (s + 4 < NK16) {
+            wh[s & 3] = wp[((s + 4) * 2) * 64 + lane];
+            wl[s & 3] = wp[((s + 4) * 2 + 1) * 64 + lane];
+        }
+        // per accumulator: a_lo.w_hi, a_hi.w_lo, a_hi.w_hi — the order of gemm_sf16_ring.hip / gemm_sf16_bt.hip
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], cwh, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], cwl, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], cwh, acc[i], 0, 0, 0);
+    }
+}
+
+// write v (row = 32 i + 8 q + 4 h + u, k = this lane's column) into the panel as the split-f16 operand of the next GEMM
+__device__ __forceinline__ void chain_put(unsigned char* X, const ChainLane& L, int i, int q, int u, float v) {
+    unsigned char* p = X + L.xw[q & 1] + (unsigned)(i * 2048 + q * 512 + u * 64);
+    const _Float16 hi = (_Float16)v;
+    *reinterpret_cast<_Float16*>(p) = hi;
+    *reinterpret_cast<_Float16*>(p + CH_PLANE) = (_Float16)(v - (float)hi);
+}
+
+__device__ __forceinline__ NeuronP chain_lif(const float* __restrict__ lif, int d, int col) {
+    NeuronP np;
+    np.decay = clampf(lif[col], 0.1f, 0.99f);
+    np.adapt = clampf(lif[d + col], 0.001f, 0.1f);
+    np.rdecay = clampf(lif[2 * d + col], 0.1f, 0.95f);
+    np.theta0 = lif[3 * d + col];
+    np.dT = 0.f;
+    np.rh = 0.f;
+    return np;
+}
+
+template <int D, int KK>
+__global__ __launch_bounds__(D * 2) void fn_edge_chain_kernel(const ChainArgs a) {
+    constexpr int NT = D * 2;
+    constexpr int PPG = CH_ROWS / KK;                      // points per group
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char* X = smem;
+    float4* pdl = reinterpret_cast<float4*>(smem + CH_ROWS * D * 4);
+    int2* rinfo = reinterpret_cast<int2*>(smem + CH_ROWS * D * 4 + CH_ROWS * 16);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    ChainLane L;
+    L.r32 = lane & 31;
+    L.h = lane >> 5;
+    L.col = 32 * w + L.r32;
+    // element (row, k = col): k32 step = w, chunk = r32 >> 3, half = r32 & 7; (row >> 2) & 3 = (2 q + h) & 3
+#pragma unroll
+    for (int qo = 0; qo < 2; ++qo)
+        L.xw[qo] = (unsigned)(w * CH_KSTEP + L.h * 256 + (((L.r32 >> 3) ^ ((2 * qo + L.h) & 3)) * 16) + (L.r32 & 7) * 2);
+
+    // group of this workgroup: contiguous ranges of groups per XCD (blockIdx & 7), so that the tiles of one patch — which
+    // gather the same q / k / v rows — share an L2
+    const int64_t ngroups = (a.P + PPG - 1) / PPG;
+    int64_t g;
+    {
+        const int64_t nx = gridDim.x < 8 ? 1 : 8;
+        const int64_t x = nx == 1 ? 0 : (blockIdx.x & 7), slot = nx == 1 ? blockIdx.x : (blockIdx.x >> 3);
+        const int64_t qd = ngroups / nx, rem = ngroups % nx;
+        g = x * qd + (x < rem ? x : rem) + slot;
+        if (slot >= qd + (x < rem ? 1 : 0)) return;
+    }
+    const int64_t pt0 = g * PPG;
+    const int npts = (int)((a.P - pt0) < PPG ? (a.P - pt0) : PPG);
+
+    // ---- phase 0: edge records of the group's rows; pe1 = LIF(fc_delta(x_i - x_j)) -> panel              fn:310,355-358
+    if (tid < CH_ROWS) {
+        const int pl = tid / KK;
+        const bool ok = pl < npts;                                           // pad rows replay the group's first edge row
+        const int64_t er = ok ? pt0 * KK + tid : pt0 * KK;
+        rinfo[tid] = a.tab[er];
+        pdl[tid] = a.pd[er];
+    }
+    {
+        constexpr int TPR = D / 4;                         // threads per row, 4 consecutive channels each
+        constexpr int RPP = NT / TPR;                      // rows per pass (8)
+        const int rsub = tid / TPR;
+        const int c = (tid - rsub * TPR) * 4;
+        float wx[4], wy[4], wz[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            wx[u] = a.wd[(c + u) * 3];
+            wy[u] = a.wd[(c + u) * 3 + 1];
+            wz[u] = a.wd[(c + u) * 3 + 2];
+        }
+        const float4 bb = ld4(a.bd + c);
+        ColParams4 cp;
+        cp.bias = bb;
+        cp.decay = ld4(a.lifd + c);
+        cp.adapt = ld4(a.lifd + D + c);
+        cp.rdecay = ld4(a.lifd + 2 * D + c);
+        cp.theta0 = ld4(a.lifd + 3 * D + c);
+        NeuronP2 np[2];
+        clamp_col_params4(cp, np);
+        const NeuronP2 np4[4] = {np[0], np[1], np[0], np[1]};
+        const float bs[4] = {bb.x, bb.y, bb.z, bb.w};
+        const unsigned xcol = (unsigned)((c >> 5) * CH_KSTEP + (c & 7) * 2);
+        const int chunk = (c & 31) >> 3;
+        lds_barrier();                                     // edge records are in
+#pragma unroll 2
+        for (int r = rsub; r < CH_ROWS; r += 2 * RPP) {
+            const int rb = r + RPP;
+            const float4 da = pdl[r], db = pdl[rb];
+            float va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float t0 = __fmul_rn(wx[u], da.x);
+                t0 = __fmaf_rn(wy[u], da.y, t0);
+                t0 = __fmaf_rn(wz[u], da.z, t0);
+                va[u] = __fadd_rn(t0, bs[u]);
+                float t1 = __fmul_rn(wx[u], db.x);
+                t1 = __fmaf_rn(wy[u], db.y, t1);
+                t1 = __fmaf_rn(wz[u], db.z, t1);
+                vb[u] = __fadd_rn(t1, bs[u]);
+            }
+            f32x2 pv[4] = {f32x2{va[0], va[1]}, f32x2{va[2], va[3]}, f32x2{vb[0], vb[1]}, f32x2{vb[2], vb[3]}};
+            lif_selfloop_pairs<4>(pv, np4, a.T);
+            const float o[2][4] = {{pv[0].x, pv[0].y, pv[1].x, pv[1].y}, {pv[2].x, pv[2].y, pv[3].x, pv[3].y}};
+#pragma unroll
+            for (int z = 0; z < 2; ++z) {
+                const int row = z ? rb : r;
+                half4 hi, lo;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    hi[u] = (_Float16)o[z][u];
+                    lo[u] = (_Float16)(o[z][u] - (float)hi[u]);
+                }
+                unsigned char* p = X + xcol + (unsigned)(row * 64 + ((chunk ^ ((row >> 2) & 3)) * 16));
+                *reinterpret_cast<half4*>(p) = hi;
+                *reinterpret_cast<half4*>(p + CH_PLANE) = lo;
+            }
+        }
+    }
+    lds_barrier();                                         // pe1 panel complete
+
+    f32x16 acc[4], pe[4];
+    // ---- GEMM 1: fc_delta2; epilogue pe = LIF(.), attn_in = q_i - k_j + pe -> panel                       fn:360-368
+    {
+        const float b1 = a.b1[L.col];
+        const NeuronP n1 = chain_lif(a.lif1, D, L.col);
+        chain_gemm<D>(X, reinterpret_cast<const half8*>(a.w1p) + (int64_t)w * (D / 16) * 128, lane, acc);
+        lds_barrier();                                     // every wave has read the pe1 panel: it may be overwritten
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {               // 8 rows at a time: quads 2 qq, 2 qq + 1
+                int2 ri[8];
+                float qv[8], kv[8], v[8];
+#pragma unroll
+                for (int z = 0; z < 8; ++z) ri[z] = rinfo[32 * i + 8 * (2 * qq + (z >> 2)) + 4 * L.h + (z & 3)];
+#pragma unroll
+                for (int z = 0; z < 8; ++z) {
+                    qv[z] = a.qkv[(int64_t)ri[z].x * a.ldq + L.col];
+                    kv[z] = a.qkv[(int64_t)ri[z].y * a.ldq + D + L.col];
+                }
+#pragma unroll
+                for (int z = 0; z < 8; ++z) v[z] = __fadd_rn(__fmul_rn(acc[i][8 * qq + z], 0.0625f), b1);
+                lif_selfloop_n<8>(v, n1, a.T);
+#pragma unroll
+                for (int z = 0; z < 8; ++z) {
+                    pe[i][8 * qq + z] = v[z];
+                    chain_put(X, L, i, 2 * qq + (z >> 2), z & 3, __fadd_rn(__fsub_rn(qv[z], kv[z]), v[z]));
+                }
+            }
+        }
+    }
+    lds_barrier();                                         // attn_in panel complete
+    // ---- GEMM 2: fc_gamma; epilogue g = LIF(.) -> panel                                                   fn:373-376
+    {
+        const float b2 = a.b2[L.col];
+        const NeuronP n2 = chain_lif(a.lif2, D, L.col);
+        chain_gemm<D>(X, reinterpret_cast<const half8*>(a.w2p) + (int64_t)w * (D / 16) * 128, lane, acc);
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                float v[8];
+#pragma unroll
+                for (int z = 0; z < 8; ++z) v[z] = __fadd_rn(__fmul_rn(acc[i][8 * qq + z], 0.0625f), b2);
+                lif_selfloop_n<8>(v, n2, a.T);
+#pragma unroll
+                for (int z = 0; z < 8; ++z) chain_put(X, L, i, 2 * qq + (z >> 2), z & 3, v[z]);
+            }
+        }
+    }
+    lds_barrier();                                         // g panel complete
+    // ---- GEMM 3: fc_gamma2; per-point softmax over the kk neighbours, aggregation with v_j + pe           fn:378-389
+    {
+        const float b3 = a.b3[L.col];
+        chain_gemm<D>(X, reinterpret_cast<const half8*>(a.w3p) + (int64_t)w * (D / 16) * 128, lane, acc);
+        // own rows: x = (a + b) / sqrt(hd) in place of the accumulators, t = v_j + pe in place of pe
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                float vv[8];
+#pragma unroll
+                for (int z = 0; z < 8; ++z) {
+                    const int nrow = rinfo[32 * i + 8 * (2 * qq + (z >> 2)) + 4 * L.h + (z & 3)].y;
+                    vv[z] = a.qkv[(int64_t)nrow * a.ldq + 2 * D + L.col];
+                }
+#pragma unroll
+                for (int z = 0; z < 8; ++z) {
+                    const int e = 8 * qq + z;
+                    acc[i][e] = __fmul_rn(__fadd_rn(__fmul_rn(acc[i][e], 0.0625f), b3), a.inv_sqrt_hd);
+                    pe[i][e] = __fadd_rn(vv[z], pe[i][e]);
+                }
+            }
+        }
+        // per point: its kk rows alternate between the lane halves in quads; both halves fetch the other's values and
+        // run the same neighbour-ordered sums (fn_softmax_agg_kernel's operation order)
+#pragma unroll
+        for (int p = 0; p < PPG; ++p) {
+            float xs[KK], ts[KK];
+#pragma unroll
+            for (int j = 0; j < KK; ++j) {
+                const int r = p * KK + j, i = r >> 5, rr = r & 31;
+                const int e = ((rr >> 3) << 2) | (rr & 3), hr = (rr >> 2) & 1;
+                xs[j] = half_bcast(acc[i][e], hr);
+                ts[j] = half_bcast(pe[i][e], hr);
+            }
+            float mx = -__builtin_huge_valf();
+#pragma unroll
+            for (int j = 0; j < KK; ++j) mx = fmaxf(mx, xs[j]);
+            float den = 0.f;
+#pragma unroll
+            for (int j = 0; j < KK; ++j) {
+                xs[j] = fast_exp(__fsub_rn(xs[j], mx));
+                den = __fadd_rn(den, xs[j]);
+            }
+            const float inv_den = __fdiv_rn(1.0f, den);
+            float out = 0.f;
+#pragma unroll
+            for (int j = 0; j < KK; ++j) out = __fmaf_rn(__fmul_rn(xs[j], inv_den), ts[j], out);
+            if (p < npts && (p & 1) == L.h) {              // both halves hold the result: each stores every other point
+                const int64_t pt = pt0 + p;
+                if (a.res_split) store_split(a.res, pt, D, L.col, out);
+                else a.res[pt * D + L.col] = out;
+            }
+        }
+    }
+}
+
+template <int D, int KK>
+static int launch_chain_t(const ChainArgs& a, hipStream_t st) {
+    const int lds = CH_ROWS * D * 4 + CH_ROWS * 16 + CH_ROWS * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SAPCU_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fn_edge_chain_kernel<D, KK>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    constexpr int PPG = CH_ROWS / KK;
+    const int64_t ngroups = (a.P + PPG - 1) / PPG;
+    const int64_t grid = ngroups < 8 ? ngroups : ((ngroups + 7) / 8) * 8;      // 8 XCD ranges of equal slot count
+    SAPCU_CHECK_ARG(grid < 0x7fffffffLL, "edge_chain: too many groups");
+    hipLaunchKernelGGL((fn_edge_chain_kernel<D, KK>), dim3((unsigned)grid), dim3(D * 2), lds, st, a);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+bool fn_edge_chain_ok(int d, int kk) { return (d == 128 && kk == 24) || (d == 256 && kk == 18); }
+
+int launch_fn_edge_chain(ChainArgs a, const float* patch, const int32_t* idx, int d, int kk, int2* tab, float4* pd,
+                         hipStream_t st) {
+    if (a.P == 0) return SAPCU_OK;
+    SAPCU_CHECK_ARG(fn_edge_chain_ok(d, kk), "edge_chain: unsupported block shape d=%d kk=%d", d, kk);
+    SAPCU_CHECK_ARG(a.P * (int64_t)kk < 0x7fffffffLL && a.P * (int64_t)(a.ldq) < (1LL << 40), "edge_chain: too many rows");
+    const int64_t rows = a.P * kk;
+    hipLaunchKernelGGL(edge_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, patch, idx, rows, a.m, kk, tab, pd);
+    SAPCU_CHECK_LAUNCH();
+    a.tab = tab;
+    a.pd = pd;
+    if (d == 128) return launch_chain_t<128, 24>(a, st);
+    return launch_chain_t<256, 18>(a, st);
+}
+
+int launch_pack_chain_weights(const void* w16_hi, const void* w16_lo, int d, void* out, hipStream_t st) {
+    const int64_t total = (int64_t)(d / 32) * (d / 16) * 2 * 64;
+    hipLaunchKernelGGL(pack_chain_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const _Float16*)w16_hi, (const _Float16*)w16_lo, d, (_Float16*)out);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+}  // namespace sapcu

@@ -83,6 +83,7 @@ struct sapcu_model {
     bool sf16;
     void* w16_hi;
     void* w16_lo;
+    void* chain_w;             // fn: fc_delta2 | fc_gamma | fc_gamma2 of blocks 1, 2 in MFMA-fragment order (fn_edge_chain.hip)
     int* ovf_dev;
     // common
     int emb, T, heads;
@@ -188,7 +189,7 @@ static int64_t fn_ws_bytes(const sapcu_model* m, int64_t b, int mp) {
     int64_t fl = 0;
     auto add = [&](int64_t n, int64_t esz) { fl += ((n * esz) + 255) & ~(int64_t)255; };
     for (int l = 0; l < 3; ++l) add(P * pl.kk[l], 4);          // idx
-    { int kmx = 1; for (int l = 0; l < 3; ++l) kmx = kmx > pl.kk[l] ? kmx : pl.kk[l]; add(P * kmx, 8); }   // edge table
+    { int kmx = 1; for (int l = 0; l < 3; ++l) kmx = kmx > pl.kk[l] ? kmx : pl.kk[l]; add(P * kmx, 8); add(P * kmx, 16); }   // edge table, position differences
     add(P * 64, 4); add(P * 192, 4); add(P * 512, 4); add(P * 1536, 4); add(P * 512, 4);
     add(pl.edge_floats, 4); add(pl.edge_floats, 4); add(pl.edge_floats, 4);
     add(pl.cb * m->emb, 4); add(pl.cb * 2048, 4); add(pl.cb * 1024, 4); add(pl.cb * 512, 4); add(pl.cb * 256, 4);
@@ -219,6 +220,7 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
         int kmx = 1;
         for (int l = 0; l < 3; ++l) kmx = kmx > pl.kk[l] ? kmx : pl.kk[l];
         int2* tab = A.take<int2>(pl.cb * mp * kmx);
+        float4* pdiff = A.take<float4>(pl.cb * mp * kmx);
         float* feat0 = A.take<float>(pl.cb * mp * 64);
         float* cat = A.take<float>(pl.cb * mp * 192);
         float* X = A.take<float>(pl.cb * mp * 512);
@@ -266,31 +268,47 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
             // q|k|v = LIF(w_qs|w_ks|w_vs (x))                                       fn:322-335
             SAPCU_TRY(gemm(m, X, P, d, d, m->p(sb + B_QKV_W), 3 * d, m->p(sb + B_QKV_B), QKV, 3 * d, EPI_LIF, st,
                            m->p(sb + B_QKV_LIF), 4, nullptr, 0, SP));
-            // pe1 = LIF(fc_delta(x_i - x_j))                                        fn:310,355-358
-            SAPCU_TRY(launch_fn_pe1(pc, idx[l], R, mp, kk, d, m->p(sb + B_DELTA_W), m->p(sb + B_DELTA_B),
-                                    m->p(sb + B_DELTA_LIF), 4, B1, SP, st));
-            // pe = LIF(fc_delta2(pe1)) -> B2, and in the same epilogue attn_in = q_i - k_j + pe -> B3   fn:360-368
-            {
-                GemmArgs g;
-                memset(&g, 0, sizeof(g));
-                g.a = B1; g.r = R; g.k = d; g.lda = d; g.w = m->p(sb + B_DELTA2_W); g.n = d;
-                g.bias = m->p(sb + B_DELTA2_B); g.c = B2; g.ldc = d; g.epi = EPI_LIF_ATTN;
-                g.lif = m->p(sb + B_DELTA2_LIF); g.lif_T = 4; g.c2 = B3;
-                g.q = QKV; g.kf = QKV + d; g.ldq = 3 * d; g.tab = tab;
-                g.a_split = SP; g.c2_split = SP;
-                SAPCU_TRY(launch_edge_table(idx[l], R, mp, kk, tab, st));
-                SAPCU_TRY(run_gemm(m, g, st));
-            }
-            // g = LIF(fc_gamma(attn_in)) -> B1                                      fn:373-376
-            SAPCU_TRY(gemm(m, B3, R, d, d, m->p(sb + B_GAMMA_W), d, m->p(sb + B_GAMMA_B), B1, d, EPI_LIF, st,
-                           m->p(sb + B_GAMMA_LIF), 4, nullptr, 0, SP | (SP << 1)));
             const float sqrt_hd = (float)sqrt((double)(d / m->heads));
-            {
-                // a = fc_gamma2(g) -> B3                                            fn:378
-                SAPCU_TRY(gemm(m, B1, R, d, d, m->p(sb + B_GAMMA2_W), d, m->p(sb + B_GAMMA2_B), B3, d, EPI_BIAS, st, nullptr, 0,
-                               nullptr, 0, SP));
-                // res = sum_j softmax_j(a / sqrt(hd)) * (v_j + pe)                  fn:379-389
-                SAPCU_TRY(launch_fn_softmax_agg(B3, B2, QKV + 2 * d, 3 * d, idx[l], P, mp, kk, d, sqrt_hd, RES, SP, st));
+            const char* che = getenv("SAPCU_CHAIN");              // read per call: the parity test flips it inside one process
+            if (SP && m->chain_w && l < 2 && fn_edge_chain_ok(d, kk) && !(che && strcmp(che, "0") == 0)) {
+                // the whole edge chain in one kernel, activations in LDS (fn_edge_chain.hip)      fn:355-389
+                ChainArgs ca;
+                memset(&ca, 0, sizeof(ca));
+                ca.P = P; ca.m = mp; ca.qkv = QKV; ca.ldq = 3 * d;
+                ca.wd = m->p(sb + B_DELTA_W); ca.bd = m->p(sb + B_DELTA_B); ca.lifd = m->p(sb + B_DELTA_LIF);
+                const _Float16* cw = (const _Float16*)m->chain_w + (l == 0 ? 0 : (int64_t)3 * 128 * 128 * 2);
+                ca.w1p = cw; ca.b1 = m->p(sb + B_DELTA2_B); ca.lif1 = m->p(sb + B_DELTA2_LIF);
+                ca.w2p = cw + (int64_t)d * d * 2; ca.b2 = m->p(sb + B_GAMMA_B); ca.lif2 = m->p(sb + B_GAMMA_LIF);
+                ca.w3p = cw + (int64_t)2 * d * d * 2; ca.b3 = m->p(sb + B_GAMMA2_B);
+                ca.inv_sqrt_hd = 1.0f / sqrt_hd;
+                ca.res = RES; ca.res_split = SP; ca.T = 4;
+                SAPCU_TRY(launch_fn_edge_chain(ca, pc, idx[l], d, kk, tab, pdiff, st));
+            } else {
+                // pe1 = LIF(fc_delta(x_i - x_j))                                        fn:310,355-358
+                SAPCU_TRY(launch_fn_pe1(pc, idx[l], R, mp, kk, d, m->p(sb + B_DELTA_W), m->p(sb + B_DELTA_B),
+                                        m->p(sb + B_DELTA_LIF), 4, B1, SP, st));
+                // pe = LIF(fc_delta2(pe1)) -> B2, and in the same epilogue attn_in = q_i - k_j + pe -> B3   fn:360-368
+                {
+                    GemmArgs g;
+                    memset(&g, 0, sizeof(g));
+                    g.a = B1; g.r = R; g.k = d; g.lda = d; g.w = m->p(sb + B_DELTA2_W); g.n = d;
+                    g.bias = m->p(sb + B_DELTA2_B); g.c = B2; g.ldc = d; g.epi = EPI_LIF_ATTN;
+                    g.lif = m->p(sb + B_DELTA2_LIF); g.lif_T = 4; g.c2 = B3;
+                    g.q = QKV; g.kf = QKV + d; g.ldq = 3 * d; g.tab = tab;
+                    g.a_split = SP; g.c2_split = SP;
+                    SAPCU_TRY(launch_edge_table(idx[l], R, mp, kk, tab, st));
+                    SAPCU_TRY(run_gemm(m, g, st));
+                }
+                // g = LIF(fc_gamma(attn_in)) -> B1                                      fn:373-376
+                SAPCU_TRY(gemm(m, B3, R, d, d, m->p(sb + B_GAMMA_W), d, m->p(sb + B_GAMMA_B), B1, d, EPI_LIF, st,
+                               m->p(sb + B_GAMMA_LIF), 4, nullptr, 0, SP | (SP << 1)));
+                {
+                    // a = fc_gamma2(g) -> B3                                            fn:378
+                    SAPCU_TRY(gemm(m, B1, R, d, d, m->p(sb + B_GAMMA2_W), d, m->p(sb + B_GAMMA2_B), B3, d, EPI_BIAS, st, nullptr, 0,
+                                   nullptr, 0, SP));
+                    // res = sum_j softmax_j(a / sqrt(hd)) * (v_j + pe)                  fn:379-389
+                    SAPCU_TRY(launch_fn_softmax_agg(B3, B2, QKV + 2 * d, 3 * d, idx[l], P, mp, kk, d, sqrt_hd, RES, SP, st));
+                }
             }
             // out_proj, fc2 + residual                                              fn:393-394
             SAPCU_TRY(gemm(m, RES, P, d, d, m->p(sb + B_OUT_W), d, m->p(sb + B_OUT_B), X, d, EPI_BIAS, st, nullptr, 0, nullptr,
@@ -599,6 +617,7 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
     m->blob = nullptr;
     m->w16_hi = nullptr;
     m->w16_lo = nullptr;
+    m->chain_w = nullptr;
     m->ovf_dev = nullptr;
     const char* ge = getenv("SAPCU_GEMM");
     m->sf16 = !(ge && strcmp(ge, "f32") == 0);
@@ -666,6 +685,24 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
                 if (rc == SAPCU_OK) hip_ok(hipMemcpy(&wovf, m->ovf_dev + 1, sizeof(int), hipMemcpyDeviceToHost), "read ovf");
                 if (rc == SAPCU_OK && wovf != 0) m->sf16 = false;   // a parameter exceeds the f16 range: exact-f32 kernels
             }
+            // fn blocks 1 and 2 (d = 128, 256): the three d x d matrices of the edge chain again in MFMA-fragment order
+            if (rc == SAPCU_OK && m->sf16 && kind == SAPCU_KIND_FN) {
+                const int64_t halves = (int64_t)3 * 2 * (128 * 128 + 256 * 256);
+                hip_ok(hipMalloc(&m->chain_w, (size_t)halves * 2), "hipMalloc(chain_w)");
+                int64_t off = 0;
+                for (int l = 0; l < 2 && rc == SAPCU_OK; ++l) {
+                    const int d = 128 << l;
+                    static const int slots[3] = {B_DELTA2_W, B_GAMMA_W, B_GAMMA2_W};
+                    for (int q = 0; q < 3 && rc == SAPCU_OK; ++q) {
+                        const int64_t wo = m->dir[FN_BLK0 + l * B_SLOTS + slots[q]];
+                        if (launch_pack_chain_weights((const _Float16*)m->w16_hi + wo, (const _Float16*)m->w16_lo + wo, d,
+                                                      (_Float16*)m->chain_w + off, nullptr) != SAPCU_OK)
+                            rc = SAPCU_ERR_HIP;
+                        off += (int64_t)d * d * 2;
+                    }
+                }
+                if (rc == SAPCU_OK) hip_ok(hipDeviceSynchronize(), "pack chain weights");
+            }
         }
         if (rc == SAPCU_OK && kind == SAPCU_KIND_FD) {
             hip_ok(hipMalloc((void**)&m->ks_dev, 8 * sizeof(int32_t)), "hipMalloc(ks)");
@@ -677,6 +714,7 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
     if (rc != SAPCU_OK) {
         if (m->w16_hi) (void)hipFree(m->w16_hi);
         if (m->w16_lo) (void)hipFree(m->w16_lo);
+        if (m->chain_w) (void)hipFree(m->chain_w);
         if (m->ovf_dev) (void)hipFree(m->ovf_dev);
         if (m->blob) (void)hipFree(m->blob);
         if (m->ks_dev) (void)hipFree(m->ks_dev);
@@ -692,6 +730,7 @@ int sapcu_model_destroy(sapcu_model_t m) {
     if (!m) return SAPCU_OK;
     if (m->w16_hi) (void)hipFree(m->w16_hi);
     if (m->w16_lo) (void)hipFree(m->w16_lo);
+    if (m->chain_w) (void)hipFree(m->chain_w);
     if (m->ovf_dev) (void)hipFree(m->ovf_dev);
     if (m->blob) (void)hipFree(m->blob);
     if (m->ks_dev) (void)hipFree(m->ks_dev);

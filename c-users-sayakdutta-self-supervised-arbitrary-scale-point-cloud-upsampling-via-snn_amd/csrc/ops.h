@@ -16,6 +16,34 @@ int launch_fn_stem(const float* patch, int64_t rows, const float* w, const float
                    float* out, hipStream_t st);
 int launch_fn_pe1(const float* patch, const int32_t* idx, int64_t rows, int m, int kk, int d, const float* w,
                   const float* bias, const float* lif, int T, float* out, int split, hipStream_t st);
+// fused per-edge chain of an fn block (fn_edge_chain.hip): tab / pd are filled by the launcher
+struct ChainArgs {
+    int64_t P;                 // points (rows of qkv / res)
+    int m;                     // points per patch
+    const int2* tab;           // [P*kk] (point row, neighbour row)
+    const float4* pd;          // [P*kk] x_i - x_j
+    const float* qkv;          // [P, ldq]: q | k | v, d columns each
+    int ldq;
+    const float* wd;           // fc_delta  [d][3], bias [d], raw neuron parameters [4][d]
+    const float* bd;
+    const float* lifd;
+    const _Float16* w1p;       // fc_delta2 in fragment order (launch_pack_chain_weights), bias, neuron parameters
+    const float* b1;
+    const float* lif1;
+    const _Float16* w2p;       // fc_gamma
+    const float* b2;
+    const float* lif2;
+    const _Float16* w3p;       // fc_gamma2
+    const float* b3;
+    float inv_sqrt_hd;
+    float* res;                // [P, d] (split rows when res_split)
+    int res_split;
+    int T;                     // neuron self-loop steps (4)
+};
+bool fn_edge_chain_ok(int d, int kk);
+int launch_fn_edge_chain(ChainArgs a, const float* patch, const int32_t* idx, int d, int kk, int2* tab_ws, float4* pd_ws,
+                         hipStream_t st);      // tab_ws / pd_ws: P*kk entries each
+int launch_pack_chain_weights(const void* w16_hi, const void* w16_lo, int d, void* out, hipStream_t st);
 int launch_edge_table(const int32_t* idx, int64_t rows, int m, int kk, int2* tab, hipStream_t st);
 int launch_fn_softmax_agg(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx, int64_t pts,
                           int m, int kk, int d, float sqrt_hd, float* res, int split, hipStream_t st);

@@ -45,6 +45,10 @@ def test_inpatch_knn_indices_exact():
         for k in (8, 12, 16, 18, 24, 32, 48):
             idx = O.inpatch_knn(f, k).numpy()
             assert np.array_equal(idx, g["idx_c%d_k%d" % (c, k)].astype(np.int64)), (c, k)
+        # the score matrix the reference itself ranked (captured inside its knn() call): same formula, same torch ops
+        sc = O.inpatch_knn_scores(f).numpy()
+        ref = g["score_c%d" % c]
+        assert sc.shape == ref.shape and np.abs(sc - ref).max() <= 16 * np.spacing(np.float32(np.abs(ref).max())), c
 
 
 def test_fn_stage_taps(weights):
