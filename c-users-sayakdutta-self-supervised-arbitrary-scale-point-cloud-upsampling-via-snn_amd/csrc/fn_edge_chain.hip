@@ -31,7 +31,6 @@
 #include "ops.h"
 
 namespace sapcu {
-
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr int CH_ROWS = 128;                      // MFMA rows per group
@@ -82,18 +81,25 @@ struct ChainLane {       // per-lane constants of the epilogues
     unsigned xw[2];      // LDS byte offset of (row 4h + .., this lane's column as k) for rows with ((row>>3)&1) = 0 / 1
 };
 
+struct ChainW {           // weight fragments of four k16 steps (hi, lo)
+    half8 wh[4], wl[4];
+};
+
+// first four k16 steps of a GEMM's weight stream: issued well before the GEMM so that their L2 latency is covered
+__device__ __forceinline__ void chain_w_prefetch(const half8* __restrict__ wp, int lane, ChainW& W) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        W.wh[s] = wp[(s * 2) * 64 + lane];
+        W.wl[s] = wp[(s * 2 + 1) * 64 + lane];
+    }
+}
+
 template <int D>
-__device__ __forceinline__ void chain_gemm(const unsigned char* X, const half8* __restrict__ wp, int lane, f32x16 (&acc)[4]) {
+__device__ __forceinline__ void chain_gemm(const unsigned char* X, const half8* __restrict__ wp, int lane, ChainW& W, f32x16 (&acc)[4]) {
     constexpr int NK16 = D / 16;
     const int r32 = lane & 31, h = lane >> 5;
     const int sw = (r32 >> 2) & 3;                         // (row >> 2) & 3 of rows 32 i + r32
     const unsigned char* xa = X + r32 * 64;
-    half8 wh[4], wl[4];                                     // weight fragments, four k16 steps ahead
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        wh[s] = wp[(s * 2) * 64 + lane];
-        wl[s] = wp[(s * 2 + 1) * 64 + lane];
-    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -107,10 +113,10 @@ __device__ __forceinline__ void chain_gemm(const unsigned char* X, const half8* 
             ah[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048);
             al[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048 + CH_PLANE);
         }
-        const half8 cwh = wh[s & 3], cwl = wl[s & 3];
-        if (s + 4 < NK16) {
-            wh[s & 3] = wp[((s + 4) * 2) * 64 + lane];
-            wl[s & 3] = wp[((s + 4) * 2 + 1) * 64 + lane];
+        const half8 cwh = W.wh[s & 3], cwl = W.wl[s & 3];
+        if (s + 4 < NK16) {                                // four k16 steps ahead
+            W.wh[s & 3] = wp[((s + 4) * 2) * 64 + lane];
+            W.wl[s & 3] = wp[((s + 4) * 2 + 1) * 64 + lane];
         }
         // per accumulator: a_lo.w_hi, a_hi.w_lo, a_hi.w_hi — the order of gemm_sf16_ring.hip / gemm_sf16_bt.hip
 #pragma unroll
@@ -142,8 +148,7 @@ __device__ __forceinline__ NeuronP chain_lif(const float* __restrict__ lif, int 
 }
 
 template <int D, int KK>
-__global__ __launch_bounds__(D * 2) void fn_edge_chain_kernel(const ChainArgs a) {
-    constexpr int NT = D * 2;
+__global__ __launch_bounds__(D * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void fn_edge_chain_kernel(const ChainArgs a) {
     constexpr int PPG = CH_ROWS / KK;                      // points per group
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* X = smem;
@@ -176,7 +181,10 @@ __global__ __launch_bounds__(D * 2) void fn_edge_chain_kernel(const ChainArgs a)
     const int64_t pt0 = g * PPG;
     const int npts = (int)((a.P - pt0) < PPG ? (a.P - pt0) : PPG);
 
+    f32x16 acc[4], pe[4];
+    ChainW W;
     // ---- phase 0: edge records of the group's rows; pe1 = LIF(fc_delta(x_i - x_j)) -> panel              fn:310,355-358
+    float qp[PPG];                                         // q_i of the group's points, this lane's column
     if (tid < CH_ROWS) {
         const int pl = tid / KK;
         const bool ok = pl < npts;                                           // pad rows replay the group's first edge row
@@ -185,104 +193,89 @@ __global__ __launch_bounds__(D * 2) void fn_edge_chain_kernel(const ChainArgs a)
         pdl[tid] = a.pd[er];
     }
     {
-        constexpr int TPR = D / 4;                         // threads per row, 4 consecutive channels each
-        constexpr int RPP = NT / TPR;                      // rows per pass (8)
-        const int rsub = tid / TPR;
-        const int c = (tid - rsub * TPR) * 4;
-        float wx[4], wy[4], wz[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            wx[u] = a.wd[(c + u) * 3];
-            wy[u] = a.wd[(c + u) * 3 + 1];
-            wz[u] = a.wd[(c + u) * 3 + 2];
-        }
-        const float4 bb = ld4(a.bd + c);
-        ColParams4 cp;
-        cp.bias = bb;
-        cp.decay = ld4(a.lifd + c);
-        cp.adapt = ld4(a.lifd + D + c);
-        cp.rdecay = ld4(a.lifd + 2 * D + c);
-        cp.theta0 = ld4(a.lifd + 3 * D + c);
-        NeuronP2 np[2];
-        clamp_col_params4(cp, np);
-        const NeuronP2 np4[4] = {np[0], np[1], np[0], np[1]};
-        const float bs[4] = {bb.x, bb.y, bb.z, bb.w};
-        const unsigned xcol = (unsigned)((c >> 5) * CH_KSTEP + (c & 7) * 2);
-        const int chunk = (c & 31) >> 3;
+        // accumulator layout, like the epilogues: this lane's column for its 64 rows (the neuron parameters are per-lane
+        // constants; the position differences are LDS broadcasts)
+        const float wx = a.wd[L.col * 3], wy = a.wd[L.col * 3 + 1], wz = a.wd[L.col * 3 + 2], bd = a.bd[L.col];
+        const NeuronP nd = chain_lif(a.lifd, D, L.col);
         lds_barrier();                                     // edge records are in
-#pragma unroll 2
-        for (int r = rsub; r < CH_ROWS; r += 2 * RPP) {
-            const int rb = r + RPP;
-            const float4 da = pdl[r], db = pdl[rb];
-            float va[4], vb[4];
+        // q_i of the group's points for the first epilogue (fn:368): issued here, consumed after GEMM 1
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float t0 = __fmul_rn(wx[u], da.x);
-                t0 = __fmaf_rn(wy[u], da.y, t0);
-                t0 = __fmaf_rn(wz[u], da.z, t0);
-                va[u] = __fadd_rn(t0, bs[u]);
-                float t1 = __fmul_rn(wx[u], db.x);
-                t1 = __fmaf_rn(wy[u], db.y, t1);
-                t1 = __fmaf_rn(wz[u], db.z, t1);
-                vb[u] = __fadd_rn(t1, bs[u]);
-            }
-            f32x2 pv[4] = {f32x2{va[0], va[1]}, f32x2{va[2], va[3]}, f32x2{vb[0], vb[1]}, f32x2{vb[2], vb[3]}};
-            lif_selfloop_pairs<4>(pv, np4, a.T);
-            const float o[2][4] = {{pv[0].x, pv[0].y, pv[1].x, pv[1].y}, {pv[2].x, pv[2].y, pv[3].x, pv[3].y}};
-#pragma unroll
-            for (int z = 0; z < 2; ++z) {
-                const int row = z ? rb : r;
-                half4 hi, lo;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    hi[u] = (_Float16)o[z][u];
-                    lo[u] = (_Float16)(o[z][u] - (float)hi[u]);
-                }
-                unsigned char* p = X + xcol + (unsigned)(row * 64 + ((chunk ^ ((row >> 2) & 3)) * 16));
-                *reinterpret_cast<half4*>(p) = hi;
-                *reinterpret_cast<half4*>(p + CH_PLANE) = lo;
-            }
-        }
-    }
-    lds_barrier();                                         // pe1 panel complete
-
-    f32x16 acc[4], pe[4];
-    // ---- GEMM 1: fc_delta2; epilogue pe = LIF(.), attn_in = q_i - k_j + pe -> panel                       fn:360-368
-    {
-        const float b1 = a.b1[L.col];
-        const NeuronP n1 = chain_lif(a.lif1, D, L.col);
-        chain_gemm<D>(X, reinterpret_cast<const half8*>(a.w1p) + (int64_t)w * (D / 16) * 128, lane, acc);
-        lds_barrier();                                     // every wave has read the pe1 panel: it may be overwritten
+        for (int p = 0; p < PPG; ++p) qp[p] = a.qkv[(pt0 + (p < npts ? p : 0)) * a.ldq + L.col];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {               // 8 rows at a time: quads 2 qq, 2 qq + 1
-                int2 ri[8];
-                float qv[8], kv[8], v[8];
-#pragma unroll
-                for (int z = 0; z < 8; ++z) ri[z] = rinfo[32 * i + 8 * (2 * qq + (z >> 2)) + 4 * L.h + (z & 3)];
+            for (int qq = 0; qq < 2; ++qq) {
+                float v[8];
 #pragma unroll
                 for (int z = 0; z < 8; ++z) {
-                    qv[z] = a.qkv[(int64_t)ri[z].x * a.ldq + L.col];
-                    kv[z] = a.qkv[(int64_t)ri[z].y * a.ldq + D + L.col];
+                    const float4 dd = pdl[32 * i + 8 * (2 * qq + (z >> 2)) + 4 * L.h + (z & 3)];
+                    float t0 = __fmul_rn(wx, dd.x);
+                    t0 = __fmaf_rn(wy, dd.y, t0);
+                    t0 = __fmaf_rn(wz, dd.z, t0);
+                    v[z] = __fadd_rn(t0, bd);
                 }
+                lif_selfloop_n<8>(v, nd, a.T);
 #pragma unroll
-                for (int z = 0; z < 8; ++z) v[z] = __fadd_rn(__fmul_rn(acc[i][8 * qq + z], 0.0625f), b1);
-                lif_selfloop_n<8>(v, n1, a.T);
-#pragma unroll
-                for (int z = 0; z < 8; ++z) {
-                    pe[i][8 * qq + z] = v[z];
-                    chain_put(X, L, i, 2 * qq + (z >> 2), z & 3, __fadd_rn(__fsub_rn(qv[z], kv[z]), v[z]));
-                }
+                for (int z = 0; z < 8; ++z) chain_put(X, L, i, 2 * qq + (z >> 2), z & 3, v[z]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+    }
+    const half8* const wp1 = reinterpret_cast<const half8*>(a.w1p) + (int64_t)w * (D / 16) * 128;
+    const half8* const wp2 = reinterpret_cast<const half8*>(a.w2p) + (int64_t)w * (D / 16) * 128;
+    const half8* const wp3 = reinterpret_cast<const half8*>(a.w3p) + (int64_t)w * (D / 16) * 128;
+    // k_j and v_j of 8 rows (one epilogue unit u: block u >> 1, quads 2 (u & 1), 2 (u & 1) + 1), this lane's column
+    float kq[2][8], vq[2][8];
+    auto gather_kv = [&](int u, float (&kd)[8], float (&vd)[8]) {
+#pragma unroll
+        for (int z = 0; z < 8; ++z) {
+            const int nrow = rinfo[32 * (u >> 1) + 8 * (2 * (u & 1) + (z >> 2)) + 4 * L.h + (z & 3)].y;
+            kd[z] = a.qkv[(int64_t)nrow * a.ldq + D + L.col];
+            vd[z] = a.qkv[(int64_t)nrow * a.ldq + 2 * D + L.col];
+        }
+    };
+    gather_kv(0, kq[0], vq[0]);                            // in flight during GEMM 1
+    chain_w_prefetch(wp1, lane, W);
+    lds_barrier();                                         // pe1 panel complete
+
+    // ---- GEMM 1: fc_delta2; epilogue pe = LIF(.), attn_in = q_i - k_j + pe -> panel, t = v_j + pe stays      fn:360-368
+    {
+        const float b1 = a.b1[L.col];
+        const NeuronP n1 = chain_lif(a.lif1, D, L.col);
+        chain_gemm<D>(X, wp1, lane, W, acc);
+        lds_barrier();                                     // every wave has read the pe1 panel: it may be overwritten
+        // software pipeline over the 8 units: the gathers of unit u + 1 are issued before the neuron arithmetic of unit u
+        // and consumed after the one of unit u + 1 (the in-order vector-memory counter then waits for loads that are one
+        // arithmetic block old)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = u >> 1, qq = u & 1;
+            if (u + 1 < 8) gather_kv(u + 1, kq[(u + 1) & 1], vq[(u + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            float v[8];
+#pragma unroll
+            for (int z = 0; z < 8; ++z) v[z] = __fmaf_rn(acc[i][8 * qq + z], 0.0625f, b1);      // undoes the x16 of the pre-scaled weights (exact)
+            lif_selfloop_n<8>(v, n1, a.T);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int z = 0; z < 8; ++z) {
+                // the row's point: row = 32 i + 8 q + 4 h + u, compile-time per lane half (pad rows: any point)
+                const int r0 = 32 * i + 8 * (2 * qq + (z >> 2)) + (z & 3), r1 = r0 + 4;
+                const int p0 = r0 / KK < PPG ? r0 / KK : PPG - 1, p1 = r1 / KK < PPG ? r1 / KK : PPG - 1;
+                const float qv = p0 == p1 ? qp[p0] : (L.h ? qp[p1] : qp[p0]);
+                chain_put(X, L, i, 2 * qq + (z >> 2), z & 3, __fadd_rn(__fsub_rn(qv, kq[u & 1][z]), v[z]));
+                pe[i][8 * qq + z] = __fadd_rn(vq[u & 1][z], v[z]);                        // t = v_j + pe (fn:386-389)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        chain_w_prefetch(wp2, lane, W);
     }
     lds_barrier();                                         // attn_in panel complete
     // ---- GEMM 2: fc_gamma; epilogue g = LIF(.) -> panel                                                   fn:373-376
     {
         const float b2 = a.b2[L.col];
         const NeuronP n2 = chain_lif(a.lif2, D, L.col);
-        chain_gemm<D>(X, reinterpret_cast<const half8*>(a.w2p) + (int64_t)w * (D / 16) * 128, lane, acc);
+        chain_gemm<D>(X, wp2, lane, W, acc);
         lds_barrier();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -290,37 +283,25 @@ __global__ __launch_bounds__(D * 2) void fn_edge_chain_kernel(const ChainArgs a)
             for (int qq = 0; qq < 2; ++qq) {
                 float v[8];
 #pragma unroll
-                for (int z = 0; z < 8; ++z) v[z] = __fadd_rn(__fmul_rn(acc[i][8 * qq + z], 0.0625f), b2);
+                for (int z = 0; z < 8; ++z) v[z] = __fmaf_rn(acc[i][8 * qq + z], 0.0625f, b2);
                 lif_selfloop_n<8>(v, n2, a.T);
 #pragma unroll
                 for (int z = 0; z < 8; ++z) chain_put(X, L, i, 2 * qq + (z >> 2), z & 3, v[z]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        chain_w_prefetch(wp3, lane, W);
     }
     lds_barrier();                                         // g panel complete
     // ---- GEMM 3: fc_gamma2; per-point softmax over the kk neighbours, aggregation with v_j + pe           fn:378-389
     {
         const float b3 = a.b3[L.col];
-        chain_gemm<D>(X, reinterpret_cast<const half8*>(a.w3p) + (int64_t)w * (D / 16) * 128, lane, acc);
-        // own rows: x = (a + b) / sqrt(hd) in place of the accumulators, t = v_j + pe in place of pe
+        chain_gemm<D>(X, wp3, lane, W, acc);
+        // own rows: x = (a + b) / sqrt(hd) in place of the accumulators (pe already holds t = v_j + pe)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                float vv[8];
-#pragma unroll
-                for (int z = 0; z < 8; ++z) {
-                    const int nrow = rinfo[32 * i + 8 * (2 * qq + (z >> 2)) + 4 * L.h + (z & 3)].y;
-                    vv[z] = a.qkv[(int64_t)nrow * a.ldq + 2 * D + L.col];
-                }
-#pragma unroll
-                for (int z = 0; z < 8; ++z) {
-                    const int e = 8 * qq + z;
-                    acc[i][e] = __fmul_rn(__fadd_rn(__fmul_rn(acc[i][e], 0.0625f), b3), a.inv_sqrt_hd);
-                    pe[i][e] = __fadd_rn(vv[z], pe[i][e]);
-                }
-            }
-        }
+            for (int e = 0; e < 16; ++e) acc[i][e] = __fmul_rn(__fmaf_rn(acc[i][e], 0.0625f, b3), a.inv_sqrt_hd);
         // per point: its kk rows alternate between the lane halves in quads; both halves fetch the other's values and
         // run the same neighbour-ordered sums (fn_softmax_agg_kernel's operation order)
 #pragma unroll

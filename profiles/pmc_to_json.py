@@ -7,8 +7,23 @@ WRITE_SIZE is exact for 4-16 B/lane streaming stores."""
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_sha256():
+    """Hash of the kernel sources the counters were taken on (bench.py refuses a PMC file whose hash is not the tree's)."""
+    d = os.path.join(ROOT, "c-users-sayakdutta-self-supervised-arbitrary-scale-point-cloud-upsampling-via-snn_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
 def per_kernel(d, counter):
@@ -36,7 +51,7 @@ def per_kernel_raw(d, counter):
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
-def main(fetch_dir, write_dir, out, mfma_dir=None):
+def main(fetch_dir, write_dir, out, mfma_dir=None, steps_profiled=None):
     fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     # third pass (optional): matrix-pipe busy cycles (= 32 per v_mfma_f32_32x32x16, summed over the chip's SIMDs) and
     # GRBM_GUI_ACTIVE (summed over the 8 XCDs) -> busy fraction = busy / (gui_active / 8 * 1024 SIMDs)
@@ -44,7 +59,7 @@ def main(fetch_dir, write_dir, out, mfma_dir=None):
     ga = per_kernel_raw(mfma_dir, "GRBM_GUI_ACTIVE") if mfma_dir else {}
     res = {}
     for k in sorted(set(fe) | set(wr)):
-        if not k.startswith(("gemm", "fn_", "fd_", "patch_", "knn_", "rowgroup", "edge_", "gather", "displace")):
+        if not k.startswith(("gemm", "fn_", "fd_", "patch_", "knn_", "rowgroup", "edge_", "gather", "displace", "l2_", "to_split")):
             continue
         f, nf = fe.get(k, (0.0, 0))
         w, nw = wr.get(k, (0.0, 0))
@@ -67,9 +82,19 @@ def main(fetch_dir, write_dir, out, mfma_dir=None):
             act = sum(v["gui_active_sum_xcd"] * v["launches"] for v in fam)
             comb["mfma_busy_frac"] = round(busy / (act / 8.0 * 1024.0), 4)
         res["gemm_bt_kernel<6>"] = comb
+    # whole step: sum over the kernels of (bytes per launch x launches) / steps profiled (warmup + timed; the PMC runs use
+    # --no-roofline --no-strong-leg, so every launch belongs to a step)
+    if steps_profiled:
+        n = float(steps_profiled)
+        tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in res.items() if "members" not in v)
+        res["_step"] = {"steps_profiled": int(n), "hbm_bytes_per_step": round(tot / n),
+                        "launches_per_step": {k: v["launches"] / n for k, v in res.items() if "members" not in v and not k.startswith("_")}}
+    res["_meta"] = {"csrc_sha256": csrc_sha256(),
+                    "commit": os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % ROOT).read().strip() or None,
+                    "units": "bytes; FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, separate --pmc passes"}
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
-    print(json.dumps(res.get("gemm_bt_kernel<6>") or res.get("gemm_ring_kernel<6, true>"), indent=1))
+    print(json.dumps({k: res[k] for k in res if k.startswith("_")}, indent=1)[:2000])
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])
