@@ -19,11 +19,11 @@ contiguously over the ranks, one all-gather of the refined cloud per step; the d
 the extra object "strong_scaling" so that the driver's N = 1, 2, 4, 8 runs give a strong-scaling curve too.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel (the positional-encoding GEMM gemm_bt_kernel<EPI_LIF_ATTN, .>,
-                fn/snn_coder.py:360-368: d x d contraction + 4-step neuron loop + q-k+pe gather), its
-                three per-block shapes launched back to back on the current stream between two
-                events: achieved = mean algorithmic HBM bytes per launch (3*r*d*4: read pe1, write pe,
-                write attn_in) / mean launch time against 8 TB/s; MFMA-side figures alongside.
+  roofline      the dominant kernel (fn_edge_chain_kernel<256, 18>: block 2 of fn, its whole per-edge chain fn/snn_coder.py:355-389
+                in one launch), launched alone through its C-ABI entry between two events on the current stream: achieved =
+                issued f16 MFMA TFLOP/s against the 2.5 PFLOP/s dense peak; beside it SURVEY.md 8(d)'s fp32-MFMA model figure,
+                the VALU neuron-loop rate against its measured floor, HBM bytes per launch and per step from the committed
+                --pmc passes (null when they were not taken on these kernel sources).
   cpu_baseline  the oracle (our CPU restatement, torch-CPU, all host threads) timed on a bounded
                 sample of the same workload (rank 0, N=1 only).
 """
@@ -47,6 +47,7 @@ FN_KW = dict(k_values=[24, 18, 12], emb_dims=640, time_steps_enc=T_STEPS, num_he
 FD_KW = dict(k=32, emb_dims=768, time_steps_enc=T_STEPS, num_heads=8, k_scales=[8, 16, 32, 48])
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md, Chip-level parameters (spec; 6.3 TB/s measured copy)
 PEAK_F16_MFMA_TFLOPS = 2500.0   # dense f16 MFMA (spec)
+PEAK_F32_MFMA_TFLOPS = 157.3    # f32-input MFMA = the vector rate (MI355X_MICROARCH.md, Matrix cores)
 
 
 def build_models(dev):
@@ -68,82 +69,120 @@ def build_models(dev):
     return fn, fd, sdn, sdd
 
 
-def roofline_leg(dev, reps=3):
-    """Time the dominant kernel alone: gemm_bt_kernel<EPI_LIF_ATTN, .> (pos-enc GEMM, fn/snn_coder.py:360-368; gemm_ring_kernel with SAPCU_BT=0),
-    its three per-block launches for one chunk of patches, back to back on the current stream.
+def csrc_sha256():
+    """Hash of the kernel sources (the same function as profiles/pmc_to_json.py): a PMC file is only quoted when it was taken
+    on exactly these kernels."""
+    import hashlib
+    d = os.path.join(ROOT, "c-users-sayakdutta-self-supervised-arbitrary-scale-point-cloud-upsampling-via-snn_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
-    The kernel reads pe1 [r,d] and writes pe [r,d] and attn_in [r,d] (f32) and runs the 4-step neuron loop on
-    every output: it is bound by HBM streaming and the VALU neuron loop, not by the matrix pipe, so the roofline
-    is the HBM one; the MFMA-side figures are reported next to it."""
+
+def recorded_pmc():
+    """Newest profiles/r*_pmc.json taken on the current kernel sources, or (None, reason)."""
+    cands = sorted([f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json")], reverse=True)
+    mine = csrc_sha256()
+    for cand in cands:
+        try:
+            recs = json.load(open(os.path.join(ROOT, "profiles", cand)))
+        except (OSError, ValueError):
+            continue
+        if recs.get("_meta", {}).get("csrc_sha256") == mine:
+            return recs, "profiles/" + cand
+    return None, ("no profiles/*_pmc.json was taken on these kernel sources (csrc sha256 %s...): re-run profiles/run_profiles.sh" % mine[:12])
+
+
+# SURVEY.md 8(d): algorithmic HBM bytes per query = 2 x 576 B patches in + 16 B out + ~410 B outer-kNN share
+ALGO_BYTES_PER_QUERY = 2 * 576 + 16 + 410
+NEURON_FLOOR_NS_PER_1000 = 1.58       # profiles/micro/lif_rate.hip on MI355X: the 4-step LIF loop alone, 2 waves per SIMD
+
+
+def roofline_leg(dev, reps=5):
+    """Time the dominant kernel alone: fn_edge_chain_kernel<256, 18> (csrc/fn_edge_chain.hip) — block 2 of fn, the whole per-edge
+    chain (fn/snn_coder.py:355-389: pe1 -> fc_delta2 -> attn_in -> fc_gamma -> fc_gamma2 -> softmax-aggregate) of one 4096-patch
+    batch in ONE launch — through its C-ABI entry, on the current stream between two events.
+
+    Roofline: the matrix pipe.  achieved = ISSUED f16 MFMA flops (3 split-f16 products per algorithmic MAC: 3 x 3 GEMMs x
+    2 r d^2) / launch time against the 2.5 PFLOP/s dense f16 peak; SURVEY.md 8(d)'s model (algorithmic flops against the
+    157.3 TFLOP/s fp32-MFMA rate) and the VALU side (the kernel's real bound: the 4-step neuron loops, against the measured
+    floor of the bare loop) are reported beside it; `traffic` = HBM bytes per launch from the separate --pmc passes."""
     from sapcu_amd import _lib
     lib = _lib.load()
-    chunk = min(int(os.environ.get("SAPCU_CHUNK", "4096")), B_PER_GPU)
-    torch.manual_seed(0)
-    shapes = []
-    for l, kk in enumerate(FN_KW["k_values"]):
-        d = 128 << l
-        pts = chunk * M_PTS
-        r = pts * kk
-        pe = torch.rand((r, d), device=dev)
-        pes = torch.empty_like(pe)
-        _lib.check(lib.sapcu_to_split_rows(_lib.ptr(pe), r, d, d, _lib.ptr(pes), d, _lib.current_stream()))
-        pe = pes                       # the models hand pe1 over as split rows (written by fn_pe1_kernel)
-        qkv = torch.rand((pts, 3 * d), device=dev)
-        idx = torch.randint(0, M_PTS, (r,), dtype=torch.int32, device=dev)
-        w = (torch.rand((d, d), device=dev) - 0.5) * (2.0 / d ** 0.5)
-        bias = torch.rand((d,), device=dev) + 0.3
-        lif = torch.stack([torch.full((d,), 0.9), torch.full((d,), 0.01), torch.full((d,), 0.5), torch.ones(d)]).to(dev)
-        out = torch.empty((r, d), device=dev)
-        out2 = torch.empty((r, d), device=dev)
-        tab = torch.empty((r, 2), dtype=torch.int32, device=dev)
-        w16 = torch.zeros(4 * d * d + 16, dtype=torch.uint8, device=dev)
-        shapes.append((pe, r, d, w, bias, lif, qkv, idx, kk, out, out2, tab, w16))
+    d, kk, heads, T = 256, FN_KW["k_values"][1], FN_KW["num_heads"], 4
+    P = B_PER_GPU * M_PTS
+    r = P * kk
+    g = torch.Generator(device="cpu").manual_seed(0)
+    patch = (torch.randn((B_PER_GPU, M_PTS, 3), generator=g) * 0.05).to(dev)
+    idx = torch.stack([torch.randperm(M_PTS, generator=g)[:kk] for _ in range(P)]).to(torch.int32).to(dev)   # any neighbours
+    qkv = torch.rand((P, 3 * d), generator=g).to(dev)
 
-    def launch_all():
-        for pe, r, d, w, bias, lif, qkv, idx, kk, out, out2, tab, w16 in shapes:
-            _lib.check(lib.sapcu_posenc_gemm_f32(_lib.ptr(pe), r, d, _lib.ptr(w), _lib.ptr(bias), _lib.ptr(lif), 4, _lib.ptr(qkv),
-                                                 _lib.ptr(idx), kk, M_PTS, _lib.ptr(out), _lib.ptr(out2), _lib.ptr(tab),
-                                                 _lib.ptr(w16), 1, _lib.current_stream()))
+    def lin(n, k, gain):
+        return ((torch.rand((n, k), generator=g) * 2 - 1) * gain / k ** 0.5).to(dev), (torch.randn(n, generator=g) * 0.4 + 0.6).to(dev)
 
-    launch_all()
+    def lif():
+        return torch.stack([torch.full((d,), 0.9), torch.full((d,), 0.01), torch.full((d,), 0.5), torch.ones(d)]).to(dev)
+
+    wd, bd = lin(d, 3, 20.0)
+    (w1, b1), (w2, b2), (w3, b3) = lin(d, d, 2.0), lin(d, d, 2.0), lin(d, d, 4.0)
+    ld, l1, l2 = lif(), lif(), lif()
+    need = lib.sapcu_fn_edge_chain_workspace_bytes(P, d, kk)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    res = torch.empty((P, d), device=dev)
+    ops = [patch.view(P, 3), idx.view(-1), qkv, wd, bd, ld, w1, b1, l1, w2, b2, l2, w3, b3]
+
+    def launch():
+        _lib.check(lib.sapcu_fn_edge_chain_f32(_lib.ptr(ops[0]), _lib.ptr(ops[1]), P, M_PTS, d, kk, *[_lib.ptr(t) for t in ops[2:]],
+                                               heads, T, _lib.ptr(res), _lib.ptr(ws), need, _lib.current_stream()))
+
+    launch()
     torch.cuda.synchronize()
-    # the entry point also runs two tiny helper kernels (edge table, weight split): time them out of the figure
-    # by timing the GEMM-only part = total - helpers is not separable with events; they are < 1% (10 us vs ms)
+    assert torch.isfinite(res).all()
+    # the entry point also runs five tiny helper kernels (edge records, weight split / pack: ~40 us against ~9 ms)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()                       # torch's current stream IS the stream the kernels are launched on
     for _ in range(reps):
-        launch_all()
+        launch()
     e1.record()
     torch.cuda.synchronize()
-    n_launch = reps * len(shapes)
-    avg_s = e0.elapsed_time(e1) * 1e-3 / n_launch
-    flop = float(np.mean([2.0 * s[1] * s[2] * s[2] for s in shapes]))
-    byts = float(np.mean([3.0 * s[1] * s[2] * 4 for s in shapes]))      # read pe1, write pe, write attn_in (f32)
-    steps = float(np.mean([4.0 * s[1] * s[2] for s in shapes]))         # neuron element-steps
-    gbs = byts / avg_s / 1e9
-    # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
-    # command, corrected as MI355X_MICROARCH.md prescribes) — condensed by profiles/pmc_to_json.py
-    traffic, src, busy = None, None, None
-    for cand in sorted([f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json")], reverse=True):
-        try:
-            recs = json.load(open(os.path.join(ROOT, "profiles", cand)))
-            bt_off = os.environ.get("SAPCU_BT") == "0"
-            rec = (None if bt_off else recs.get("gemm_bt_kernel<6>")) or recs.get("gemm_ring_kernel<6, true>") or recs.get("gemm_ring_kernel<6>")
-            if rec:
-                traffic, src = float(rec["hbm_bytes_per_launch"]), "profiles/" + cand
-                busy = rec.get("mfma_busy_frac")      # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs), third PMC pass
-                break
-        except (OSError, ValueError, KeyError):
-            pass
-    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": src,
-            "kernel": ("gemm_ring_kernel<EPI_LIF_ATTN>" if os.environ.get("SAPCU_BT") == "0" else "gemm_bt_kernel<EPI_LIF_ATTN, 256|128>"),
-            "avg_launch_ms": round(avg_s * 1e3, 4),
-            "bytes_per_launch": byts, "launches_timed": n_launch, "chunk_patches": chunk,
-            "mfma": {"algorithmic_tflops": round(flop / avg_s / 1e12, 2), "issued_f16_tflops": round(3 * flop / avg_s / 1e12, 2),
-                     "peak_f16_dense_tflops": PEAK_F16_MFMA_TFLOPS, "issued_frac": round(3 * flop / avg_s / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
-                     "busy_frac_pmc": busy},
-            "neuron_element_steps_per_s": round(steps / avg_s, 0)}
+    avg_s = e0.elapsed_time(e1) * 1e-3 / reps
+    flop = 3 * 2.0 * r * d * d                         # algorithmic: three d x d contractions per edge row
+    issued = 3 * flop                                  # a_lo.w_hi + a_hi.w_lo + a_hi.w_hi
+    elems = 3.0 * r * d                                # neuron elements (4 steps each): pe1, pe, g
+    algo_bytes = r * 24.0 + P * 3 * d * 4.0 + P * d * 4.0      # edge records + q|k|v rows in, res out
+    recs, src = recorded_pmc()
+    traffic, busy, step_traffic = None, None, None
+    if recs is not None:
+        rec = recs.get("fn_edge_chain_kernel<256, 18>")
+        if rec:
+            traffic, busy = float(rec["hbm_bytes_per_launch"]), rec.get("mfma_busy_frac")
+        st = recs.get("_step")
+        if st:
+            algo_step = float(ALGO_BYTES_PER_QUERY * B_PER_GPU)
+            step_traffic = {"hbm_bytes_per_step": st["hbm_bytes_per_step"], "algorithmic_bytes_per_step": algo_step,
+                            "traffic_ratio": round(st["hbm_bytes_per_step"] / algo_step, 1),
+                            "note": "counter bytes of one 4096-query step / SURVEY.md 8(d) algorithmic bytes (patches in, results out, "
+                                    "kNN share); the step also streams 33 MB of weights"}
+    ns_per_1000 = avg_s * 1e9 / (elems / 1000.0)
+    return {"bound": "mfma", "achieved": round(issued / avg_s / 1e12, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(issued / avg_s / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+            "traffic": traffic, "traffic_source": src, "kernel": "fn_edge_chain_kernel<256, 18>",
+            "avg_launch_ms": round(avg_s * 1e3, 4), "launches_timed": reps,
+            "flops_per_launch": {"algorithmic": flop, "issued_f16": issued},
+            "algorithmic_tflops": round(flop / avg_s / 1e12, 2),
+            "fp32_mfma_model": {"peak_tflops": PEAK_F32_MFMA_TFLOPS, "frac": round(flop / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                "note": "SURVEY.md 8(d): algorithmic flops against the fp32-MFMA rate (the path issues 3 f16 MFMAs per "
+                                        "f32-quality product, so this is a model figure, not a utilisation)"},
+            "mfma_busy_frac_pmc": busy,
+            "algorithmic_bytes_per_launch": algo_bytes,
+            "valu": {"neuron_elements_per_launch": elems, "ns_per_1000_elements": round(ns_per_1000, 3),
+                     "floor_ns_per_1000_elements": NEURON_FLOOR_NS_PER_1000, "frac_of_neuron_floor": round(NEURON_FLOOR_NS_PER_1000 / ns_per_1000, 4),
+                     "note": "the kernel's physical bound is VALU issue of the 4-step neuron loops (13 packed + 2 clamp + 6 transcendental "
+                             "instructions per pair and step); floor = the bare loop, profiles/micro/lif_rate.hip"},
+            "step_traffic": step_traffic}
 
 
 def knn_leg(dev, cloud, seeds, reps=20):

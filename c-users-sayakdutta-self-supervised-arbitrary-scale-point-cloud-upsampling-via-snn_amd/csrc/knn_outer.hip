@@ -12,7 +12,9 @@
 //     slot p/64; k <= 128), so an insertion is one ballot+popcount (position) and one lane shift —
 //     no LDS, no divergence beyond the wave-uniform candidate loop;
 //   * candidates are visited in ascending point index and compared with strict '<' against the
-//     current k-th distance, which yields the (distance, index) ascending order of a stable sort.
+//     current k-th distance, which yields the (distance, index) ascending order of a stable sort;
+//   * the FIRST 64-point slab does not go through 64 serial insertions (every one of them passes an empty list's
+//     threshold): it is sorted across the lanes by a bitonic network on (distance, index) keys and becomes the list.
 #include "common.h"
 
 namespace sapcu {
@@ -79,6 +81,28 @@ __global__ __launch_bounds__(256) void knn_outer_kernel(const double* __restrict
                 d = __dmul_rn(dx, dx);
                 d = __dadd_rn(d, __dmul_rn(dy, dy));
                 d = __dadd_rn(d, __dmul_rn(dz, dz));
+            }
+            if (base == 0 && off == 0) {
+                // the list is empty: entries 0..63 = this slab in (distance, index) order (lanes past the cloud: INF, last)
+                int si = j < cnt ? j : 0x7fffffff;
+#pragma unroll
+                for (int kb = 2; kb <= 64; kb <<= 1) {
+#pragma unroll
+                    for (int jb = kb >> 1; jb > 0; jb >>= 1) {
+                        const double od = __shfl_xor(d, jb);
+                        const int oi = __shfl_xor(si, jb);
+                        const bool own_less = d < od || (d == od && si < oi);
+                        const bool want_less = ((lane & jb) == 0) == ((lane & kb) == 0);     // lower lane of an ascending pair
+                        if (own_less != want_less) {
+                            d = od;
+                            si = oi;
+                        }
+                    }
+                }
+                s0.d = d;
+                s0.i = si == 0x7fffffff ? -1 : si;
+                if (!TWO || k <= 64) tau = readlane_d(s0.d, (k - 1) & 63);      // k <= 64: the list is full (INF while cnt < k)
+                continue;
             }
             unsigned long long mask = __ballot(d < tau);
             while (mask) {

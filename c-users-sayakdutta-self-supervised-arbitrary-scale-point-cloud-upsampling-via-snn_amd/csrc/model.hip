@@ -606,6 +606,57 @@ int sapcu_posenc_gemm_f32(const float* pe1, int64_t r, int d, const float* w, co
     return launch_gemm(g, (hipStream_t)stream);
 }
 
+int64_t sapcu_fn_edge_chain_workspace_bytes(int64_t points, int d, int kk) {
+    if (points < 0 || !fn_edge_chain_ok(d, kk)) {
+        set_error("fn_edge_chain_workspace_bytes: unsupported shape (d=%d kk=%d)", d, kk);
+        return SAPCU_ERR_ARG;
+    }
+    const int64_t rows = points * kk;
+    auto up = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
+    return up(rows * 8) + up(rows * 16) + 3 * (up((int64_t)d * d * 4 + 16) + up((int64_t)d * d * 4)) + 256;
+}
+
+int sapcu_fn_edge_chain_f32(const float* patch, const int32_t* idx, int64_t points, int m_pts, int d, int kk,
+                            const float* qkv, const float* w_delta, const float* b_delta, const float* lif_delta,
+                            const float* w1, const float* b1, const float* lif1, const float* w2, const float* b2,
+                            const float* lif2, const float* w3, const float* b3, int heads, int lif_steps,
+                            float* res_out, void* workspace, int64_t workspace_bytes, void* stream) {
+    SAPCU_CHECK_ARG(patch && idx && qkv && w_delta && b_delta && lif_delta && w1 && b1 && lif1 && w2 && b2 && lif2 && w3 && b3 &&
+                        res_out && workspace, "fn_edge_chain: null pointer");
+    SAPCU_CHECK_ARG(fn_edge_chain_ok(d, kk), "fn_edge_chain: unsupported shape (d=%d kk=%d)", d, kk);
+    SAPCU_CHECK_ARG(points >= 0 && m_pts >= kk && heads >= 1 && d % heads == 0 && lif_steps >= 1, "fn_edge_chain: bad sizes");
+    const int64_t need = sapcu_fn_edge_chain_workspace_bytes(points, d, kk);
+    if (workspace_bytes < need) {
+        set_error("fn_edge_chain: workspace %lld B < required %lld B", (long long)workspace_bytes, (long long)need);
+        return SAPCU_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    Arena A{(char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), workspace_bytes, 0};
+    int2* tab = A.take<int2>(points * kk);
+    float4* pd = A.take<float4>(points * kk);
+    const float* ws[3] = {w1, w2, w3};
+    const _Float16* packed[3];
+    for (int q = 0; q < 3; ++q) {
+        char* split = A.take<char>((int64_t)d * d * 4 + 16);              // hi | lo | overflow counter
+        _Float16* pk = A.take<_Float16>((int64_t)d * d * 2);
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        SAPCU_TRY(split_into_ws(ws[q], (int64_t)d * d, split, g, st));
+        SAPCU_TRY(launch_pack_chain_weights(g.w16_hi, g.w16_lo, d, pk, st));
+        packed[q] = pk;
+    }
+    ChainArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.P = points; ca.m = m_pts; ca.qkv = qkv; ca.ldq = 3 * d;
+    ca.wd = w_delta; ca.bd = b_delta; ca.lifd = lif_delta;
+    ca.w1p = packed[0]; ca.b1 = b1; ca.lif1 = lif1;
+    ca.w2p = packed[1]; ca.b2 = b2; ca.lif2 = lif2;
+    ca.w3p = packed[2]; ca.b3 = b3;
+    ca.inv_sqrt_hd = 1.0f / (float)sqrt((double)(d / heads));
+    ca.res = res_out; ca.res_split = 0; ca.T = lif_steps;
+    return launch_fn_edge_chain(ca, patch, idx, d, kk, tab, pd, st);
+}
+
 int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob, int64_t blob_floats,
                        const int64_t* dir_host, int n_dir, sapcu_model_t* out) {
     SAPCU_CHECK_ARG(hp && blob && dir_host && out && blob_floats > 0, "model_create: null pointer");

@@ -269,6 +269,23 @@ int sapcu_posenc_gemm_f32(const float* pe1, int64_t r, int d, const float* w, co
                           int m_pts, float* pe_out, float* attn_in_out, void* edge_table_ws, void* w16_ws,
                           int split_rows, void* stream);
 
+/* The whole per-edge chain of one fn transformer block in ONE kernel, activations in LDS (csrc/fn_edge_chain.hip) — what the
+ * models run for the blocks with d = 128 (kk = 24) and d = 256 (kk = 18); fn/snn_coder.py:355-389:
+ *   pe1 = LIF_x4(fc_delta(x_i - x_j)), pe = LIF_x4(fc_delta2(pe1)), attn_in = q_i - k_j + pe, g = LIF_x4(fc_gamma(attn_in)),
+ *   a = fc_gamma2(g), res[i,:] = sum_j softmax_j(a / sqrt(d / heads)) * (v_j + pe)
+ * patch [points,3] f32 (points = patches * m_pts, patch-major); idx [points*kk] int32 in-patch neighbours; qkv [points, 3d]
+ * (q | k | v); w_delta [d,3]; w1 / w2 / w3 = fc_delta2 / fc_gamma / fc_gamma2 [d,d]; biases [d]; lif* = raw neuron parameters
+ * [4,d] (membrane_decay, threshold_adapt, refractory_decay, threshold_base; clamped inside as the reference does);
+ * res_out [points, d] f32.  Results equal the five-kernel chain (sapcu_posenc_gemm_f32 etc.) bit for bit.
+ * workspace: sapcu_fn_edge_chain_workspace_bytes(points, d, kk) bytes (edge records + the split / fragment-ordered weights,
+ * rebuilt by every call).  Returns SAPCU_ERR_ARG for any other (d, kk). */
+int64_t sapcu_fn_edge_chain_workspace_bytes(int64_t points, int d, int kk);
+int sapcu_fn_edge_chain_f32(const float* patch, const int32_t* idx, int64_t points, int m_pts, int d, int kk,
+                            const float* qkv, const float* w_delta, const float* b_delta, const float* lif_delta,
+                            const float* w1, const float* b1, const float* lif1, const float* w2, const float* b2,
+                            const float* lif2, const float* w3, const float* b3, int heads, int lif_steps,
+                            float* res_out, void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1141,6 +1141,61 @@ def test_big_tile_posenc_attention_gemm_is_bit_identical_to_the_ring_kernel(b, m
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("b,d,kk", [(6, 128, 24), (5, 256, 18), (1, 128, 24)])
+def test_fused_edge_chain_entry_against_the_oracle_primitives(b, d, kk):
+    """sapcu_fn_edge_chain_f32 (the C ABI of fn_edge_chain.hip) on random operands against the oracle's building blocks in the
+    reference's own tensor shapes ([b,C,N,k] 1x1 convolutions, T-step neuron loops, softmax over the neighbours, fn:355-389)."""
+    from sapcu_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(d + kk + b)
+    m, heads, T = 48, 8, 4
+    P = b * m
+    xyz = torch.from_numpy(rng.normal(0, 0.05, (b, m, 3)).astype(np.float32))
+    idx = O.inpatch_knn(xyz.permute(0, 2, 1).contiguous(), kk)                     # [b,m,kk]
+    qkv = torch.from_numpy(rng.random((P, 3 * d)).astype(np.float32))
+    def lin(n, k, gain):
+        return (torch.from_numpy((rng.uniform(-1, 1, (n, k)) * gain / np.sqrt(k)).astype(np.float32)),
+                torch.from_numpy(rng.normal(0.6, 0.4, n).astype(np.float32)))
+    def lif():
+        return torch.from_numpy(np.stack([rng.uniform(0.05, 1.1, d), rng.uniform(0.0, 0.2, d), rng.uniform(0.05, 1.0, d),
+                                          rng.normal(0.8, 0.3, d)]).astype(np.float32))
+    wd, bd = lin(d, 3, 20.0)
+    w1, b1 = lin(d, d, 2.0)
+    w2, b2 = lin(d, d, 2.0)
+    w3, b3 = lin(d, d, 4.0)
+    ld, l1, l2 = lif(), lif(), lif()
+    # reference in the model's own layout
+    def npar(l):
+        return {"decay": torch.clamp(l[0], 0.1, 0.99), "adapt": torch.clamp(l[1], 0.001, 0.1), "rdecay": torch.clamp(l[2], 0.1, 0.95), "theta0": l[3]}
+    def conv(x, w, bias):
+        return torch.nn.functional.conv2d(x, w[:, :, None, None], bias)
+    with torch.no_grad():
+        pos = xyz.permute(0, 2, 1)
+        pos_diff = (pos.unsqueeze(-1) - O.gather_cols(pos, idx)).contiguous()
+        q = qkv[:, :d].view(b, m, d).permute(0, 2, 1)
+        kf = qkv[:, d:2 * d].view(b, m, d).permute(0, 2, 1).contiguous()
+        v = qkv[:, 2 * d:].view(b, m, d).permute(0, 2, 1).contiguous()
+        pe = O.neuron_selfloop(conv(pos_diff, wd, bd), npar(ld), T)
+        pe = O.neuron_selfloop(conv(pe, w1, b1), npar(l1), T)
+        a = q.unsqueeze(-1) - O.gather_cols(kf, idx) + pe
+        a = O.neuron_selfloop(conv(a, w2, b2), npar(l2), T)
+        a = torch.softmax(conv(a, w3, b3) / np.sqrt(d // heads), dim=-1)
+        want = torch.einsum("bcnk,bcnk->bcn", a, O.gather_cols(v, idx) + pe).permute(0, 2, 1).reshape(P, d)
+    need = lib.sapcu_fn_edge_chain_workspace_bytes(P, d, kk)
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device=U.dev())
+    res = torch.full((P, d), float("nan"), device=U.dev())
+    args = [_dev(x) for x in (xyz.reshape(P, 3), idx.reshape(-1).to(torch.int32), qkv, wd, bd, ld, w1, b1, l1, w2, b2, l2, w3, b3)]
+    _lib.check(lib.sapcu_fn_edge_chain_f32(_lib.ptr(args[0]), _lib.ptr(args[1]), P, m, d, kk, *[_lib.ptr(t) for t in args[2:]],
+                                           heads, T, _lib.ptr(res), _lib.ptr(ws), need, _lib.current_stream()))
+    torch.cuda.synchronize()
+    err = (res.cpu() - want).abs().max().item()
+    print("edge chain d=%d kk=%d: max |device - oracle primitives| %.3g (|res| up to %.3g)" % (d, kk, err, want.abs().max()))
+    assert err <= 2e-5 * max(1.0, float(want.abs().max()))
+    assert lib.sapcu_fn_edge_chain_workspace_bytes(P, 512, 12) < 0                  # shapes the fused kernel does not take
+    assert lib.sapcu_fn_edge_chain_f32(*([None] * 2), P, m, 512, 12, *([None] * 12), heads, T, None, None, 0, None) < 0
+
+
 def test_fused_edge_chain_equals_the_unfused_chain_bit_for_bit(weights, monkeypatch):
     """fn_edge_chain.hip (blocks 1 and 2: pe1 -> fc_delta2 -> attn_in -> fc_gamma -> fc_gamma2 -> softmax-aggregate in one kernel,
     activations in LDS) against the five-kernel chain (SAPCU_CHAIN=0, read per launch): identical block outputs and normals,
