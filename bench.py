@@ -208,6 +208,24 @@ def knn_leg(dev, cloud, seeds, reps=20):
             "pair_distances_per_s": round(float(seeds.shape[0]) * cloud.shape[0] / t, 0)}
 
 
+def m100_leg(fn, fd, dev, cloud, seeds, steps=3):
+    """The same step at the reference's DEFAULT patch size (generation.py:68 k_neighbors=100; BASELINE's M=48 is a benchmark
+    choice): B=4096 queries, M=100, T=4 — a secondary figure, not the headline metric."""
+    import sapcu_amd
+    gen100 = sapcu_amd.Generator3D6(fn, fd, dev, k_neighbors=100, batch_size=B_PER_GPU)
+    with torch.no_grad():
+        gen100.refine(cloud, seeds)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out, _, _ = gen100.refine(cloud, seeds)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(out).all()
+    return {"workload": "as config.workload with M=100 neighbours (the reference's default k_neighbors)", "value": round(B_PER_GPU / dt, 2),
+            "unit": "query-points/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps}
+
+
 def cpu_baseline(sdn, sdd, sample=64):
     """Oracle on `sample` of the same queries (kNN + fn + rotate + fd + displace), all host threads."""
     from sapcu_amd import testing as T
@@ -402,6 +420,8 @@ def main():
             line["roofline"] = roofline_leg(dev)
             log("roofline leg done: %s" % line["roofline"])
             line["knn_kernel"] = knn_leg(dev, cloud, seeds)
+            line["m100"] = m100_leg(fn, fd, dev, cloud, seeds)
+            log("M=100 leg: %s" % line["m100"])
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sdn, sdd)
             log("cpu baseline done: %s" % line["cpu_baseline"])

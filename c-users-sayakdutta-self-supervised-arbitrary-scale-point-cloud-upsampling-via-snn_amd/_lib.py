@@ -41,6 +41,9 @@ _SIGNATURES = {
     "sapcu_bn_train_forward": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 4 + [c_void_p, c_int64, c_void_p]),
     "sapcu_bn_train_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int] + [c_void_p] * 3 + [c_void_p] * 3 + [c_void_p, c_int64, c_void_p]),
     "sapcu_conv1x1_wgrad_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "sapcu_gemm_bf16": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "sapcu_wgrad_bf16_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "sapcu_conv1x1_wgrad_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "sapcu_softmax_agg_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "sapcu_softmax_agg_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float,
                                           c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

@@ -87,7 +87,8 @@ struct sapcu_model {
     int* ovf_dev;
     // common
     int emb, T, heads;
-    int64_t chunk;
+    int64_t chunk;             // patches per chunk: SAPCU_CHUNK, or 0 = from the workspace budget (ws_budget bytes per forward)
+    int64_t ws_budget;
     float* blob;
     int64_t blob_floats;
     std::vector<int64_t> dir;
@@ -170,10 +171,35 @@ struct FnPlan {
     int64_t edge_floats;   // per-chunk size of one [rows, d] edge buffer
 };
 
+// bytes of chunk workspace per patch (the footprint is linear in the chunk size): the three edge buffers dominate
+static int64_t fn_bytes_per_patch(const sapcu_model* m, int mp) {
+    int64_t edge = (int64_t)mp * m->emb;
+    int kmx = 1;
+    int64_t idxs = 0;
+    for (int l = 0; l < 3; ++l) {
+        const int kk = imin(m->kv[l], mp);
+        edge = imax(edge, (int64_t)mp * kk * (128 << l));
+        idxs += (int64_t)mp * kk * 4;
+        kmx = kmx > kk ? kmx : kk;
+    }
+    return 3 * edge * 4 + idxs + (int64_t)mp * kmx * 24 + (int64_t)mp * (64 + 192 + 512 + 1536 + 512) * 4 +
+           ((int64_t)m->emb + 2048 + 1024 + 512 + 256 + 3) * 4;
+}
+
+// patches per chunk: SAPCU_CHUNK when set, else as many as the workspace budget holds (a multiple of 64, at least 64)
+static int64_t chunk_patches(const sapcu_model* m, int64_t b, int64_t bytes_per_patch) {
+    int64_t cb = m->chunk;
+    if (cb <= 0) {
+        cb = m->ws_budget / (bytes_per_patch > 0 ? bytes_per_patch : 1);
+        cb = cb < 64 ? 64 : (cb / 64) * 64;
+    }
+    if (cb > b) cb = b;
+    return cb < 1 ? 1 : cb;
+}
+
 static FnPlan fn_plan(const sapcu_model* m, int64_t b, int mp) {
     FnPlan pl;
-    pl.cb = b < m->chunk ? b : m->chunk;
-    if (pl.cb < 1) pl.cb = 1;
+    pl.cb = chunk_patches(m, b, fn_bytes_per_patch(m, mp));
     int64_t per_patch = (int64_t)mp * m->emb;
     for (int l = 0; l < 3; ++l) {
         pl.kk[l] = imin(m->kv[l], mp);
@@ -348,9 +374,13 @@ struct FdPlan {
 
 static FdPlan fd_plan(const sapcu_model* m, int64_t b, int mp) {
     FdPlan pl;
-    // fd intermediates are ~1.4 MB per patch and T-strided; cap the chunk so the agg buffer stays small
-    pl.cb = b < m->chunk ? b : m->chunk;
-    if (pl.cb < 1) pl.cb = 1;
+    // fd intermediates: T x (960 spikes + emb aggregate) + 1024 + block-0 features per point, neighbour tables
+    int kmax0 = 1;
+    for (int i = 0; i < m->nscale; ++i) kmax0 = kmax0 > m->ks[i] ? kmax0 : m->ks[i];
+    const int64_t per_patch = (int64_t)mp * (((int64_t)m->T * (960 + m->emb) + 1024 + 64 * (m->nscale + 1)) * 4 +
+                                            (int64_t)(imin(kmax0, mp) + 3 * imin(m->k, mp)) * 4) +
+                              ((int64_t)(m->T + 1) * m->emb + 256 + 3 * 128 + 3 * 64 + 192 + 64) * 4;
+    pl.cb = chunk_patches(m, b, per_patch);
     int kmax = 1;
     for (int i = 0; i < m->nscale; ++i) kmax = kmax > m->ks[i] ? kmax : m->ks[i];
     pl.kmax0 = imin(kmax, mp);
@@ -673,8 +703,14 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
     const char* ge = getenv("SAPCU_GEMM");
     m->sf16 = !(ge && strcmp(ge, "f32") == 0);
     const char* ce = getenv("SAPCU_CHUNK");
-    m->chunk = ce ? atoll(ce) : 4096;
-    if (m->chunk < 1) m->chunk = 1;
+    m->chunk = ce ? atoll(ce) : 0;
+    if (m->chunk < 0) m->chunk = 0;
+    // workspace budget per forward (the caller owns the buffer; sapcu_workspace_bytes reports what a batch needs under it):
+    // 20 GiB holds the whole 4096-patch benchmark batch at M = 48 in one chunk (16.9 GB fn, 6.7 GB fd) and cuts the reference's
+    // default M = 100 (8.5 MB per patch) into chunks of ~2400 patches instead of a 35 GB workspace
+    const char* be = getenv("SAPCU_WS_BUDGET_MB");
+    m->ws_budget = (be ? atoll(be) : 20480) * (int64_t)(1 << 20);
+    if (m->ws_budget < (int64_t)(64 << 20)) m->ws_budget = (int64_t)(64 << 20);
     int rc = SAPCU_OK;
     if (kind == SAPCU_KIND_FN) {
         if (n_hp != 6 || n_dir != FN_SLOTS) {

@@ -1,9 +1,14 @@
 """Training driver for fn — the reference's ``fn/trainer.py`` ``Trainer`` (:9-148 train_step, :150-227 evaluate, :229-247
 eval_step) over the HIP training ops of sapcu_amd/train.py.  Same constructor arguments, same return values, same
 skip-the-batch behaviour on NaN/Inf.  The optimiser is whatever torch optimiser the caller built on model.parameters()
-(the reference's trainfn.py:107-109 builds AdamW/Adam); the HIP ops compute in f32 whatever ``use_amp`` says — the flag
-and the scaler are accepted and the scaler's scale/unscale/step protocol is honoured so a reference training script runs
-unchanged."""
+(the reference's trainfn.py:107-109 builds AdamW/Adam).  ``use_amp=True`` runs the Conv / Linear GEMMs of the step — forward,
+data gradient, weight gradient — on bf16 operands with f32 accumulation (sapcu_amd.train.gemm_precision, csrc/train_bf16.hip):
+the counterpart of the reference's ``torch.amp.autocast`` region (fn/trainer.py:67-83; BASELINE config 5 names bf16, whose f32
+exponent range needs no loss scaling — a GradScaler, if given, is still driven through scale / unscale_ / step / update so a
+reference training script runs unchanged).  ``run_epoch`` is the batch loop of trainfn.py:253-330; ``SyntheticPU1K`` stands in
+for the PU1K mesh sampler (fn/datacore.py needs trimesh and the meshes, absent here)."""
+import time
+
 import numpy as np
 import torch
 from torch.nn import functional as F
@@ -42,19 +47,21 @@ class Trainer:
         if not self._finite(points) or not self._finite(gt):
             print("WARNING: NaN/Inf detected in the batch at step %d" % self.accumulation_step)
             return None, None
+        from . import train as T
         gt = F.normalize(gt, dim=-1)
-        pred = self.model(points)
-        if not self._finite(pred):
-            print("WARNING: NaN/Inf in model predictions")
-            return None, None
-        pred = F.normalize(pred, dim=-1)
-        loss, loss_dict = self.model.compute_loss(pred, gt, points)
-        if not self._finite(loss):
-            print("WARNING: NaN/Inf in loss value")
-            return None, None
-        scaled = loss / self.gradient_accumulation
         amp = self.use_amp and self.scaler is not None
-        (self.scaler.scale(scaled) if amp else scaled).backward()
+        with T.gemm_precision("bf16" if self.use_amp else "f32"):      # forward and backward, like the autocast region + backward
+            pred = self.model(points)
+            if not self._finite(pred):
+                print("WARNING: NaN/Inf in model predictions")
+                return None, None
+            pred = F.normalize(pred, dim=-1)
+            loss, loss_dict = self.model.compute_loss(pred, gt, points)
+            if not self._finite(loss):
+                print("WARNING: NaN/Inf in loss value")
+                return None, None
+            scaled = loss / self.gradient_accumulation
+            (self.scaler.scale(scaled) if amp else scaled).backward()
         if self.accumulation_step % self.gradient_accumulation == 0:
             total = None
             if self.grad_clip is not None:
@@ -126,6 +133,76 @@ class Trainer:
             metrics['confidence'] = float(np.mean(confs))
         metrics['angular_error_deg'] = total_err / n
         return total_loss / n, total_conf / n, metrics
+
+
+class SyntheticPU1K(object):
+    """Stand-in for the reference's PU1K training loader (fn/datacore.py; config/fn.yaml: batch_size 4, 64 patches of 12 points
+    per cloud): batches {'input': [B, N, M, 3] f32 centred patches, 'normal': [B, N, 3] unit normals} sampled from analytic
+    surfaces whose normals are known (sphere and torus shells, random pose), deterministic in (seed, batch index)."""
+
+    def __init__(self, batches, batch_size=4, patches=64, points=12, seed=0, radius=0.06):
+        self.batches, self.batch_size, self.patches, self.points, self.seed, self.radius = batches, batch_size, patches, points, seed, radius
+
+    def __len__(self):
+        return self.batches
+
+    def _cloud(self, rng):
+        n, m = self.patches, self.points
+        c = rng.normal(size=(n, 3))
+        c /= np.linalg.norm(c, axis=1, keepdims=True)                    # patch centres on a unit sphere ...
+        nrm = c.copy()
+        if rng.random() < 0.5:                                           # ... or on a torus (R = 0.7, r = 0.3): normals differ from positions
+            u, v = rng.uniform(0, 2 * np.pi, (2, n))
+            c = np.stack([(0.7 + 0.3 * np.cos(v)) * np.cos(u), (0.7 + 0.3 * np.cos(v)) * np.sin(u), 0.3 * np.sin(v)], 1)
+            nrm = np.stack([np.cos(v) * np.cos(u), np.cos(v) * np.sin(u), np.sin(v)], 1)
+        # tangent-plane samples around each centre, pushed back along the normal by the local curvature (1 / 2 x^2 term)
+        t1 = np.cross(nrm, rng.normal(size=(n, 3)))
+        t1 /= np.linalg.norm(t1, axis=1, keepdims=True)
+        t2 = np.cross(nrm, t1)
+        ab = rng.uniform(-self.radius, self.radius, (n, m, 2))
+        pts = ab[..., :1] * t1[:, None, :] + ab[..., 1:] * t2[:, None, :] - 0.5 * (ab ** 2).sum(-1, keepdims=True) * nrm[:, None, :]
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))                     # random pose of the whole cloud
+        return (pts @ q.T).astype(np.float32), (nrm @ q.T).astype(np.float32)
+
+    def __iter__(self):
+        for b in range(self.batches):
+            rng = np.random.default_rng([self.seed, b])
+            clouds = [self._cloud(rng) for _ in range(self.batch_size)]
+            yield {"input": torch.from_numpy(np.stack([c[0] for c in clouds])), "normal": torch.from_numpy(np.stack([c[1] for c in clouds]))}
+
+
+def run_epoch(trainer, train_loader, it=0, epoch_it=0, lr=None, warmup_steps=0, warmup_factor=0.01, state_reset_freq=0, print_every=0,
+              log=print):
+    """One pass over ``train_loader`` — the batch loop of the reference's trainfn.py:253-330 without its logging / checkpoint
+    side effects: iteration counter, SNN state reset every ``state_reset_freq`` iterations, linear learning-rate warm-up, skipped
+    invalid or non-finite batches, per-iteration losses, samples per second.  -> (it, losses, stats)."""
+    model, optimizer = trainer.model, trainer.optimizer
+    lr = optimizer.param_groups[0]["lr"] if lr is None else lr
+    losses, skipped, start, seen = [], 0, time.time(), 0
+    for batch in train_loader:
+        it += 1
+        if "input" not in batch:                                         # trainfn.py:259-260
+            continue
+        if state_reset_freq > 0 and it % state_reset_freq == 0 and hasattr(model, "reset_states"):
+            model.reset_states()
+        if warmup_steps > 0 and it < warmup_steps:                       # trainfn.py:266-269
+            f = warmup_factor + (1 - warmup_factor) * (it / warmup_steps)
+            for g in optimizer.param_groups:
+                g["lr"] = lr * f
+        loss, _ = trainer.train_step(batch)
+        if loss is None:
+            skipped += 1
+            continue
+        losses.append(float(loss))
+        seen += int(batch["input"].shape[0])
+        if print_every > 0 and it % print_every == 0:
+            log("[Epoch %03d] it=%06d, loss=%.6f, avg_loss=%.6f, lr=%.6f, samples/s=%.1f" % (
+                epoch_it, it, losses[-1], float(np.mean(losses[-print_every:])), optimizer.param_groups[0]["lr"],
+                seen / max(time.time() - start, 1e-9)))
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    dt = time.time() - start
+    return it, losses, {"clouds": seen, "seconds": dt, "clouds_per_s": seen / max(dt, 1e-9), "skipped": skipped}
 
 
 class GraphedTrainStep:

@@ -60,13 +60,55 @@ def _ws(lib, rows, ch, k, dev):
     return torch.empty((nbytes,), dtype=torch.uint8, device=dev), nbytes
 
 
+# Arithmetic of the training GEMMs (forward, data gradient, weight gradient): "f32" = the exact-f32 MFMA kernels (the parity
+# reference), "bf16" = operands rounded to bf16, f32 accumulation (csrc/train_bf16.hip) — what Trainer(use_amp=True) selects,
+# the counterpart of the reference's torch.amp.autocast region (fn/trainer.py:67-83).  Everything else (BatchNorm statistics,
+# neuron loops, softmax, losses, the optimiser) stays f32 in both modes, as under autocast.
+_GEMM_PRECISION = ["f32"]
+
+
+class gemm_precision(object):
+    """``with gemm_precision("bf16"): loss = ...; loss.backward()`` — covers the forward AND the backward launched inside."""
+
+    def __init__(self, mode):
+        if mode not in ("f32", "bf16"):
+            raise ValueError("gemm_precision: 'f32' or 'bf16'")
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = _GEMM_PRECISION[0]
+        _GEMM_PRECISION[0] = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        _GEMM_PRECISION[0] = self.prev
+        return False
+
+
 def _gemm(lib, a, w, bias, out):
-    """out[r, n] = a[r, k] . w[n, k]^T (+ bias): the exact-f32 MFMA kernel (k % 32 == 0)."""
+    """out[r, n] = a[r, k] . w[n, k]^T (+ bias): the exact-f32 MFMA kernel (k % 32 == 0), or bf16 operands."""
     r, k = a.shape
     n = w.shape[0]
+    if _GEMM_PRECISION[0] == "bf16":
+        _lib.check(lib.sapcu_gemm_bf16(_lib.ptr(a), r, k, k, _lib.ptr(w), n, _lib.ptr(bias), _lib.ptr(out), n, _lib.current_stream()))
+        return out
     _lib.check(lib.sapcu_gemm_f32(_lib.ptr(a), r, k, k, _lib.ptr(w), n, _lib.ptr(bias), None, 0, _lib.ptr(out), n, None, 0, 0,
                                   _lib.current_stream()))
     return out
+
+
+def _wgrad(lib, dy, x, rows, cout, cin, dw, db, ws, nbytes, st):
+    """dw[cout, cin] = dy^T . x, db = column sums of dy — f32 or bf16 operands like _gemm."""
+    if _GEMM_PRECISION[0] == "bf16":
+        need = int(lib.sapcu_wgrad_bf16_workspace_bytes(rows, cout, cin))
+        if need > nbytes:
+            ws = torch.empty((need,), dtype=torch.uint8, device=dy.device)
+            nbytes = need
+        _lib.check(lib.sapcu_conv1x1_wgrad_bf16(_lib.ptr(dy), cout, _lib.ptr(x), cin, rows, cout, cin, _lib.ptr(dw), _lib.ptr(db),
+                                                _lib.ptr(ws), nbytes, st))
+        return
+    _lib.check(lib.sapcu_conv1x1_wgrad_f32(_lib.ptr(dy), cout, _lib.ptr(x), cin, rows, cout, cin, _lib.ptr(dw), _lib.ptr(db),
+                                           _lib.ptr(ws), nbytes, st))
 
 
 class _ConvBnLifTrain(torch.autograd.Function):
@@ -137,8 +179,7 @@ class _ConvBnLifTrain(torch.autograd.Function):
             _lib.check(lib.sapcu_bn_train_backward(_lib.ptr(y), _lib.ptr(dz), rows, cout, _lib.ptr(gamma), _lib.ptr(mean),
                                                    _lib.ptr(invstd), _lib.ptr(dy), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws),
                                                    nbytes, st))
-            _lib.check(lib.sapcu_conv1x1_wgrad_f32(_lib.ptr(dy), cout, _lib.ptr(x), cin, rows, cout, cin, _lib.ptr(dw),
-                                                   _lib.ptr(dbias), _lib.ptr(ws), nbytes, st))
+            _wgrad(lib, dy, x, rows, cout, cin, dw, dbias, ws, nbytes, st)
             if ctx.needs_input_grad[0]:
                 _gemm(lib, dy, w.t().contiguous(), None, dx)        # dx[r, cin] = dy[r, cout] . (W^T)[cin, cout]^T
             else:
@@ -321,8 +362,7 @@ class _LinearTrain(torch.autograd.Function):
         dw, db, dx = torch.empty_like(w), torch.empty((cout,), dtype=torch.float32, device=x.device), torch.empty_like(x)
         ws, nbytes = _ws(lib, rows, cout, cin, x.device)
         with torch.cuda.device(x.device):
-            _lib.check(lib.sapcu_conv1x1_wgrad_f32(_lib.ptr(g), cout, _lib.ptr(x), cin, rows, cout, cin, _lib.ptr(dw), _lib.ptr(db),
-                                                   _lib.ptr(ws), nbytes, _lib.current_stream()))
+            _wgrad(lib, g, x, rows, cout, cin, dw, db, ws, nbytes, _lib.current_stream())
             _gemm(lib, g, w.t().contiguous(), None, dx)
         return dx, dw, db
 

@@ -134,6 +134,18 @@ int sapcu_bn_train_backward(const float* y, const float* grad_z, int64_t rows, i
 int sapcu_conv1x1_wgrad_f32(const float* grad_y, int ldy, const float* x, int ldx, int64_t rows, int n, int k,
                             float* grad_w, float* grad_bias, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* bf16-operand variants of the two training GEMMs (csrc/train_bf16.hip) — the counterpart of the reference's AMP training
+ * (fn/trainer.py:67-83 torch.amp.autocast; BASELINE config 5): operands rounded to bf16 (nearest even), f32 accumulation on the
+ * bf16 MFMA; tensors stay f32 in memory.  sapcu_gemm_bf16: c[r,n] = a[r,k] . w[n,k]^T + bias (forward; data gradient with
+ * w = W^T); k % 4 == 0.  sapcu_conv1x1_wgrad_bf16: as sapcu_conv1x1_wgrad_f32 (grad_bias summed in f32); workspace
+ * sapcu_wgrad_bf16_workspace_bytes(rows, n, k).  Opt-in (sapcu_amd.train.gemm_precision / Trainer(use_amp=True)): this IS a
+ * precision reduction; the f32 entries above remain the parity reference. */
+int sapcu_gemm_bf16(const float* a, int64_t r, int k, int lda, const float* w, int n, const float* bias, float* c, int ldc,
+                    void* stream);
+int64_t sapcu_wgrad_bf16_workspace_bytes(int64_t rows, int n, int k);
+int sapcu_conv1x1_wgrad_bf16(const float* grad_y, int ldy, const float* x, int ldx, int64_t rows, int n, int k,
+                             float* grad_w, float* grad_bias, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Per-channel softmax over the k neighbours + weighted aggregation (fn/snn_coder.py:379-389), as its own differentiable op:
  *   res[pt, c] = sum_j softmax_j(a[pt, j, c] / sqrt_hd) * (v[nbr(pt, j), c] + pe[pt, j, c])
  * a, pe, grad_a, grad_pe: [pts*kk, d] (edge rows); v, grad_v: [pts, ld] rows; idx [pts*kk] = in-patch neighbour indices,

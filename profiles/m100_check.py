@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sanity run at the reference's DEFAULT patch size (k_neighbors = 100, batch_size = 400): 40 000 seeds through Generator3D6.refine."""
 import sys, time, torch, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import bench, sapcu_amd
 from sapcu_amd import testing as T, generation as gen
 dev = torch.device('cuda:0')
