@@ -331,11 +331,18 @@ __device__ __forceinline__ float gelu_erf(float x) {   // nn.GELU() default (exa
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 __device__ __forceinline__ float lrelu02(float x) { return x >= 0.f ? x : 0.2f * x; }
+// order-preserving map float -> unsigned (a < b  <=>  key(a) < key(b) for non-NaN values); 0 is below every key
+__device__ __forceinline__ unsigned float_max_key(float x) {
+    const unsigned b = __float_as_uint(x);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float float_from_max_key(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
 // ---------------------------------------------------------------------------------------------
 // GEMM (gemm_f32.hip):  C[r,n] = epi( pro(A)[r,k] * W[n,k]^T + bias[n] )
 // ---------------------------------------------------------------------------------------------
-enum GemmEpi { EPI_BIAS = 0, EPI_LIF = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_LRELU = 4, EPI_RESID_GELU = 5, EPI_LIF_ATTN = 6 };
+enum GemmEpi { EPI_BIAS = 0, EPI_LIF = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_LRELU = 4, EPI_RESID_GELU = 5, EPI_LIF_ATTN = 6,
+               EPI_LRELU_MAX = 7 };   // gemm_sf16.hip only: LeakyReLU, then max over groups of max_m rows instead of storing C
 
 struct GemmArgs {
     const float* a;      // [r, lda]
@@ -365,6 +372,11 @@ struct GemmArgs {
     int* ovf;            // device counter raised when an activation tile exceeds the f16 range (may be null)
     // "split rows" (gemm_epi.h): A already split by its producer -> all-DMA ring kernel; outputs to be split
     int a_split, c_split, c2_split;
+    // EPI_LRELU_MAX (fd/snn_coder.py:476-480: multi_scale_conv -> max over the patch's points): C is never stored;
+    // max_keys[(row / max_m) * n + col] = max over the group's rows of the order-preserving integer key of the value
+    // (float_max_key; the buffer starts at 0 = below every key; launch_decode_max_keys turns it into floats)
+    unsigned* max_keys;
+    int max_m;
 };
 int launch_gemm(const GemmArgs& g, hipStream_t st);        // f32 MFMA (exact f32 products)
 int launch_gemm_sf16(const GemmArgs& g, hipStream_t st);   // 3 x f16 MFMA, f32-quality (needs w16_hi/lo); f32 A

@@ -63,9 +63,29 @@ __device__ __forceinline__ void epilogue_group(const GemmArgs& g, const float (&
 #pragma unroll
     for (int u = 0; u < W; ++u) {
         if (EPI == EPI_GELU) v[u] = gelu_erf(v[u]);
-        if (EPI == EPI_LRELU) v[u] = lrelu02(v[u]);
+        if (EPI == EPI_LRELU || EPI == EPI_LRELU_MAX) v[u] = lrelu02(v[u]);
         if (EPI == EPI_RESID) v[u] = __fadd_rn(v[u], res[u]);
         if (EPI == EPI_RESID_GELU) v[u] = gelu_erf(__fadd_rn(v[u], res[u]));
+    }
+    if (EPI == EPI_LRELU_MAX) {
+        // max over the row groups instead of a store: consecutive rows of one group are combined in registers, one
+        // integer atomicMax per (group, column) and lane (the maximum does not depend on the order: exact)
+        int64_t cur = -1;
+        float best = 0.f;
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            if (!ok[u]) continue;
+            const int64_t grp = (row + u) / g.max_m;
+            if (grp != cur) {
+                if (cur >= 0) atomicMax(g.max_keys + cur * g.n + col, float_max_key(best));
+                cur = grp;
+                best = v[u];
+            } else {
+                best = fmaxf(best, v[u]);
+            }
+        }
+        if (cur >= 0) atomicMax(g.max_keys + cur * g.n + col, float_max_key(best));
+        return;
     }
 #pragma unroll
     for (int u = 0; u < W; ++u) {

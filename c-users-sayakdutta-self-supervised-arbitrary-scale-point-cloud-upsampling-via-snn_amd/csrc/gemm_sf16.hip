@@ -365,6 +365,9 @@ int launch_gemm_sf16(const GemmArgs& g, hipStream_t st) {
         case EPI_GELU: return launch_t16<EPI_GELU>(g, st);
         case EPI_RESID: return launch_t16<EPI_RESID>(g, st);
         case EPI_LRELU: return launch_t16<EPI_LRELU>(g, st);
+        case EPI_LRELU_MAX:
+            SAPCU_CHECK_ARG(g.max_keys && g.max_m >= 1, "gemm_sf16: EPI_LRELU_MAX needs max_keys and max_m");
+            return launch_t16<EPI_LRELU_MAX>(g, st);
         case EPI_RESID_GELU: return launch_t16<EPI_RESID_GELU>(g, st);
         case EPI_LIF_ATTN:
             SAPCU_CHECK_ARG(g.ldq > 0 && g.tab && g.q && g.kf && g.c2, "gemm_sf16: bad attn operands");

@@ -470,8 +470,22 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
                                                SPK + (int64_t)t * P * 960, P * 960 * 4, hipMemcpyDeviceToDevice, st));
         }
         // multi_scale_conv + BN + LeakyReLU over all T*P rows, max over points        fd:476-480
-        SAPCU_TRY(gemm(m, SPK, (int64_t)T * P, 960, 960, m->p(FD_MSC_W), emb, m->p(FD_MSC_B), AGG, emb, EPI_LRELU, st));
-        SAPCU_TRY(launch_rowgroup_max(AGG, (int64_t)T * cb, mp, emb, POOLED, st));
+        const char* mxe = getenv("SAPCU_FD_MAXFUSE");        // read per call: the parity test flips it inside one process
+        if (m->sf16 && !(mxe && strcmp(mxe, "0") == 0)) {
+            // the max over the patch's points inside the GEMM's epilogue (integer atomicMax on order-preserving keys): the
+            // [T*P, emb] aggregate is never written.  The key buffer is the head of the (now unused) AGG area.
+            unsigned* keys = reinterpret_cast<unsigned*>(AGG);
+            SAPCU_CHECK_HIP(hipMemsetAsync(keys, 0, (size_t)T * cb * emb * 4, st));
+            GemmArgs g;
+            memset(&g, 0, sizeof(g));
+            g.a = SPK; g.r = (int64_t)T * P; g.k = 960; g.lda = 960; g.w = m->p(FD_MSC_W); g.n = emb; g.bias = m->p(FD_MSC_B);
+            g.c = nullptr; g.ldc = emb; g.epi = EPI_LRELU_MAX; g.max_keys = keys; g.max_m = mp;
+            SAPCU_TRY(run_gemm(m, g, st));
+            SAPCU_TRY(launch_decode_max_keys(keys, (int64_t)T * cb * emb, POOLED, st));
+        } else {
+            SAPCU_TRY(gemm(m, SPK, (int64_t)T * P, 960, 960, m->p(FD_MSC_W), emb, m->p(FD_MSC_B), AGG, emb, EPI_LRELU, st));
+            SAPCU_TRY(launch_rowgroup_max(AGG, (int64_t)T * cb, mp, emb, POOLED, st));
+        }
         if (taps && taps[SAPCU_FD_TAP_POOLED]) {
             for (int t = 0; t < T; ++t)
                 SAPCU_CHECK_HIP(hipMemcpyAsync((float*)taps[SAPCU_FD_TAP_POOLED] + ((int64_t)t * b + s) * emb,

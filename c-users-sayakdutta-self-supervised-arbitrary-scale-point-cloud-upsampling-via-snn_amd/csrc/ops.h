@@ -47,6 +47,7 @@ int launch_pack_chain_weights(const void* w16_hi, const void* w16_lo, int d, voi
 int launch_edge_table(const int32_t* idx, int64_t rows, int m, int kk, int2* tab, hipStream_t st);
 int launch_fn_softmax_agg(const float* a, const float* pe, const float* v, int ldv, const int32_t* idx, int64_t pts,
                           int m, int kk, int d, float sqrt_hd, float* res, int split, hipStream_t st);
+int launch_decode_max_keys(const unsigned* keys, int64_t count, float* out, hipStream_t st);   // float_from_max_key, element-wise
 int launch_rowgroup_max(const float* in, int64_t groups, int m, int c, float* out, hipStream_t st);
 int launch_fn_tail(const float* h, int64_t b, int kdim, const float* w, const float* bias, const float* lnw,
                    const float* lnb, float* logits, float* normals, hipStream_t st);

@@ -502,6 +502,19 @@ __global__ __launch_bounds__(256) void rowgroup_max_kernel(const float* __restri
     out[t] = mx;
 }
 
+// keys written by the GEMM's EPI_LRELU_MAX epilogue (common.h float_max_key) -> the maxima as floats
+__global__ __launch_bounds__(256) void decode_max_keys_kernel(const unsigned* __restrict__ keys, int64_t count, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = float_from_max_key(keys[i]);
+}
+
+int launch_decode_max_keys(const unsigned* keys, int64_t count, float* out, hipStream_t st) {
+    if (count == 0) return SAPCU_OK;
+    hipLaunchKernelGGL(decode_max_keys_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, keys, count, out);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
 int launch_rowgroup_max(const float* in, int64_t groups, int m, int c, float* out, hipStream_t st) {
     if (groups == 0) return SAPCU_OK;
     hipLaunchKernelGGL(rowgroup_max_kernel, dim3((unsigned)((groups * c + 255) / 256)), dim3(256), 0, st, in, groups,
