@@ -33,9 +33,19 @@
 namespace sapcu {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-constexpr int CH_ROWS = 128;                      // MFMA rows per group
-constexpr int CH_PLANE = CH_ROWS * 64;            // one plane of one k32 step: [128 rows][32 halves]
-constexpr int CH_KSTEP = 2 * CH_PLANE;            // hi | lo
+// MFMA rows per group: 128 for d = 128 / 256; 64 for d = 512 (a 128-row panel of 512 columns would be 256 KiB).
+// One plane of one k32 step is [ROWS][32 halves]; a k32 step = hi plane | lo plane.
+template <int D> struct ChainShape {
+    static constexpr int ROWS = D <= 256 ? 128 : 64;
+    static constexpr int RB = ROWS / 32;              // 32-row MFMA blocks per wave tile
+    static constexpr int PLANE = ROWS * 64;
+    static constexpr int KSTEP = 2 * PLANE;
+    static constexpr int LDS = ROWS * D * 4 + ROWS * 16 + ROWS * 8;
+    // register budget: 256 per wave at d <= 256 (2 waves per SIMD), 128 at d = 512 (16 waves per workgroup): epilogue
+    // units of 8 / 4 elements per lane, weight fragments 4 / 2 k16 steps ahead
+    static constexpr int US = D <= 256 ? 8 : 4;
+    static constexpr int WD = D <= 256 ? 4 : 2;
+};
 
 // ---------------------------------------------------------------------------------------------
 // edge preparation: per edge row (point i, neighbour slot j) the rows of point i and of its neighbour in the [points, .]
@@ -81,59 +91,64 @@ struct ChainLane {       // per-lane constants of the epilogues
     unsigned xw[2];      // LDS byte offset of (row 4h + .., this lane's column as k) for rows with ((row>>3)&1) = 0 / 1
 };
 
-struct ChainW {           // weight fragments of four k16 steps (hi, lo)
-    half8 wh[4], wl[4];
+template <int WD>
+struct ChainW {           // weight fragments of WD k16 steps (hi, lo)
+    half8 wh[WD], wl[WD];
 };
 
-// first four k16 steps of a GEMM's weight stream: issued well before the GEMM so that their L2 latency is covered
-__device__ __forceinline__ void chain_w_prefetch(const half8* __restrict__ wp, int lane, ChainW& W) {
+// first WD k16 steps of a GEMM's weight stream: issued well before the GEMM so that their L2 latency is covered
+template <int WD>
+__device__ __forceinline__ void chain_w_prefetch(const half8* __restrict__ wp, int lane, ChainW<WD>& W) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < WD; ++s) {
         W.wh[s] = wp[(s * 2) * 64 + lane];
         W.wl[s] = wp[(s * 2 + 1) * 64 + lane];
     }
 }
 
 template <int D>
-__device__ __forceinline__ void chain_gemm(const unsigned char* X, const half8* __restrict__ wp, int lane, ChainW& W, f32x16 (&acc)[4]) {
-    constexpr int NK16 = D / 16;
+__device__ __forceinline__ void chain_gemm(const unsigned char* X, const half8* __restrict__ wp, int lane, ChainW<ChainShape<D>::WD>& W,
+                                           f32x16 (&acc)[ChainShape<D>::RB]) {
+    constexpr int NK16 = D / 16, WD = ChainShape<D>::WD;
+    constexpr int RB = ChainShape<D>::RB, CH_PLANE = ChainShape<D>::PLANE, CH_KSTEP = ChainShape<D>::KSTEP;
     const int r32 = lane & 31, h = lane >> 5;
     const int sw = (r32 >> 2) & 3;                         // (row >> 2) & 3 of rows 32 i + r32
     const unsigned char* xa = X + r32 * 64;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 #pragma unroll
     for (int s = 0; s < NK16; ++s) {
         const unsigned ko = (unsigned)((s >> 1) * CH_KSTEP + ((((s & 1) * 2 + h) ^ sw) * 16));
-        half8 ah[4], al[4];
+        half8 ah[RB], al[RB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < RB; ++i) {
             ah[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048);
             al[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048 + CH_PLANE);
         }
-        const half8 cwh = W.wh[s & 3], cwl = W.wl[s & 3];
-        if (s + 4 < NK16) {                                // four k16 steps ahead
-            W.wh[s & 3] = wp[((s + 4) * 2) * 64 + lane];
-            W.wl[s & 3] = wp[((s + 4) * 2 + 1) * 64 + lane];
+        const half8 cwh = W.wh[s & (WD - 1)], cwl = W.wl[s & (WD - 1)];
+        if (s + WD < NK16) {                               // WD k16 steps ahead
+            W.wh[s & (WD - 1)] = wp[((s + WD) * 2) * 64 + lane];
+            W.wl[s & (WD - 1)] = wp[((s + WD) * 2 + 1) * 64 + lane];
         }
         // per accumulator: a_lo.w_hi, a_hi.w_lo, a_hi.w_hi — the order of gemm_sf16_ring.hip / gemm_sf16_bt.hip
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], cwh, acc[i], 0, 0, 0);
+        for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], cwh, acc[i], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], cwl, acc[i], 0, 0, 0);
+        for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], cwl, acc[i], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], cwh, acc[i], 0, 0, 0);
+        for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], cwh, acc[i], 0, 0, 0);
     }
 }
 
 // write v (row = 32 i + 8 q + 4 h + u, k = this lane's column) into the panel as the split-f16 operand of the next GEMM
+template <int PLANE>
 __device__ __forceinline__ void chain_put(unsigned char* X, const ChainLane& L, int i, int q, int u, float v) {
     unsigned char* p = X + L.xw[q & 1] + (unsigned)(i * 2048 + q * 512 + u * 64);
     const _Float16 hi = (_Float16)v;
     *reinterpret_cast<_Float16*>(p) = hi;
-    *reinterpret_cast<_Float16*>(p + CH_PLANE) = (_Float16)(v - (float)hi);
+    *reinterpret_cast<_Float16*>(p + PLANE) = (_Float16)(v - (float)hi);
 }
 
 __device__ __forceinline__ NeuronP chain_lif(const float* __restrict__ lif, int d, int col) {
@@ -147,9 +162,12 @@ __device__ __forceinline__ NeuronP chain_lif(const float* __restrict__ lif, int 
     return np;
 }
 
+// threads = 2 d (one wave per 32 columns).  d = 128: two 256-thread workgroups per CU (<= 256 registers per wave)
 template <int D, int KK>
-__global__ __launch_bounds__(D * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void fn_edge_chain_kernel(const ChainArgs a) {
+__global__ __launch_bounds__(D * 2, (D == 128 ? 2 : 1)) void fn_edge_chain_kernel(const ChainArgs a) {
+    constexpr int CH_ROWS = ChainShape<D>::ROWS, RB = ChainShape<D>::RB, CH_PLANE = ChainShape<D>::PLANE, CH_KSTEP = ChainShape<D>::KSTEP;
     constexpr int PPG = CH_ROWS / KK;                      // points per group
+    constexpr int US = ChainShape<D>::US, UPB = 16 / US;   // elements per epilogue unit, units per 32-row block
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* X = smem;
     float4* pdl = reinterpret_cast<float4*>(smem + CH_ROWS * D * 4);
@@ -181,8 +199,8 @@ __global__ __launch_bounds__(D * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int64_t pt0 = g * PPG;
     const int npts = (int)((a.P - pt0) < PPG ? (a.P - pt0) : PPG);
 
-    f32x16 acc[4], pe[4];
-    ChainW W;
+    f32x16 acc[RB], pe[RB];
+    ChainW<ChainShape<D>::WD> W;
     // ---- phase 0: edge records of the group's rows; pe1 = LIF(fc_delta(x_i - x_j)) -> panel              fn:310,355-358
     float qp[PPG];                                         // q_i of the group's points, this lane's column
     if (tid < CH_ROWS) {
@@ -202,34 +220,33 @@ __global__ __launch_bounds__(D * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll
         for (int p = 0; p < PPG; ++p) qp[p] = a.qkv[(pt0 + (p < npts ? p : 0)) * a.ldq + L.col];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int u = 0; u < RB * UPB; ++u) {
+            const int i = u / UPB, e0 = US * (u % UPB);
+            float v[US];
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                float v[8];
-#pragma unroll
-                for (int z = 0; z < 8; ++z) {
-                    const float4 dd = pdl[32 * i + 8 * (2 * qq + (z >> 2)) + 4 * L.h + (z & 3)];
-                    float t0 = __fmul_rn(wx, dd.x);
-                    t0 = __fmaf_rn(wy, dd.y, t0);
-                    t0 = __fmaf_rn(wz, dd.z, t0);
-                    v[z] = __fadd_rn(t0, bd);
-                }
-                lif_selfloop_n<8>(v, nd, a.T);
-#pragma unroll
-                for (int z = 0; z < 8; ++z) chain_put(X, L, i, 2 * qq + (z >> 2), z & 3, v[z]);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int z = 0; z < US; ++z) {
+                const float4 dd = pdl[32 * i + 8 * ((e0 + z) >> 2) + 4 * L.h + ((e0 + z) & 3)];
+                float t0 = __fmul_rn(wx, dd.x);
+                t0 = __fmaf_rn(wy, dd.y, t0);
+                t0 = __fmaf_rn(wz, dd.z, t0);
+                v[z] = __fadd_rn(t0, bd);
             }
+            lif_selfloop_n<US>(v, nd, a.T);
+#pragma unroll
+            for (int z = 0; z < US; ++z) chain_put<CH_PLANE>(X, L, i, (e0 + z) >> 2, (e0 + z) & 3, v[z]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     const half8* const wp1 = reinterpret_cast<const half8*>(a.w1p) + (int64_t)w * (D / 16) * 128;
     const half8* const wp2 = reinterpret_cast<const half8*>(a.w2p) + (int64_t)w * (D / 16) * 128;
     const half8* const wp3 = reinterpret_cast<const half8*>(a.w3p) + (int64_t)w * (D / 16) * 128;
-    // k_j and v_j of 8 rows (one epilogue unit u: block u >> 1, quads 2 (u & 1), 2 (u & 1) + 1), this lane's column
-    float kq[2][8], vq[2][8];
-    auto gather_kv = [&](int u, float (&kd)[8], float (&vd)[8]) {
+    // k_j and v_j of one epilogue unit u (block u / UPB, elements US (u % UPB) .. + US - 1 of this lane), this lane's column
+    float kq[2][US], vq[2][US];
+    auto gather_kv = [&](int u, float (&kd)[US], float (&vd)[US]) {
 #pragma unroll
-        for (int z = 0; z < 8; ++z) {
-            const int nrow = rinfo[32 * (u >> 1) + 8 * (2 * (u & 1) + (z >> 2)) + 4 * L.h + (z & 3)].y;
+        for (int z = 0; z < US; ++z) {
+            const int e = US * (u % UPB) + z;
+            const int nrow = rinfo[32 * (u / UPB) + 8 * (e >> 2) + 4 * L.h + (e & 3)].y;
             kd[z] = a.qkv[(int64_t)nrow * a.ldq + D + L.col];
             vd[z] = a.qkv[(int64_t)nrow * a.ldq + 2 * D + L.col];
         }
@@ -244,27 +261,28 @@ __global__ __launch_bounds__(D * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         const NeuronP n1 = chain_lif(a.lif1, D, L.col);
         chain_gemm<D>(X, wp1, lane, W, acc);
         lds_barrier();                                     // every wave has read the pe1 panel: it may be overwritten
-        // software pipeline over the 8 units: the gathers of unit u + 1 are issued before the neuron arithmetic of unit u
+        // software pipeline over the units: the gathers of unit u + 1 are issued before the neuron arithmetic of unit u
         // and consumed after the one of unit u + 1 (the in-order vector-memory counter then waits for loads that are one
         // arithmetic block old)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = u >> 1, qq = u & 1;
-            if (u + 1 < 8) gather_kv(u + 1, kq[(u + 1) & 1], vq[(u + 1) & 1]);
+        for (int u = 0; u < RB * UPB; ++u) {
+            const int i = u / UPB, e0 = US * (u % UPB);
+            if (u + 1 < RB * UPB) gather_kv(u + 1, kq[(u + 1) & 1], vq[(u + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
-            float v[8];
+            float v[US];
 #pragma unroll
-            for (int z = 0; z < 8; ++z) v[z] = __fmaf_rn(acc[i][8 * qq + z], 0.0625f, b1);      // undoes the x16 of the pre-scaled weights (exact)
-            lif_selfloop_n<8>(v, n1, a.T);
+            for (int z = 0; z < US; ++z) v[z] = __fmaf_rn(acc[i][e0 + z], 0.0625f, b1);      // undoes the x16 of the pre-scaled weights (exact)
+            lif_selfloop_n<US>(v, n1, a.T);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int z = 0; z < 8; ++z) {
+            for (int z = 0; z < US; ++z) {
                 // the row's point: row = 32 i + 8 q + 4 h + u, compile-time per lane half (pad rows: any point)
-                const int r0 = 32 * i + 8 * (2 * qq + (z >> 2)) + (z & 3), r1 = r0 + 4;
+                const int e = e0 + z;
+                const int r0 = 32 * i + 8 * (e >> 2) + (e & 3), r1 = r0 + 4;
                 const int p0 = r0 / KK < PPG ? r0 / KK : PPG - 1, p1 = r1 / KK < PPG ? r1 / KK : PPG - 1;
                 const float qv = p0 == p1 ? qp[p0] : (L.h ? qp[p1] : qp[p0]);
-                chain_put(X, L, i, 2 * qq + (z >> 2), z & 3, __fadd_rn(__fsub_rn(qv, kq[u & 1][z]), v[z]));
-                pe[i][8 * qq + z] = __fadd_rn(vq[u & 1][z], v[z]);                        // t = v_j + pe (fn:386-389)
+                chain_put<CH_PLANE>(X, L, i, e >> 2, e & 3, __fadd_rn(__fsub_rn(qv, kq[u & 1][z]), v[z]));
+                pe[i][e] = __fadd_rn(vq[u & 1][z], v[z]);                                  // t = v_j + pe (fn:386-389)
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -278,17 +296,15 @@ __global__ __launch_bounds__(D * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         chain_gemm<D>(X, wp2, lane, W, acc);
         lds_barrier();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int u = 0; u < RB * UPB; ++u) {
+            const int i = u / UPB, e0 = US * (u % UPB);
+            float v[US];
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                float v[8];
+            for (int z = 0; z < US; ++z) v[z] = __fmaf_rn(acc[i][e0 + z], 0.0625f, b2);
+            lif_selfloop_n<US>(v, n2, a.T);
 #pragma unroll
-                for (int z = 0; z < 8; ++z) v[z] = __fmaf_rn(acc[i][8 * qq + z], 0.0625f, b2);
-                lif_selfloop_n<8>(v, n2, a.T);
-#pragma unroll
-                for (int z = 0; z < 8; ++z) chain_put(X, L, i, 2 * qq + (z >> 2), z & 3, v[z]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int z = 0; z < US; ++z) chain_put<CH_PLANE>(X, L, i, (e0 + z) >> 2, (e0 + z) & 3, v[z]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         chain_w_prefetch(wp3, lane, W);
     }
@@ -299,7 +315,7 @@ __global__ __launch_bounds__(D * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         chain_gemm<D>(X, wp3, lane, W, acc);
         // own rows: x = (a + b) / sqrt(hd) in place of the accumulators (pe already holds t = v_j + pe)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][e] = __fmul_rn(__fmaf_rn(acc[i][e], 0.0625f, b3), a.inv_sqrt_hd);
         // per point: its kk rows alternate between the lane halves in quads; both halves fetch the other's values and
@@ -338,14 +354,14 @@ __global__ __launch_bounds__(D * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 
 template <int D, int KK>
 static int launch_chain_t(const ChainArgs& a, hipStream_t st) {
-    const int lds = CH_ROWS * D * 4 + CH_ROWS * 16 + CH_ROWS * 8;
+    constexpr int lds = ChainShape<D>::LDS;
     static bool attr_set = false;
     if (!attr_set) {
         SAPCU_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fn_edge_chain_kernel<D, KK>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    constexpr int PPG = CH_ROWS / KK;
+    constexpr int PPG = ChainShape<D>::ROWS / KK;
     const int64_t ngroups = (a.P + PPG - 1) / PPG;
     const int64_t grid = ngroups < 8 ? ngroups : ((ngroups + 7) / 8) * 8;      // 8 XCD ranges of equal slot count
     SAPCU_CHECK_ARG(grid < 0x7fffffffLL, "edge_chain: too many groups");
@@ -354,7 +370,7 @@ static int launch_chain_t(const ChainArgs& a, hipStream_t st) {
     return SAPCU_OK;
 }
 
-bool fn_edge_chain_ok(int d, int kk) { return (d == 128 && kk == 24) || (d == 256 && kk == 18); }
+bool fn_edge_chain_ok(int d, int kk) { return (d == 128 && kk == 24) || (d == 256 && kk == 18) || (d == 512 && kk == 12); }
 
 int launch_fn_edge_chain(ChainArgs a, const float* patch, const int32_t* idx, int d, int kk, int2* tab, float4* pd,
                          hipStream_t st) {
@@ -367,7 +383,8 @@ int launch_fn_edge_chain(ChainArgs a, const float* patch, const int32_t* idx, in
     a.tab = tab;
     a.pd = pd;
     if (d == 128) return launch_chain_t<128, 24>(a, st);
-    return launch_chain_t<256, 18>(a, st);
+    if (d == 256) return launch_chain_t<256, 18>(a, st);
+    return launch_chain_t<512, 12>(a, st);
 }
 
 int launch_pack_chain_weights(const void* w16_hi, const void* w16_lo, int d, void* out, hipStream_t st) {

@@ -83,7 +83,7 @@ struct sapcu_model {
     bool sf16;
     void* w16_hi;
     void* w16_lo;
-    void* chain_w;             // fn: fc_delta2 | fc_gamma | fc_gamma2 of blocks 1, 2 in MFMA-fragment order (fn_edge_chain.hip)
+    void* chain_w;             // fn: fc_delta2 | fc_gamma | fc_gamma2 of the three blocks in MFMA-fragment order (fn_edge_chain.hip)
     int* ovf_dev;
     // common
     int emb, T, heads;
@@ -168,21 +168,42 @@ static int tap_copy(void* const* taps, int which, int64_t dst_off_bytes, const v
 struct FnPlan {
     int64_t cb;       // patches per chunk
     int kk[3];
-    int64_t edge_floats;   // per-chunk size of one [rows, d] edge buffer
+    int64_t edge_floats, edge_floats23;   // per-chunk size of edge buffer 1 (also conv_final's output) and of buffers 2, 3
 };
 
-// bytes of chunk workspace per patch (the footprint is linear in the chunk size): the three edge buffers dominate
+// does block l run its edge chain fused (fn_edge_chain.hip)?  Decided per call (SAPCU_CHAIN is read per call: the parity tests
+// flip it inside one process); the workspace plan and the forward use the same answer.
+static bool fn_block_fused(const sapcu_model* m, int l, int mp) {
+    const char* che = getenv("SAPCU_CHAIN");
+    return m->sf16 && m->chain_w && fn_edge_chain_ok(128 << l, imin(m->kv[l], mp)) && !(che && strcmp(che, "0") == 0);
+}
+
+// floats of one [rows, d] edge buffer per patch: only the unfused blocks materialise edge tensors; buffer 1 also holds
+// conv_final's [points, emb] output
+static void fn_edge_floats_per_patch(const sapcu_model* m, int mp, int64_t& first, int64_t& others) {
+    first = (int64_t)mp * m->emb;
+    others = 0;
+    for (int l = 0; l < 3; ++l) {
+        if (fn_block_fused(m, l, mp)) continue;
+        const int64_t e = (int64_t)mp * imin(m->kv[l], mp) * (128 << l);
+        first = imax(first, e);
+        others = imax(others, e);
+    }
+}
+
+// bytes of chunk workspace per patch (the footprint is linear in the chunk size): the edge buffers dominate when a block
+// runs unfused
 static int64_t fn_bytes_per_patch(const sapcu_model* m, int mp) {
-    int64_t edge = (int64_t)mp * m->emb;
+    int64_t e1, e23;
+    fn_edge_floats_per_patch(m, mp, e1, e23);
     int kmx = 1;
     int64_t idxs = 0;
     for (int l = 0; l < 3; ++l) {
         const int kk = imin(m->kv[l], mp);
-        edge = imax(edge, (int64_t)mp * kk * (128 << l));
         idxs += (int64_t)mp * kk * 4;
         kmx = kmx > kk ? kmx : kk;
     }
-    return 3 * edge * 4 + idxs + (int64_t)mp * kmx * 24 + (int64_t)mp * (64 + 192 + 512 + 1536 + 512) * 4 +
+    return (e1 + 2 * e23) * 4 + idxs + (int64_t)mp * kmx * 24 + (int64_t)mp * (64 + 192 + 512 + 1536 + 512) * 4 +
            ((int64_t)m->emb + 2048 + 1024 + 512 + 256 + 3) * 4;
 }
 
@@ -200,12 +221,11 @@ static int64_t chunk_patches(const sapcu_model* m, int64_t b, int64_t bytes_per_
 static FnPlan fn_plan(const sapcu_model* m, int64_t b, int mp) {
     FnPlan pl;
     pl.cb = chunk_patches(m, b, fn_bytes_per_patch(m, mp));
-    int64_t per_patch = (int64_t)mp * m->emb;
-    for (int l = 0; l < 3; ++l) {
-        pl.kk[l] = imin(m->kv[l], mp);
-        per_patch = imax(per_patch, (int64_t)mp * pl.kk[l] * (128 << l));
-    }
-    pl.edge_floats = per_patch * pl.cb;
+    for (int l = 0; l < 3; ++l) pl.kk[l] = imin(m->kv[l], mp);
+    int64_t e1, e23;
+    fn_edge_floats_per_patch(m, mp, e1, e23);
+    pl.edge_floats = e1 * pl.cb;
+    pl.edge_floats23 = e23 * pl.cb;
     return pl;
 }
 
@@ -217,7 +237,7 @@ static int64_t fn_ws_bytes(const sapcu_model* m, int64_t b, int mp) {
     for (int l = 0; l < 3; ++l) add(P * pl.kk[l], 4);          // idx
     { int kmx = 1; for (int l = 0; l < 3; ++l) kmx = kmx > pl.kk[l] ? kmx : pl.kk[l]; add(P * kmx, 8); add(P * kmx, 16); }   // edge table, position differences
     add(P * 64, 4); add(P * 192, 4); add(P * 512, 4); add(P * 1536, 4); add(P * 512, 4);
-    add(pl.edge_floats, 4); add(pl.edge_floats, 4); add(pl.edge_floats, 4);
+    add(pl.edge_floats, 4); add(pl.edge_floats23, 4); add(pl.edge_floats23, 4);
     add(pl.cb * m->emb, 4); add(pl.cb * 2048, 4); add(pl.cb * 1024, 4); add(pl.cb * 512, 4); add(pl.cb * 256, 4);
     add(pl.cb * 3, 4);
     return fl + 256;
@@ -253,8 +273,8 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
         float* QKV = A.take<float>(pl.cb * mp * 1536);
         float* RES = A.take<float>(pl.cb * mp * 512);
         float* B1 = A.take<float>(pl.edge_floats);
-        float* B2 = A.take<float>(pl.edge_floats);
-        float* B3 = A.take<float>(pl.edge_floats);
+        float* B2 = A.take<float>(pl.edge_floats23);
+        float* B3 = A.take<float>(pl.edge_floats23);
         float* pooled = A.take<float>(pl.cb * m->emb);
         float* enc = A.take<float>(pl.cb * 2048);
         float* h1 = A.take<float>(pl.cb * 1024);
@@ -295,14 +315,14 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
             SAPCU_TRY(gemm(m, X, P, d, d, m->p(sb + B_QKV_W), 3 * d, m->p(sb + B_QKV_B), QKV, 3 * d, EPI_LIF, st,
                            m->p(sb + B_QKV_LIF), 4, nullptr, 0, SP));
             const float sqrt_hd = (float)sqrt((double)(d / m->heads));
-            const char* che = getenv("SAPCU_CHAIN");              // read per call: the parity test flips it inside one process
-            if (SP && m->chain_w && l < 2 && fn_edge_chain_ok(d, kk) && !(che && strcmp(che, "0") == 0)) {
+            if (fn_block_fused(m, l, mp)) {
                 // the whole edge chain in one kernel, activations in LDS (fn_edge_chain.hip)      fn:355-389
                 ChainArgs ca;
                 memset(&ca, 0, sizeof(ca));
                 ca.P = P; ca.m = mp; ca.qkv = QKV; ca.ldq = 3 * d;
                 ca.wd = m->p(sb + B_DELTA_W); ca.bd = m->p(sb + B_DELTA_B); ca.lifd = m->p(sb + B_DELTA_LIF);
-                const _Float16* cw = (const _Float16*)m->chain_w + (l == 0 ? 0 : (int64_t)3 * 128 * 128 * 2);
+                static const int64_t cw_off[3] = {0, (int64_t)3 * 2 * 128 * 128, (int64_t)3 * 2 * (128 * 128 + 256 * 256)};
+                const _Float16* cw = (const _Float16*)m->chain_w + cw_off[l];
                 ca.w1p = cw; ca.b1 = m->p(sb + B_DELTA2_B); ca.lif1 = m->p(sb + B_DELTA2_LIF);
                 ca.w2p = cw + (int64_t)d * d * 2; ca.b2 = m->p(sb + B_GAMMA_B); ca.lif2 = m->p(sb + B_GAMMA_LIF);
                 ca.w3p = cw + (int64_t)2 * d * d * 2; ca.b3 = m->p(sb + B_GAMMA2_B);
@@ -786,12 +806,12 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
                 if (rc == SAPCU_OK) hip_ok(hipMemcpy(&wovf, m->ovf_dev + 1, sizeof(int), hipMemcpyDeviceToHost), "read ovf");
                 if (rc == SAPCU_OK && wovf != 0) m->sf16 = false;   // a parameter exceeds the f16 range: exact-f32 kernels
             }
-            // fn blocks 1 and 2 (d = 128, 256): the three d x d matrices of the edge chain again in MFMA-fragment order
+            // fn blocks 1-3 (d = 128, 256, 512): the three d x d matrices of the edge chain again in MFMA-fragment order
             if (rc == SAPCU_OK && m->sf16 && kind == SAPCU_KIND_FN) {
-                const int64_t halves = (int64_t)3 * 2 * (128 * 128 + 256 * 256);
+                const int64_t halves = (int64_t)3 * 2 * (128 * 128 + 256 * 256 + 512 * 512);
                 hip_ok(hipMalloc(&m->chain_w, (size_t)halves * 2), "hipMalloc(chain_w)");
                 int64_t off = 0;
-                for (int l = 0; l < 2 && rc == SAPCU_OK; ++l) {
+                for (int l = 0; l < 3 && rc == SAPCU_OK; ++l) {
                     const int d = 128 << l;
                     static const int slots[3] = {B_DELTA2_W, B_GAMMA_W, B_GAMMA2_W};
                     for (int q = 0; q < 3 && rc == SAPCU_OK; ++q) {

@@ -1250,7 +1250,7 @@ def test_big_tile_posenc_attention_gemm_is_bit_identical_to_the_ring_kernel(b, m
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("b,d,kk", [(6, 128, 24), (5, 256, 18), (1, 128, 24)])
+@pytest.mark.parametrize("b,d,kk", [(6, 128, 24), (5, 256, 18), (1, 128, 24), (7, 512, 12)])
 def test_fused_edge_chain_entry_against_the_oracle_primitives(b, d, kk):
     """sapcu_fn_edge_chain_f32 (the C ABI of fn_edge_chain.hip) on random operands against the oracle's building blocks in the
     reference's own tensor shapes ([b,C,N,k] 1x1 convolutions, T-step neuron loops, softmax over the neighbours, fn:355-389)."""
@@ -1301,15 +1301,16 @@ def test_fused_edge_chain_entry_against_the_oracle_primitives(b, d, kk):
     err = (res.cpu() - want).abs().max().item()
     print("edge chain d=%d kk=%d: max |device - oracle primitives| %.3g (|res| up to %.3g)" % (d, kk, err, want.abs().max()))
     assert err <= 2e-5 * max(1.0, float(want.abs().max()))
-    assert lib.sapcu_fn_edge_chain_workspace_bytes(P, 512, 12) < 0                  # shapes the fused kernel does not take
-    assert lib.sapcu_fn_edge_chain_f32(*([None] * 2), P, m, 512, 12, *([None] * 12), heads, T, None, None, 0, None) < 0
+    assert lib.sapcu_fn_edge_chain_workspace_bytes(P, 512, 24) < 0                  # shapes the fused kernel does not take
+    assert lib.sapcu_fn_edge_chain_f32(*([None] * 2), P, m, 512, 24, *([None] * 12), heads, T, None, None, 0, None) < 0
 
 
 def test_fused_edge_chain_equals_the_unfused_chain_bit_for_bit(weights, monkeypatch):
     """fn_edge_chain.hip (blocks 1 and 2: pe1 -> fc_delta2 -> attn_in -> fc_gamma -> fc_gamma2 -> softmax-aggregate in one kernel,
     activations in LDS) against the five-kernel chain (SAPCU_CHAIN=0, read per launch): identical block outputs and normals,
     bit for bit — full groups, a ragged last group (points not a multiple of 5 / 7), one patch, M = 100 (the reference's
-    default patch size) and M = 20 (block 1's kk = 20 is not a shape the fused kernel takes: that block stays unfused)."""
+    default patch size) and M = 20 (block 1's kk = 20 is not a shape the fused kernel takes: that block stays unfused).
+    All three blocks (d = 128 / 256 / 512) run fused."""
     fn, _, _, _ = U.build_gpu_models(weights)
     fn.knn_cache_mode = "fresh"
     for nq, mpts in ((64, 48), (37, 48), (1, 48), (9, 100), (11, 20)):
