@@ -19,7 +19,7 @@ contiguously over the ranks, one all-gather of the refined cloud per step; the d
 the extra object "strong_scaling" so that the driver's N = 1, 2, 4, 8 runs give a strong-scaling curve too.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel (fn_edge_chain_kernel<256, 18>: block 2 of fn, its whole per-edge chain fn/snn_coder.py:355-389
+  roofline      the dominant kernel (fn_edge_chain_kernel<512, 12>: block 3 of fn, its whole per-edge chain fn/snn_coder.py:355-389
                 in one launch), launched alone through its C-ABI entry between two events on the current stream: achieved =
                 issued f16 MFMA TFLOP/s against the 2.5 PFLOP/s dense peak; beside it SURVEY.md 8(d)'s fp32-MFMA model figure,
                 the VALU neuron-loop rate against its measured floor, HBM bytes per launch and per step from the committed
@@ -102,9 +102,9 @@ NEURON_FLOOR_NS_PER_1000 = 1.58       # profiles/micro/lif_rate.hip on MI355X: t
 
 
 def roofline_leg(dev, reps=5):
-    """Time the dominant kernel alone: fn_edge_chain_kernel<256, 18> (csrc/fn_edge_chain.hip) — block 2 of fn, the whole per-edge
-    chain (fn/snn_coder.py:355-389: pe1 -> fc_delta2 -> attn_in -> fc_gamma -> fc_gamma2 -> softmax-aggregate) of one 4096-patch
-    batch in ONE launch — through its C-ABI entry, on the current stream between two events.
+    """Time the dominant kernel alone: fn_edge_chain_kernel<512, 12> (csrc/fn_edge_chain.hip; 40 % of the step's GPU time) — block 3
+    of fn, the whole per-edge chain (fn/snn_coder.py:355-389: pe1 -> fc_delta2 -> attn_in -> fc_gamma -> fc_gamma2 ->
+    softmax-aggregate) of one 4096-patch batch in ONE launch — through its C-ABI entry, on the current stream between two events.
 
     Roofline: the matrix pipe.  achieved = ISSUED f16 MFMA flops (3 split-f16 products per algorithmic MAC: 3 x 3 GEMMs x
     2 r d^2) / launch time against the 2.5 PFLOP/s dense f16 peak; SURVEY.md 8(d)'s model (algorithmic flops against the
@@ -112,7 +112,7 @@ def roofline_leg(dev, reps=5):
     floor of the bare loop) are reported beside it; `traffic` = HBM bytes per launch from the separate --pmc passes."""
     from sapcu_amd import _lib
     lib = _lib.load()
-    d, kk, heads, T = 256, FN_KW["k_values"][1], FN_KW["num_heads"], 4
+    d, kk, heads, T = 512, FN_KW["k_values"][2], FN_KW["num_heads"], 4
     P = B_PER_GPU * M_PTS
     r = P * kk
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -141,7 +141,7 @@ def roofline_leg(dev, reps=5):
     launch()
     torch.cuda.synchronize()
     assert torch.isfinite(res).all()
-    # the entry point also runs five tiny helper kernels (edge records, weight split / pack: ~40 us against ~9 ms)
+    # the entry point also runs seven tiny helper kernels (edge records, weight split / pack: ~60 us against ~18 ms)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()                       # torch's current stream IS the stream the kernels are launched on
     for _ in range(reps):
@@ -156,7 +156,7 @@ def roofline_leg(dev, reps=5):
     recs, src = recorded_pmc()
     traffic, busy, step_traffic = None, None, None
     if recs is not None:
-        rec = recs.get("fn_edge_chain_kernel<256, 18>")
+        rec = recs.get("fn_edge_chain_kernel<512, 12>")
         if rec:
             traffic, busy = float(rec["hbm_bytes_per_launch"]), rec.get("mfma_busy_frac")
         st = recs.get("_step")
@@ -169,7 +169,7 @@ def roofline_leg(dev, reps=5):
     ns_per_1000 = avg_s * 1e9 / (elems / 1000.0)
     return {"bound": "mfma", "achieved": round(issued / avg_s / 1e12, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(issued / avg_s / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
-            "traffic": traffic, "traffic_source": src, "kernel": "fn_edge_chain_kernel<256, 18>",
+            "traffic": traffic, "traffic_source": src, "kernel": "fn_edge_chain_kernel<512, 12>",
             "avg_launch_ms": round(avg_s * 1e3, 4), "launches_timed": reps,
             "flops_per_launch": {"algorithmic": flop, "issued_f16": issued},
             "algorithmic_tflops": round(flop / avg_s / 1e12, 2),
@@ -285,6 +285,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-strong-leg", action="store_true", help="skip the extra whole-cloud pass of the weak mode")
+    ap.add_argument("--no-m100", action="store_true", help="skip the secondary M=100 figure")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -420,8 +421,9 @@ def main():
             line["roofline"] = roofline_leg(dev)
             log("roofline leg done: %s" % line["roofline"])
             line["knn_kernel"] = knn_leg(dev, cloud, seeds)
-            line["m100"] = m100_leg(fn, fd, dev, cloud, seeds)
-            log("M=100 leg: %s" % line["m100"])
+            if not args.no_m100:
+                line["m100"] = m100_leg(fn, fd, dev, cloud, seeds)
+                log("M=100 leg: %s" % line["m100"])
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sdn, sdd)
             log("cpu baseline done: %s" % line["cpu_baseline"])

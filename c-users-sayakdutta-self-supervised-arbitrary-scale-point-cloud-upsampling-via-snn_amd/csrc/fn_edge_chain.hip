@@ -118,28 +118,39 @@ __device__ __forceinline__ void chain_gemm(const unsigned char* X, const half8* 
     for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-#pragma unroll
-    for (int s = 0; s < NK16; ++s) {
-        const unsigned ko = (unsigned)((s >> 1) * CH_KSTEP + ((((s & 1) * 2 + h) ^ sw) * 16));
-        half8 ah[RB], al[RB];
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            ah[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048);
-            al[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048 + CH_PLANE);
-        }
-        const half8 cwh = W.wh[s & (WD - 1)], cwl = W.wl[s & (WD - 1)];
-        if (s + WD < NK16) {                               // WD k16 steps ahead
-            W.wh[s & (WD - 1)] = wp[((s + WD) * 2) * 64 + lane];
-            W.wl[s & (WD - 1)] = wp[((s + WD) * 2 + 1) * 64 + lane];
-        }
-        // per accumulator: a_lo.w_hi, a_hi.w_lo, a_hi.w_hi — the order of gemm_sf16_ring.hip / gemm_sf16_bt.hip
-#pragma unroll
-        for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], cwh, acc[i], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], cwl, acc[i], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], cwh, acc[i], 0, 0, 0);
+    // one k16 step S; SJ = its slot of the weight ring (S % WD, a compile-time value in both loop forms below)
+#define SAPCU_CHAIN_STEP(S, SJ)                                                                                             \
+    {                                                                                                                       \
+        const int s_ = (S);                                                                                                 \
+        const unsigned ko = (unsigned)((s_ >> 1) * CH_KSTEP + ((((s_ & 1) * 2 + h) ^ sw) * 16));                            \
+        half8 ah[RB], al[RB];                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                                                    \
+            ah[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048);                                                    \
+            al[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048 + CH_PLANE);                                         \
+        }                                                                                                                   \
+        const half8 cwh = W.wh[SJ], cwl = W.wl[SJ];                                                                         \
+        if (s_ + WD < NK16) { /* WD k16 steps ahead */                                                                      \
+            W.wh[SJ] = wp[((s_ + WD) * 2) * 64 + lane];                                                                     \
+            W.wl[SJ] = wp[((s_ + WD) * 2 + 1) * 64 + lane];                                                                 \
+        }                                                                                                                   \
+        /* per accumulator: a_lo.w_hi, a_hi.w_lo, a_hi.w_hi — the order of gemm_sf16_ring.hip / gemm_sf16_bt.hip */         \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], cwh, acc[i], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], cwl, acc[i], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], cwh, acc[i], 0, 0, 0); \
     }
+    if constexpr (D <= 256) {                              // 8 / 16 steps: fully unrolled
+#pragma unroll
+        for (int s = 0; s < NK16; ++s) SAPCU_CHAIN_STEP(s, s & (WD - 1))
+    } else {
+        // d = 512: 32 steps at 128 registers per wave — a rolled loop of WD-step bodies keeps the weight ring's indices static
+        // without letting the scheduler hoist 32 steps' worth of operands (fully unrolled: 42 spilled registers, this: 28)
+#pragma unroll 1
+        for (int s0 = 0; s0 < NK16; s0 += WD) {
+#pragma unroll
+            for (int sj = 0; sj < WD; ++sj) SAPCU_CHAIN_STEP(s0 + sj, sj)
+        }
+    }
+#undef SAPCU_CHAIN_STEP
 }
 
 // write v (row = 32 i + 8 q + 4 h + u, k = this lane's column) into the panel as the split-f16 operand of the next GEMM

@@ -13,13 +13,13 @@ tail -3 $R/gpurun_out/gpu_tests.log
 fi
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/trace $R/gpurun_out/pmc_f $R/gpurun_out/pmc_w $R/gpurun_out/pmc_m
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-strong-leg"
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-strong-leg --no-m100"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trace -- $BENCH --steps 3 --warmup 1 > $R/gpurun_out/trace.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_f -- $BENCH --steps 2 --warmup 1 --no-roofline > $R/gpurun_out/pmc_f.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_w -- $BENCH --steps 2 --warmup 1 --no-roofline > $R/gpurun_out/pmc_w.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_m -- $BENCH --steps 2 --warmup 1 --no-roofline > $R/gpurun_out/pmc_m.log 2>&1
 cd $R
-python3 profiles/make_summary.py gpurun_out/trace "$TAG: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strong-leg (1 x MI355X)" gpurun_out/${TAG}_gemm_launches.json > gpurun_out/${TAG}_summary.md
+python3 profiles/make_summary.py gpurun_out/trace "$TAG: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strong-leg --no-m100 (1 x MI355X)" gpurun_out/${TAG}_gemm_launches.json > gpurun_out/${TAG}_summary.md
 python3 profiles/pmc_to_json.py gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/${TAG}_pmc.json gpurun_out/pmc_m 3
 cp gpurun_out/trace/*/*_kernel_stats.csv gpurun_out/${TAG}_kernel_stats.csv
 # keep the merged-back payload small
