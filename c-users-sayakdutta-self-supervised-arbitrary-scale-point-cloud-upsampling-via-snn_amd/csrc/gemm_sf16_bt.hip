@@ -365,7 +365,35 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
         }
         // interior tile and a format the fast path has (wave-uniform): everything the models launch; else the generic path
         const bool interior = tm * TBM + TBM <= g.r;
-        if (interior && EPI == EPI_LIF_ATTN && !g.c_split && g.c2_split) {
+        if (EPI == EPI_LRELU_MAX) {
+            // LeakyReLU, then the max over groups of max_m rows instead of a store (fd/snn_coder.py:476-480).  A lane walks its
+            // column's 64 rows in ascending order and keeps a running maximum per group: one integer atomicMax per (group,
+            // column) and lane half instead of one per value (the maximum does not depend on the order: exact).
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const int col = col0 + j * 32 + r32;
+                int64_t cur = -1, boundary = 0;
+                float best = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int64_t rr = row0 + i * 32 + 8 * (e >> 2) + 4 * h + (e & 3);
+                        if (rr >= g.r) continue;
+                        const float v = lrelu02(__fadd_rn(__fmul_rn(acc[i][j][e], 0.0625f), pbias[j]));
+                        if (rr >= boundary) {                 // first row, or a new group starts
+                            if (cur >= 0) atomicMax(g.max_keys + cur * g.n + col, float_max_key(best));
+                            cur = rr / g.max_m;
+                            boundary = (cur + 1) * g.max_m;
+                            best = v;
+                        } else {
+                            best = fmaxf(best, v);
+                        }
+                    }
+                }
+                if (cur >= 0) atomicMax(g.max_keys + cur * g.n + col, float_max_key(best));
+            }
+        } else if (interior && EPI == EPI_LIF_ATTN && !g.c_split && g.c2_split) {
             bt_epilogue_fast<EPI, CT, false, true>(g, acc, row0, col0, r32, h, pbias, pnp);
         } else if (interior && EPI == EPI_LIF && g.c_split) {
             bt_epilogue_fast<EPI, CT, true, false>(g, acc, row0, col0, r32, h, pbias, pnp);
@@ -443,6 +471,7 @@ bool gemm_sf16_bt_ok(const GemmArgs& g) {
     if (g.ldc % 4 || !al16(g.c) || (g.bias && !al16(g.bias))) return false;
     if ((g.epi == EPI_LIF || g.epi == EPI_LIF_ATTN) && !al16(g.lif)) return false;
     if (g.epi == EPI_LIF_ATTN && (g.ldq % 4 || !al16(g.q) || !al16(g.kf) || !al16(g.c2))) return false;
+    if (g.epi == EPI_LRELU_MAX) return g.max_keys != nullptr && g.max_m >= 1;
     return g.epi == EPI_BIAS || g.epi == EPI_LIF || g.epi == EPI_LIF_ATTN;
 }
 
@@ -453,6 +482,7 @@ int launch_gemm_sf16_bt(const GemmArgs& g, hipStream_t st) {
     if (g.epi == EPI_LIF_ATTN) SAPCU_CHECK_ARG(g.ldq > 0 && g.tab && g.q && g.kf && g.c2, "gemm_bt: bad attn operands");
     const bool wide = g.n % 256 == 0;
     switch (g.epi) {
+        case EPI_LRELU_MAX: return wide ? launch_bt_t<EPI_LRELU_MAX, 256>(g, st) : launch_bt_t<EPI_LRELU_MAX, 128>(g, st);
         case EPI_BIAS: return wide ? launch_bt_t<EPI_BIAS, 256>(g, st) : launch_bt_t<EPI_BIAS, 128>(g, st);
         case EPI_LIF: return wide ? launch_bt_t<EPI_LIF, 256>(g, st) : launch_bt_t<EPI_LIF, 128>(g, st);
         default: return wide ? launch_bt_t<EPI_LIF_ATTN, 256>(g, st) : launch_bt_t<EPI_LIF_ATTN, 128>(g, st);

@@ -397,7 +397,7 @@ static FdPlan fd_plan(const sapcu_model* m, int64_t b, int mp) {
     // fd intermediates: T x (960 spikes + emb aggregate) + 1024 + block-0 features per point, neighbour tables
     int kmax0 = 1;
     for (int i = 0; i < m->nscale; ++i) kmax0 = kmax0 > m->ks[i] ? kmax0 : m->ks[i];
-    const int64_t per_patch = (int64_t)mp * (((int64_t)m->T * (960 + m->emb) + 1024 + 64 * (m->nscale + 1)) * 4 +
+    const int64_t per_patch = (int64_t)mp * (((int64_t)m->T * (960 + m->emb) + 960 + 1024 + 64 * (m->nscale + 1)) * 4 +
                                             (int64_t)(imin(kmax0, mp) + 3 * imin(m->k, mp)) * 4) +
                               ((int64_t)(m->T + 1) * m->emb + 256 + 3 * 128 + 3 * 64 + 192 + 64) * 4;
     pl.cb = chunk_patches(m, b, per_patch);
@@ -415,7 +415,7 @@ static int64_t fd_ws_bytes(const sapcu_model* m, int64_t b, int mp) {
     auto add = [&](int64_t n, int64_t esz) { fl += ((n * esz) + 255) & ~(int64_t)255; };
     add(P * pl.kmax0, 4); add(3 * P * pl.kk, 4);
     add(P * 64 * m->nscale, 4); add(P * 64, 4);
-    add((int64_t)m->T * P * 960, 4); add(P * 1024, 4); add((int64_t)m->T * P * m->emb, 4);
+    add((int64_t)m->T * P * 960, 4); add(P * 960, 4); add(P * 1024, 4); add((int64_t)m->T * P * m->emb, 4);
     add((int64_t)m->T * pl.cb * m->emb, 4); add(pl.cb * m->emb, 4);
     add(pl.cb * 256, 4);
     for (int i = 0; i < 3; ++i) add(pl.cb * 128, 4);
@@ -442,6 +442,7 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
         float* E0 = A.take<float>(pl.cb * mp * 64 * m->nscale);
         float* FUSED = A.take<float>(pl.cb * mp * 64);
         float* SPK = A.take<float>((int64_t)T * pl.cb * mp * 960);
+        float* F0 = A.take<float>(pl.cb * mp * 960);
         float* AB = A.take<float>(pl.cb * mp * 1024);
         float* AGG = A.take<float>((int64_t)T * pl.cb * mp * emb);
         float* POOLED = A.take<float>((int64_t)T * pl.cb * emb);
@@ -464,12 +465,33 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
         SAPCU_TRY(gemm(m, E0, P, 64 * m->nscale, 64 * m->nscale, m->p(FD_FUSE_W), 64, m->p(FD_FUSE_B), FUSED, 64,
                        EPI_LRELU, st));
         SAPCU_TRY(tap_copy(taps, SAPCU_FD_TAP_FUSED0, s * mp * 64 * 4, FUSED, P * 64 * 4, st));
-        SAPCU_TRY(launch_fd_neuron(true, 0, FUSED, 64, nullptr, 0, mp, nullptr, P, 64, m->p(FD_SNN0), T, SPK, 960, 0,
-                                   nullptr, m->gate_dev, st));
+        // multi_scale_conv's operand: split rows written by the neuron kernels themselves (the GEMM then streams them by LDS-DMA
+        // on the big-tile kernel and takes the max over the points in its epilogue) whenever that kernel takes the shape; the
+        // step-0 spikes also go to F0 as f32 for the next blocks' neighbour search and EdgeConv.  Otherwise (tiny batches,
+        // SAPCU_GEMM=f32, SAPCU_FD_MAXFUSE=0 / SAPCU_FD_SPLIT=0, or a caller asking for the spike tap): f32 spikes for all steps.
+        GemmArgs mg;
+        memset(&mg, 0, sizeof(mg));
+        mg.a = SPK; mg.r = (int64_t)T * P; mg.k = 960; mg.lda = 960; mg.w = m->p(FD_MSC_W); mg.n = emb; mg.bias = m->p(FD_MSC_B);
+        mg.c = nullptr; mg.ldc = emb; mg.epi = EPI_LRELU_MAX; mg.max_keys = reinterpret_cast<unsigned*>(AGG); mg.max_m = mp;
+        const char* mxe = getenv("SAPCU_FD_MAXFUSE");        // read per call: the parity tests flip these inside one process
+        const char* spe = getenv("SAPCU_FD_SPLIT");
+        const bool maxfuse = m->sf16 && !(mxe && strcmp(mxe, "0") == 0);
+        bool split_spikes = false;
+        if (maxfuse && !(spe && strcmp(spe, "0") == 0) && !(taps && taps[SAPCU_FD_TAP_SPIKES])) {
+            GemmArgs probe = mg;
+            probe.a_split = 1;
+            probe.w16_hi = (const _Float16*)m->w16_hi + (mg.w - m->blob);
+            probe.w16_lo = (const _Float16*)m->w16_lo + (mg.w - m->blob);
+            split_spikes = gemm_sf16_bt_ok(probe);
+        }
+        float* const SPKS = split_spikes ? SPK : nullptr;       // [T*P, 960] split rows (same buffer, other format)
+        float* const SPK0 = split_spikes ? F0 : SPK;            // where the step-0 f32 spikes live ([P, 960] slab)
+        SAPCU_TRY(launch_fd_neuron(true, 0, FUSED, 64, nullptr, 0, mp, nullptr, P, 64, m->p(FD_SNN0), T, SPK0, 960, 0,
+                                   nullptr, m->gate_dev, st, SPKS));
         // blocks 1..3: feature-space kNN on the t=0 spikes, factored EdgeConv, neuron  fd:447-474
         for (int l = 1; l <= 3; ++l) {
             int32_t* idl = idxb + (int64_t)(l - 1) * pl.cb * mp * pl.kk;
-            const float* F = SPK + coff[l - 1];   // t = 0 slab, row stride 960
+            const float* F = SPK0 + coff[l - 1];   // t = 0 slab, row stride 960
             if (knn_force) {
                 SAPCU_CHECK_HIP(hipMemcpyAsync(idl, knn_force + ((int64_t)(l - 1) * b + s) * mp * pl.kk, P * pl.kk * 4,
                                                hipMemcpyDeviceToDevice, st));
@@ -482,7 +504,7 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
             const int ew = FD_EDGE1_W + 3 * (l - 1);
             SAPCU_TRY(gemm(m, F, P, cin[l], 960, m->p(ew), 2 * cout[l], nullptr, AB, 2 * cout[l], EPI_BIAS, st));
             SAPCU_TRY(launch_fd_neuron(l == 1, 1, AB, 2 * cout[l], idl, pl.kk, mp, m->p(ew + 1), P, cout[l], m->p(ew + 2),
-                                       T, SPK, 960, coff[l], nullptr, m->gate_dev, st));
+                                       T, SPK0, 960, coff[l], nullptr, m->gate_dev, st, SPKS));
         }
         if (taps && taps[SAPCU_FD_TAP_SPIKES]) {
             for (int t = 0; t < T; ++t)
@@ -490,18 +512,13 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
                                                SPK + (int64_t)t * P * 960, P * 960 * 4, hipMemcpyDeviceToDevice, st));
         }
         // multi_scale_conv + BN + LeakyReLU over all T*P rows, max over points        fd:476-480
-        const char* mxe = getenv("SAPCU_FD_MAXFUSE");        // read per call: the parity test flips it inside one process
-        if (m->sf16 && !(mxe && strcmp(mxe, "0") == 0)) {
+        if (maxfuse) {
             // the max over the patch's points inside the GEMM's epilogue (integer atomicMax on order-preserving keys): the
-            // [T*P, emb] aggregate is never written.  The key buffer is the head of the (now unused) AGG area.
-            unsigned* keys = reinterpret_cast<unsigned*>(AGG);
-            SAPCU_CHECK_HIP(hipMemsetAsync(keys, 0, (size_t)T * cb * emb * 4, st));
-            GemmArgs g;
-            memset(&g, 0, sizeof(g));
-            g.a = SPK; g.r = (int64_t)T * P; g.k = 960; g.lda = 960; g.w = m->p(FD_MSC_W); g.n = emb; g.bias = m->p(FD_MSC_B);
-            g.c = nullptr; g.ldc = emb; g.epi = EPI_LRELU_MAX; g.max_keys = keys; g.max_m = mp;
-            SAPCU_TRY(run_gemm(m, g, st));
-            SAPCU_TRY(launch_decode_max_keys(keys, (int64_t)T * cb * emb, POOLED, st));
+            // [T*P, emb] aggregate is never written.  The key buffer is the head of the (otherwise unused) AGG area.
+            SAPCU_CHECK_HIP(hipMemsetAsync(mg.max_keys, 0, (size_t)T * cb * emb * 4, st));
+            mg.a_split = split_spikes ? 1 : 0;
+            SAPCU_TRY(run_gemm(m, mg, st));
+            SAPCU_TRY(launch_decode_max_keys(mg.max_keys, (int64_t)T * cb * emb, POOLED, st));
         } else {
             SAPCU_TRY(gemm(m, SPK, (int64_t)T * P, 960, 960, m->p(FD_MSC_W), emb, m->p(FD_MSC_B), AGG, emb, EPI_LRELU, st));
             SAPCU_TRY(launch_rowgroup_max(AGG, (int64_t)T * cb, mp, emb, POOLED, st));

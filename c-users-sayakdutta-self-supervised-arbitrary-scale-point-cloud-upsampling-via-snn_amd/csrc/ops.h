@@ -57,7 +57,7 @@ int launch_fd_edge0(const float* patch, const int32_t* idx, int kmax, int64_t pt
                     const int32_t* ks_dev, const float* w, const float* bias, float* out, hipStream_t st);
 int launch_fd_neuron(bool eif, int mode, const float* in, int ldi, const int32_t* idx, int kk, int m,
                      const float* shift, int64_t pts, int C, const float* prm, int T, float* spk, int ldo, int coff,
-                     float* pre_out, int* gate_violations, hipStream_t st);
+                     float* pre_out, int* gate_violations, hipStream_t st, float* spk_split = nullptr);   // spk_split: see fd_neuron_kernel
 int launch_fd_temporal(const float* pooled, int T, int64_t b, int emb, const float* tw, const float* lif, float* out,
                        hipStream_t st);
 int launch_fd_tail(const float* x, const float* qkv, int64_t b, int heads, const float* wo_t, const float* bo,

@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256) void fd_neuron_kernel(const float* __restrict_
                                                         const float* __restrict__ shift, int64_t pts, int C,
                                                         const float* __restrict__ prm, int T, float* __restrict__ spk,
                                                         int ldo, int coff, float* __restrict__ pre_out,
-                                                        int* __restrict__ gate_violations) {
+                                                        int* __restrict__ gate_violations, float* __restrict__ spk_split) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= pts * C) return;
     const int c = (int)(t % C);
@@ -748,7 +748,14 @@ __global__ __launch_bounds__(256) void fd_neuron_kernel(const float* __restrict_
         if (step == 0) x = pre;
         else if (s.r <= 0.f) atomicAdd(gate_violations, 1);
         const float sp = neuron_step<EIF>(x, s, p);
-        spk[((int64_t)step * pts + row) * ldo + coff + c] = sp;
+        // spk_split: every step as split rows (the operand of the multi_scale_conv GEMM), f32 only for step 0 (the features
+        // the next blocks' neighbour search and EdgeConv read) — spk is then the [pts, ldo] slab of step 0 alone
+        if (spk_split) {
+            store_split(spk_split, (int64_t)step * pts + row, ldo, coff + c, sp);
+            if (step == 0) spk[row * ldo + coff + c] = sp;
+        } else {
+            spk[((int64_t)step * pts + row) * ldo + coff + c] = sp;
+        }
     }
 }
 
@@ -763,7 +770,7 @@ __global__ __launch_bounds__(FDE_CH) void fd_edge_neuron_kernel(const float* __r
                                                                 const float* __restrict__ shift, int64_t pts, int C,
                                                                 const float* __restrict__ prm, int T,
                                                                 float* __restrict__ spk, int ldo, int coff,
-                                                                int* __restrict__ gate_violations) {
+                                                                int* __restrict__ gate_violations, float* __restrict__ spk_split) {
     extern __shared__ float sA[];                       // [m][FDE_CH]
     const int tx = threadIdx.x;
     const int c = blockIdx.y * FDE_CH + tx;
@@ -791,32 +798,41 @@ __global__ __launch_bounds__(FDE_CH) void fd_edge_neuron_kernel(const float* __r
         for (int step = 0; step < T; ++step) {
             if (step > 0 && ns.gate_open()) atomicAdd(gate_violations, 1);
             const f32x2 sp = ns.step(step == 0 ? pre : f32x2{0.f, 0.f}, step == 0);
-            spk[((int64_t)step * pts + ra) * ldo + coff + c] = sp.x;
-            if (i1 != i) spk[((int64_t)step * pts + rb) * ldo + coff + c] = sp.y;
+            if (spk_split) {                             // (see fd_neuron_kernel)
+                store_split(spk_split, (int64_t)step * pts + ra, ldo, coff + c, sp.x);
+                if (i1 != i) store_split(spk_split, (int64_t)step * pts + rb, ldo, coff + c, sp.y);
+                if (step == 0) {
+                    spk[ra * ldo + coff + c] = sp.x;
+                    if (i1 != i) spk[rb * ldo + coff + c] = sp.y;
+                }
+            } else {
+                spk[((int64_t)step * pts + ra) * ldo + coff + c] = sp.x;
+                if (i1 != i) spk[((int64_t)step * pts + rb) * ldo + coff + c] = sp.y;
+            }
         }
     }
 }
 
 int launch_fd_neuron(bool eif, int mode, const float* in, int ldi, const int32_t* idx, int kk, int m,
                      const float* shift, int64_t pts, int C, const float* prm, int T, float* spk, int ldo, int coff,
-                     float* pre_out, int* gate_violations, hipStream_t st) {
+                     float* pre_out, int* gate_violations, hipStream_t st, float* spk_split) {
     if (pts == 0) return SAPCU_OK;
     if (mode == 1 && pre_out == nullptr && pts % m == 0) {
         const dim3 g2((unsigned)(pts / m), (unsigned)((C + FDE_CH - 1) / FDE_CH));
         const size_t lds = (size_t)m * FDE_CH * sizeof(float);
         if (eif)
             hipLaunchKernelGGL(fd_edge_neuron_kernel<true>, g2, dim3(FDE_CH), lds, st, in, ldi, idx, kk, m, shift, pts, C, prm,
-                               T, spk, ldo, coff, gate_violations);
+                               T, spk, ldo, coff, gate_violations, spk_split);
         else
             hipLaunchKernelGGL(fd_edge_neuron_kernel<false>, g2, dim3(FDE_CH), lds, st, in, ldi, idx, kk, m, shift, pts, C,
-                               prm, T, spk, ldo, coff, gate_violations);
+                               prm, T, spk, ldo, coff, gate_violations, spk_split);
         SAPCU_CHECK_LAUNCH();
         return SAPCU_OK;
     }
     const dim3 grid((unsigned)((pts * C + 255) / 256)), blk(256);
 #define SAPCU_FDN(E, M)                                                                                            \
     hipLaunchKernelGGL((fd_neuron_kernel<E, M>), grid, blk, 0, st, in, ldi, idx, kk, m, shift, pts, C, prm, T, spk, \
-                       ldo, coff, pre_out, gate_violations)
+                       ldo, coff, pre_out, gate_violations, spk_split)
     if (eif && mode == 0) SAPCU_FDN(true, 0);
     else if (eif) SAPCU_FDN(true, 1);
     else if (mode == 0) SAPCU_FDN(false, 0);

@@ -1330,28 +1330,33 @@ def test_fused_edge_chain_equals_the_unfused_chain_bit_for_bit(weights, monkeypa
 
 
 def test_fd_max_over_points_fused_into_the_gemm_is_bit_identical(weights, monkeypatch):
-    """fd's multi_scale_conv GEMM with the max over the patch's points in its epilogue (integer atomicMax on order-preserving
-    keys, EPI_LRELU_MAX: the [T*P, 768] aggregate is never written) against the GEMM + rowgroup_max pair (SAPCU_FD_MAXFUSE=0,
-    read per launch): identical pooled features, encodings and distances, for full patches, M = 100 and M = 5 (groups that do
-    not align with the 4-row register groups of the epilogue)."""
+    """fd's multi_scale_conv in its three forms: (default) the neuron kernels write the spikes as split rows, the big-tile GEMM
+    streams them by LDS-DMA and takes the max over the patch's points in its epilogue (integer atomicMax on order-preserving keys:
+    the [T*P, 768] aggregate is never written); SAPCU_FD_SPLIT=0: f32 spikes, the f32-A GEMM with the same epilogue;
+    SAPCU_FD_MAXFUSE=0: GEMM + rowgroup_max.  Identical pooled features, encodings and distances, for full patches, M = 100,
+    M = 5 (groups that do not align with the 4-row register groups) and batches too small for the big-tile kernel."""
     _, fd, _, _ = U.build_gpu_models(weights)
-    for nq, mpts in ((40, 48), (7, 100), (5, 5), (1, 48)):
+    for nq, mpts in ((40, 48), (7, 100), (70, 5), (5, 5), (1, 48)):
         patch = U.sphere_patches(nq, mpts, skip=1500).to(U.dev())
         kk = min(32, mpts)
         knn = torch.empty((3, nq, mpts, kk), dtype=torch.int32, device=U.dev())
         outs = []
-        for fuse in ("1", "0"):
-            monkeypatch.setenv("SAPCU_FD_MAXFUSE", fuse)
+        for env in ({}, {"SAPCU_FD_SPLIT": "0"}, {"SAPCU_FD_MAXFUSE": "0"}):
+            monkeypatch.delenv("SAPCU_FD_SPLIT", raising=False)
+            monkeypatch.delenv("SAPCU_FD_MAXFUSE", raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
             taps = {"pooled": torch.full((4, nq, 768), float("nan"), device=U.dev()), "enc": torch.full((nq, 768), float("nan"), device=U.dev())}
-            if fuse == "1":
+            if not outs:
                 taps["knn"] = knn
                 d = fd(patch, taps=taps)
             else:
-                d = fd(patch, taps=taps, knn_force=knn)          # same neighbour tables for both runs
+                d = fd(patch, taps=taps, knn_force=knn)          # same neighbour tables for all runs
             torch.cuda.synchronize()
             outs.append((d, taps["pooled"], taps["enc"]))
         assert not bool(torch.isnan(outs[0][1]).any())
-        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[1][0]), (nq, mpts)
+        for o in outs[1:]:
+            assert torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][2], o[2]) and torch.equal(outs[0][0], o[0]), (nq, mpts)
     assert fd.gate_violations() == 0
 
 
