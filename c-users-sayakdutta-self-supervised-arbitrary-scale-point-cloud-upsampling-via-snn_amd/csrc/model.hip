@@ -114,10 +114,13 @@ static inline int imin(int a, int b) { return a < b ? a : b; }
 
 // GEMM on split rows: the big-tile kernel for the shapes it takes (SAPCU_BT=0 keeps everything on the ring kernel; the two
 // are bit-identical), else the 128x128 ring kernel.
-int launch_gemm_split_rows(const GemmArgs& g, hipStream_t st) {
+static bool split_rows_gemm_on_big_tile(const GemmArgs& g) {
     const char* e = getenv("SAPCU_BT");                 // read per call: the parity test flips it inside one process
-    const bool use_bt = !(e && strcmp(e, "0") == 0);
-    if (use_bt && gemm_sf16_bt_ok(g)) return launch_gemm_sf16_bt(g, st);
+    return !(e && strcmp(e, "0") == 0) && gemm_sf16_bt_ok(g);
+}
+
+int launch_gemm_split_rows(const GemmArgs& g, hipStream_t st) {
+    if (split_rows_gemm_on_big_tile(g)) return launch_gemm_sf16_bt(g, st);
     return launch_gemm_sf16_ring(g, st);
 }
 
@@ -482,7 +485,7 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
             probe.a_split = 1;
             probe.w16_hi = (const _Float16*)m->w16_hi + (mg.w - m->blob);
             probe.w16_lo = (const _Float16*)m->w16_lo + (mg.w - m->blob);
-            split_spikes = gemm_sf16_bt_ok(probe);
+            split_spikes = split_rows_gemm_on_big_tile(probe);     // (the ring kernel has no max-over-rows epilogue)
         }
         float* const SPKS = split_spikes ? SPK : nullptr;       // [T*P, 960] split rows (same buffer, other format)
         float* const SPK0 = split_spikes ? F0 : SPK;            // where the step-0 f32 spikes live ([P, 960] slab)
