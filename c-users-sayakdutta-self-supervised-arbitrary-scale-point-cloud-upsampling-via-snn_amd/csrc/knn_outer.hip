@@ -65,9 +65,11 @@ __global__ __launch_bounds__(256) void knn_outer_kernel(const double* __restrict
     for (int64_t base = 0; base < n; base += KNN_TILE) {
         const int cnt = (int)((n - base) < KNN_TILE ? (n - base) : KNN_TILE);
         __syncthreads();
-        for (int e = threadIdx.x; e < cnt * 3; e += 256) {
-            const double v = cloud[base * 3 + e];
-            tile[e % 3][e / 3] = v;
+        for (int pt = threadIdx.x; pt < cnt; pt += 256) {      // one point per thread and pass (no index arithmetic per element)
+            const double* c3 = cloud + (base + pt) * 3;
+            tile[0][pt] = c3[0];
+            tile[1][pt] = c3[1];
+            tile[2][pt] = c3[2];
         }
         __syncthreads();
         if (!active) continue;
