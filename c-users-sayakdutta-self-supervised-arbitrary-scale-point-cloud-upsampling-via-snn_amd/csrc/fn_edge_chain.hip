@@ -33,18 +33,23 @@
 namespace sapcu {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-// MFMA rows per group: 128 for d = 128 / 256; 64 for d = 512 (a 128-row panel of 512 columns would be 256 KiB).
-// One plane of one k32 step is [ROWS][32 halves]; a k32 step = hi plane | lo plane.
+// Shape of a workgroup's work.  ROWS = MFMA rows per group: 128 for d = 128 / 256; 64 for d = 512 (a 128-row panel of 512 columns
+// would be 256 KiB).  One plane of one k32 step is [ROWS][32 halves]; a k32 step = hi plane | lo plane.  A wave owns CB column
+// blocks of 32 and all ROWS rows: RB x CB accumulator blocks.  CB = 1 everywhere: d = 128: two 4-wave workgroups per CU and
+// d = 256: one 8-wave workgroup, 256 registers per wave; d = 512: 16 waves of 128 registers (epilogue units of 4 elements,
+// weights 2 k16 steps ahead).  Measured at d = 512: CB = 2 (8 waves of 256 registers, wave tile 64 x 64) 18.4 ms against
+// 17.6 ms for CB = 1 — the extra waves hide more latency than the larger wave tile saves in LDS reads.
 template <int D> struct ChainShape {
     static constexpr int ROWS = D <= 256 ? 128 : 64;
     static constexpr int RB = ROWS / 32;              // 32-row MFMA blocks per wave tile
+    static constexpr int CB = 1;                      // 32-column blocks per wave
+    static constexpr int NB = RB * CB;                // accumulator blocks per wave (block b: rows i = b / CB, columns j = b % CB)
+    static constexpr int NW = D / (32 * CB);          // waves per workgroup
     static constexpr int PLANE = ROWS * 64;
     static constexpr int KSTEP = 2 * PLANE;
     static constexpr int LDS = ROWS * D * 4 + ROWS * 16 + ROWS * 8;
-    // register budget: 256 per wave at d <= 256 (2 waves per SIMD), 128 at d = 512 (16 waves per workgroup): epilogue
-    // units of 8 / 4 elements per lane, weight fragments 4 / 2 k16 steps ahead
-    static constexpr int US = D <= 256 ? 8 : 4;
-    static constexpr int WD = D <= 256 ? 4 : 2;
+    static constexpr int US = D <= 256 ? 8 : 4;       // elements per lane of one epilogue unit
+    static constexpr int WD = D <= 256 ? 4 : 2;       // weight fragments this many k16 steps ahead (x CB column blocks x hi, lo)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -86,64 +91,82 @@ __device__ __forceinline__ float half_bcast(float x, int hr) {
     return __uint_as_float(hr ? r[1] : r[0]);
 }
 
+template <int CB>
 struct ChainLane {       // per-lane constants of the epilogues
-    int r32, h, col;
-    unsigned xw[2];      // LDS byte offset of (row 4h + .., this lane's column as k) for rows with ((row>>3)&1) = 0 / 1
+    int r32, h;
+    int col[CB];         // this lane's column of column block j
+    unsigned xw[CB][2];  // LDS byte offset of (row 4h + .., column col[j] as k) for rows with ((row>>3)&1) = 0 / 1
 };
 
-template <int WD>
-struct ChainW {           // weight fragments of WD k16 steps (hi, lo)
-    half8 wh[WD], wl[WD];
+template <int WD, int CB>
+struct ChainW {           // weight fragments of WD k16 steps x CB column blocks (hi, lo)
+    half8 wh[WD][CB], wl[WD][CB];
 };
+
+// fragment (column block cb, k16 step s, plane) of a packed matrix: [(cb * NK16 + s) * 2 + plane][64 lanes]
+template <int D>
+__device__ __forceinline__ half8 chain_w_frag(const half8* __restrict__ wp, int cb, int s, int plane, int lane) {
+    return wp[(((int64_t)cb * (D / 16) + s) * 2 + plane) * 64 + lane];
+}
 
 // first WD k16 steps of a GEMM's weight stream: issued well before the GEMM so that their L2 latency is covered
-template <int WD>
-__device__ __forceinline__ void chain_w_prefetch(const half8* __restrict__ wp, int lane, ChainW<WD>& W) {
+template <int D>
+__device__ __forceinline__ void chain_w_prefetch(const half8* __restrict__ wp, int cb0, int lane,
+                                                 ChainW<ChainShape<D>::WD, ChainShape<D>::CB>& W) {
 #pragma unroll
-    for (int s = 0; s < WD; ++s) {
-        W.wh[s] = wp[(s * 2) * 64 + lane];
-        W.wl[s] = wp[(s * 2 + 1) * 64 + lane];
-    }
+    for (int s = 0; s < ChainShape<D>::WD; ++s)
+#pragma unroll
+        for (int j = 0; j < ChainShape<D>::CB; ++j) {
+            W.wh[s][j] = chain_w_frag<D>(wp, cb0 + j, s, 0, lane);
+            W.wl[s][j] = chain_w_frag<D>(wp, cb0 + j, s, 1, lane);
+        }
 }
 
 template <int D>
-__device__ __forceinline__ void chain_gemm(const unsigned char* X, const half8* __restrict__ wp, int lane, ChainW<ChainShape<D>::WD>& W,
-                                           f32x16 (&acc)[ChainShape<D>::RB]) {
+__device__ __forceinline__ void chain_gemm(const unsigned char* X, const half8* __restrict__ wp, int cb0, int lane,
+                                           ChainW<ChainShape<D>::WD, ChainShape<D>::CB>& W, f32x16 (&acc)[ChainShape<D>::NB]) {
     constexpr int NK16 = D / 16, WD = ChainShape<D>::WD;
-    constexpr int RB = ChainShape<D>::RB, CH_PLANE = ChainShape<D>::PLANE, CH_KSTEP = ChainShape<D>::KSTEP;
+    constexpr int RB = ChainShape<D>::RB, CB = ChainShape<D>::CB, NB = ChainShape<D>::NB;
+    constexpr int CH_PLANE = ChainShape<D>::PLANE, CH_KSTEP = ChainShape<D>::KSTEP;
     const int r32 = lane & 31, h = lane >> 5;
     const int sw = (r32 >> 2) & 3;                         // (row >> 2) & 3 of rows 32 i + r32
     const unsigned char* xa = X + r32 * 64;
 #pragma unroll
-    for (int i = 0; i < RB; ++i)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
     // one k16 step S; SJ = its slot of the weight ring (S % WD, a compile-time value in both loop forms below)
 #define SAPCU_CHAIN_STEP(S, SJ)                                                                                             \
     {                                                                                                                       \
         const int s_ = (S);                                                                                                 \
         const unsigned ko = (unsigned)((s_ >> 1) * CH_KSTEP + ((((s_ & 1) * 2 + h) ^ sw) * 16));                            \
-        half8 ah[RB], al[RB];                                                                                               \
+        half8 ah[RB], al[RB], cwh[CB], cwl[CB];                                                                             \
         _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                                                    \
             ah[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048);                                                    \
             al[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048 + CH_PLANE);                                         \
         }                                                                                                                   \
-        const half8 cwh = W.wh[SJ], cwl = W.wl[SJ];                                                                         \
-        if (s_ + WD < NK16) { /* WD k16 steps ahead */                                                                      \
-            W.wh[SJ] = wp[((s_ + WD) * 2) * 64 + lane];                                                                     \
-            W.wl[SJ] = wp[((s_ + WD) * 2 + 1) * 64 + lane];                                                                 \
+        _Pragma("unroll") for (int j = 0; j < CB; ++j) {                                                                    \
+            cwh[j] = W.wh[SJ][j];                                                                                           \
+            cwl[j] = W.wl[SJ][j];                                                                                           \
+            if (s_ + WD < NK16) { /* WD k16 steps ahead */                                                                  \
+                W.wh[SJ][j] = chain_w_frag<D>(wp, cb0 + j, s_ + WD, 0, lane);                                               \
+                W.wl[SJ][j] = chain_w_frag<D>(wp, cb0 + j, s_ + WD, 1, lane);                                               \
+            }                                                                                                               \
         }                                                                                                                   \
         /* per accumulator: a_lo.w_hi, a_hi.w_lo, a_hi.w_hi — the order of gemm_sf16_ring.hip / gemm_sf16_bt.hip */         \
-        _Pragma("unroll") for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], cwh, acc[i], 0, 0, 0); \
-        _Pragma("unroll") for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], cwl, acc[i], 0, 0, 0); \
-        _Pragma("unroll") for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], cwh, acc[i], 0, 0, 0); \
+        _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                                      \
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b / CB], cwh[b % CB], acc[b], 0, 0, 0);                      \
+        _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                                      \
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / CB], cwl[b % CB], acc[b], 0, 0, 0);                      \
+        _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                                      \
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / CB], cwh[b % CB], acc[b], 0, 0, 0);                      \
     }
     if constexpr (D <= 256) {                              // 8 / 16 steps: fully unrolled
 #pragma unroll
         for (int s = 0; s < NK16; ++s) SAPCU_CHAIN_STEP(s, s & (WD - 1))
     } else {
-        // d = 512: 32 steps at 128 registers per wave — a rolled loop of WD-step bodies keeps the weight ring's indices static
-        // without letting the scheduler hoist 32 steps' worth of operands (fully unrolled: 42 spilled registers, this: 28)
+        // d = 512: 32 steps — a rolled loop of WD-step bodies keeps the weight ring's indices static without letting the
+        // scheduler hoist 32 steps' worth of operands
 #pragma unroll 1
         for (int s0 = 0; s0 < NK16; s0 += WD) {
 #pragma unroll
@@ -154,9 +177,9 @@ __device__ __forceinline__ void chain_gemm(const unsigned char* X, const half8* 
 }
 
 // write v (row = 32 i + 8 q + 4 h + u, k = this lane's column) into the panel as the split-f16 operand of the next GEMM
-template <int PLANE>
-__device__ __forceinline__ void chain_put(unsigned char* X, const ChainLane& L, int i, int q, int u, float v) {
-    unsigned char* p = X + L.xw[q & 1] + (unsigned)(i * 2048 + q * 512 + u * 64);
+template <int PLANE, int CB>
+__device__ __forceinline__ void chain_put(unsigned char* X, const ChainLane<CB>& L, int j, int i, int q, int u, float v) {
+    unsigned char* p = X + L.xw[j][q & 1] + (unsigned)(i * 2048 + q * 512 + u * 64);
     const _Float16 hi = (_Float16)v;
     *reinterpret_cast<_Float16*>(p) = hi;
     *reinterpret_cast<_Float16*>(p + PLANE) = (_Float16)(v - (float)hi);
@@ -173,12 +196,14 @@ __device__ __forceinline__ NeuronP chain_lif(const float* __restrict__ lif, int 
     return np;
 }
 
-// threads = 2 d (one wave per 32 columns).  d = 128: two 256-thread workgroups per CU (<= 256 registers per wave)
+// threads = 64 x (d / 32 / CB).  d = 128: two 256-thread workgroups per CU
 template <int D, int KK>
-__global__ __launch_bounds__(D * 2, (D == 128 ? 2 : 1)) void fn_edge_chain_kernel(const ChainArgs a) {
-    constexpr int CH_ROWS = ChainShape<D>::ROWS, RB = ChainShape<D>::RB, CH_PLANE = ChainShape<D>::PLANE, CH_KSTEP = ChainShape<D>::KSTEP;
+__global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? 2 : 1)) void fn_edge_chain_kernel(const ChainArgs a) {
+    using S = ChainShape<D>;
+    constexpr int CH_ROWS = S::ROWS, RB = S::RB, CB = S::CB, NB = S::NB, CH_PLANE = S::PLANE, CH_KSTEP = S::KSTEP;
     constexpr int PPG = CH_ROWS / KK;                      // points per group
-    constexpr int US = ChainShape<D>::US, UPB = 16 / US;   // elements per epilogue unit, units per 32-row block
+    constexpr int US = S::US, UPB = 16 / US;               // elements per epilogue unit, units per accumulator block
+    constexpr int NU = NB * UPB;                           // units per wave; unit u: block u / UPB, elements US (u % UPB) .. + US - 1
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* X = smem;
     float4* pdl = reinterpret_cast<float4*>(smem + CH_ROWS * D * 4);
@@ -187,14 +212,20 @@ __global__ __launch_bounds__(D * 2, (D == 128 ? 2 : 1)) void fn_edge_chain_kerne
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    ChainLane L;
+    const int cb0 = w * CB;                                // first column block of this wave
+    ChainLane<CB> L;
     L.r32 = lane & 31;
     L.h = lane >> 5;
-    L.col = 32 * w + L.r32;
-    // element (row, k = col): k32 step = w, chunk = r32 >> 3, half = r32 & 7; (row >> 2) & 3 = (2 q + h) & 3
+    // element (row, k = col): k32 step = column block, chunk = r32 >> 3, half = r32 & 7; (row >> 2) & 3 = (2 q + h) & 3
 #pragma unroll
-    for (int qo = 0; qo < 2; ++qo)
-        L.xw[qo] = (unsigned)(w * CH_KSTEP + L.h * 256 + (((L.r32 >> 3) ^ ((2 * qo + L.h) & 3)) * 16) + (L.r32 & 7) * 2);
+    for (int j = 0; j < CB; ++j) {
+        L.col[j] = 32 * (cb0 + j) + L.r32;
+#pragma unroll
+        for (int qo = 0; qo < 2; ++qo)
+            L.xw[j][qo] = (unsigned)((cb0 + j) * CH_KSTEP + L.h * 256 + (((L.r32 >> 3) ^ ((2 * qo + L.h) & 3)) * 16) + (L.r32 & 7) * 2);
+    }
+    // row of element e of row block i (this lane half)
+    auto row_of = [&](int i, int e) { return 32 * i + 8 * (e >> 2) + 4 * L.h + (e & 3); };
 
     // group of this workgroup: contiguous ranges of groups per XCD (blockIdx & 7), so that the tiles of one patch — which
     // gather the same q / k / v rows — share an L2
@@ -210,10 +241,10 @@ __global__ __launch_bounds__(D * 2, (D == 128 ? 2 : 1)) void fn_edge_chain_kerne
     const int64_t pt0 = g * PPG;
     const int npts = (int)((a.P - pt0) < PPG ? (a.P - pt0) : PPG);
 
-    f32x16 acc[RB], pe[RB];
-    ChainW<ChainShape<D>::WD> W;
+    f32x16 acc[NB], pe[NB];
+    ChainW<S::WD, CB> W;
     // ---- phase 0: edge records of the group's rows; pe1 = LIF(fc_delta(x_i - x_j)) -> panel              fn:310,355-358
-    float qp[PPG];                                         // q_i of the group's points, this lane's column
+    float qp[CB][PPG];                                     // q_i of the group's points, this lane's columns
     if (tid < CH_ROWS) {
         const int pl = tid / KK;
         const bool ok = pl < npts;                                           // pad rows replay the group's first edge row
@@ -222,68 +253,83 @@ __global__ __launch_bounds__(D * 2, (D == 128 ? 2 : 1)) void fn_edge_chain_kerne
         pdl[tid] = a.pd[er];
     }
     {
-        // accumulator layout, like the epilogues: this lane's column for its 64 rows (the neuron parameters are per-lane
+        // accumulator layout, like the epilogues: this lane's column(s) for its rows (the neuron parameters are per-lane
         // constants; the position differences are LDS broadcasts)
-        const float wx = a.wd[L.col * 3], wy = a.wd[L.col * 3 + 1], wz = a.wd[L.col * 3 + 2], bd = a.bd[L.col];
-        const NeuronP nd = chain_lif(a.lifd, D, L.col);
+        float wx[CB], wy[CB], wz[CB], bd[CB];
+        NeuronP nd[CB];
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            wx[j] = a.wd[L.col[j] * 3];
+            wy[j] = a.wd[L.col[j] * 3 + 1];
+            wz[j] = a.wd[L.col[j] * 3 + 2];
+            bd[j] = a.bd[L.col[j]];
+            nd[j] = chain_lif(a.lifd, D, L.col[j]);
+        }
         lds_barrier();                                     // edge records are in
         // q_i of the group's points for the first epilogue (fn:368): issued here, consumed after GEMM 1
 #pragma unroll
-        for (int p = 0; p < PPG; ++p) qp[p] = a.qkv[(pt0 + (p < npts ? p : 0)) * a.ldq + L.col];
+        for (int j = 0; j < CB; ++j)
 #pragma unroll
-        for (int u = 0; u < RB * UPB; ++u) {
-            const int i = u / UPB, e0 = US * (u % UPB);
+            for (int p = 0; p < PPG; ++p) qp[j][p] = a.qkv[(pt0 + (p < npts ? p : 0)) * a.ldq + L.col[j]];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int b = u / UPB, i = b / CB, j = b % CB, e0 = US * (u % UPB);
             float v[US];
 #pragma unroll
             for (int z = 0; z < US; ++z) {
-                const float4 dd = pdl[32 * i + 8 * ((e0 + z) >> 2) + 4 * L.h + ((e0 + z) & 3)];
-                float t0 = __fmul_rn(wx, dd.x);
-                t0 = __fmaf_rn(wy, dd.y, t0);
-                t0 = __fmaf_rn(wz, dd.z, t0);
-                v[z] = __fadd_rn(t0, bd);
+                const float4 dd = pdl[row_of(i, e0 + z)];
+                float t0 = __fmul_rn(wx[j], dd.x);
+                t0 = __fmaf_rn(wy[j], dd.y, t0);
+                t0 = __fmaf_rn(wz[j], dd.z, t0);
+                v[z] = __fadd_rn(t0, bd[j]);
             }
-            lif_selfloop_n<US>(v, nd, a.T);
+            lif_selfloop_n<US>(v, nd[j], a.T);
 #pragma unroll
-            for (int z = 0; z < US; ++z) chain_put<CH_PLANE>(X, L, i, (e0 + z) >> 2, (e0 + z) & 3, v[z]);
+            for (int z = 0; z < US; ++z) chain_put<CH_PLANE, CB>(X, L, j, i, (e0 + z) >> 2, (e0 + z) & 3, v[z]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    const half8* const wp1 = reinterpret_cast<const half8*>(a.w1p) + (int64_t)w * (D / 16) * 128;
-    const half8* const wp2 = reinterpret_cast<const half8*>(a.w2p) + (int64_t)w * (D / 16) * 128;
-    const half8* const wp3 = reinterpret_cast<const half8*>(a.w3p) + (int64_t)w * (D / 16) * 128;
-    // k_j and v_j of one epilogue unit u (block u / UPB, elements US (u % UPB) .. + US - 1 of this lane), this lane's column
+    const half8* const wp1 = reinterpret_cast<const half8*>(a.w1p);
+    const half8* const wp2 = reinterpret_cast<const half8*>(a.w2p);
+    const half8* const wp3 = reinterpret_cast<const half8*>(a.w3p);
+    // k_j and v_j of one epilogue unit u, this lane's column of the unit's column block
     float kq[2][US], vq[2][US];
     auto gather_kv = [&](int u, float (&kd)[US], float (&vd)[US]) {
+        const int b = u / UPB, i = b / CB, j = b % CB;
 #pragma unroll
         for (int z = 0; z < US; ++z) {
-            const int e = US * (u % UPB) + z;
-            const int nrow = rinfo[32 * (u / UPB) + 8 * (e >> 2) + 4 * L.h + (e & 3)].y;
-            kd[z] = a.qkv[(int64_t)nrow * a.ldq + D + L.col];
-            vd[z] = a.qkv[(int64_t)nrow * a.ldq + 2 * D + L.col];
+            const int nrow = rinfo[row_of(i, US * (u % UPB) + z)].y;
+            kd[z] = a.qkv[(int64_t)nrow * a.ldq + D + L.col[j]];
+            vd[z] = a.qkv[(int64_t)nrow * a.ldq + 2 * D + L.col[j]];
         }
     };
     gather_kv(0, kq[0], vq[0]);                            // in flight during GEMM 1
-    chain_w_prefetch(wp1, lane, W);
+    chain_w_prefetch<D>(wp1, cb0, lane, W);
     lds_barrier();                                         // pe1 panel complete
 
     // ---- GEMM 1: fc_delta2; epilogue pe = LIF(.), attn_in = q_i - k_j + pe -> panel, t = v_j + pe stays      fn:360-368
     {
-        const float b1 = a.b1[L.col];
-        const NeuronP n1 = chain_lif(a.lif1, D, L.col);
-        chain_gemm<D>(X, wp1, lane, W, acc);
+        float b1[CB];
+        NeuronP n1[CB];
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            b1[j] = a.b1[L.col[j]];
+            n1[j] = chain_lif(a.lif1, D, L.col[j]);
+        }
+        chain_gemm<D>(X, wp1, cb0, lane, W, acc);
         lds_barrier();                                     // every wave has read the pe1 panel: it may be overwritten
         // software pipeline over the units: the gathers of unit u + 1 are issued before the neuron arithmetic of unit u
         // and consumed after the one of unit u + 1 (the in-order vector-memory counter then waits for loads that are one
         // arithmetic block old)
 #pragma unroll
-        for (int u = 0; u < RB * UPB; ++u) {
-            const int i = u / UPB, e0 = US * (u % UPB);
-            if (u + 1 < RB * UPB) gather_kv(u + 1, kq[(u + 1) & 1], vq[(u + 1) & 1]);
+        for (int u = 0; u < NU; ++u) {
+            const int b = u / UPB, i = b / CB, j = b % CB, e0 = US * (u % UPB);
+            if (u + 1 < NU) gather_kv(u + 1, kq[(u + 1) & 1], vq[(u + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
             float v[US];
 #pragma unroll
-            for (int z = 0; z < US; ++z) v[z] = __fmaf_rn(acc[i][e0 + z], 0.0625f, b1);      // undoes the x16 of the pre-scaled weights (exact)
-            lif_selfloop_n<US>(v, n1, a.T);
+            for (int z = 0; z < US; ++z) v[z] = __fmaf_rn(acc[b][e0 + z], 0.0625f, b1[j]);      // undoes the x16 of the pre-scaled weights (exact)
+            lif_selfloop_n<US>(v, n1[j], a.T);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int z = 0; z < US; ++z) {
@@ -291,73 +337,82 @@ __global__ __launch_bounds__(D * 2, (D == 128 ? 2 : 1)) void fn_edge_chain_kerne
                 const int e = e0 + z;
                 const int r0 = 32 * i + 8 * (e >> 2) + (e & 3), r1 = r0 + 4;
                 const int p0 = r0 / KK < PPG ? r0 / KK : PPG - 1, p1 = r1 / KK < PPG ? r1 / KK : PPG - 1;
-                const float qv = p0 == p1 ? qp[p0] : (L.h ? qp[p1] : qp[p0]);
-                chain_put<CH_PLANE>(X, L, i, e >> 2, e & 3, __fadd_rn(__fsub_rn(qv, kq[u & 1][z]), v[z]));
-                pe[i][e] = __fadd_rn(vq[u & 1][z], v[z]);                                  // t = v_j + pe (fn:386-389)
+                const float qv = p0 == p1 ? qp[j][p0] : (L.h ? qp[j][p1] : qp[j][p0]);
+                chain_put<CH_PLANE, CB>(X, L, j, i, e >> 2, e & 3, __fadd_rn(__fsub_rn(qv, kq[u & 1][z]), v[z]));
+                pe[b][e] = __fadd_rn(vq[u & 1][z], v[z]);                                  // t = v_j + pe (fn:386-389)
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        chain_w_prefetch(wp2, lane, W);
+        chain_w_prefetch<D>(wp2, cb0, lane, W);
     }
     lds_barrier();                                         // attn_in panel complete
     // ---- GEMM 2: fc_gamma; epilogue g = LIF(.) -> panel                                                   fn:373-376
     {
-        const float b2 = a.b2[L.col];
-        const NeuronP n2 = chain_lif(a.lif2, D, L.col);
-        chain_gemm<D>(X, wp2, lane, W, acc);
+        float b2[CB];
+        NeuronP n2[CB];
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            b2[j] = a.b2[L.col[j]];
+            n2[j] = chain_lif(a.lif2, D, L.col[j]);
+        }
+        chain_gemm<D>(X, wp2, cb0, lane, W, acc);
         lds_barrier();
 #pragma unroll
-        for (int u = 0; u < RB * UPB; ++u) {
-            const int i = u / UPB, e0 = US * (u % UPB);
+        for (int u = 0; u < NU; ++u) {
+            const int b = u / UPB, i = b / CB, j = b % CB, e0 = US * (u % UPB);
             float v[US];
 #pragma unroll
-            for (int z = 0; z < US; ++z) v[z] = __fmaf_rn(acc[i][e0 + z], 0.0625f, b2);
-            lif_selfloop_n<US>(v, n2, a.T);
+            for (int z = 0; z < US; ++z) v[z] = __fmaf_rn(acc[b][e0 + z], 0.0625f, b2[j]);
+            lif_selfloop_n<US>(v, n2[j], a.T);
 #pragma unroll
-            for (int z = 0; z < US; ++z) chain_put<CH_PLANE>(X, L, i, (e0 + z) >> 2, (e0 + z) & 3, v[z]);
+            for (int z = 0; z < US; ++z) chain_put<CH_PLANE, CB>(X, L, j, i, (e0 + z) >> 2, (e0 + z) & 3, v[z]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        chain_w_prefetch(wp3, lane, W);
+        chain_w_prefetch<D>(wp3, cb0, lane, W);
     }
     lds_barrier();                                         // g panel complete
     // ---- GEMM 3: fc_gamma2; per-point softmax over the kk neighbours, aggregation with v_j + pe           fn:378-389
     {
-        const float b3 = a.b3[L.col];
-        chain_gemm<D>(X, wp3, lane, W, acc);
-        // own rows: x = (a + b) / sqrt(hd) in place of the accumulators (pe already holds t = v_j + pe)
+        chain_gemm<D>(X, wp3, cb0, lane, W, acc);
 #pragma unroll
-        for (int i = 0; i < RB; ++i)
+        for (int j = 0; j < CB; ++j) {
+            const float b3 = a.b3[L.col[j]];
+            // own rows: x = (a + b) / sqrt(hd) in place of the accumulators (pe already holds t = v_j + pe)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][e] = __fmul_rn(__fmaf_rn(acc[i][e], 0.0625f, b3), a.inv_sqrt_hd);
-        // per point: its kk rows alternate between the lane halves in quads; both halves fetch the other's values and
-        // run the same neighbour-ordered sums (fn_softmax_agg_kernel's operation order)
+            for (int i = 0; i < RB; ++i)
 #pragma unroll
-        for (int p = 0; p < PPG; ++p) {
-            float xs[KK], ts[KK];
+                for (int e = 0; e < 16; ++e)
+                    acc[i * CB + j][e] = __fmul_rn(__fmaf_rn(acc[i * CB + j][e], 0.0625f, b3), a.inv_sqrt_hd);
+            // per point: its kk rows alternate between the lane halves in quads; both halves fetch the other's values and
+            // run the same neighbour-ordered sums (fn_softmax_agg_kernel's operation order)
 #pragma unroll
-            for (int j = 0; j < KK; ++j) {
-                const int r = p * KK + j, i = r >> 5, rr = r & 31;
-                const int e = ((rr >> 3) << 2) | (rr & 3), hr = (rr >> 2) & 1;
-                xs[j] = half_bcast(acc[i][e], hr);
-                ts[j] = half_bcast(pe[i][e], hr);
-            }
-            float mx = -__builtin_huge_valf();
+            for (int p = 0; p < PPG; ++p) {
+                float xs[KK], ts[KK];
 #pragma unroll
-            for (int j = 0; j < KK; ++j) mx = fmaxf(mx, xs[j]);
-            float den = 0.f;
+                for (int jj = 0; jj < KK; ++jj) {
+                    const int r = p * KK + jj, i = r >> 5, rr = r & 31;
+                    const int e = ((rr >> 3) << 2) | (rr & 3), hr = (rr >> 2) & 1;
+                    xs[jj] = half_bcast(acc[i * CB + j][e], hr);
+                    ts[jj] = half_bcast(pe[i * CB + j][e], hr);
+                }
+                float mx = -__builtin_huge_valf();
 #pragma unroll
-            for (int j = 0; j < KK; ++j) {
-                xs[j] = fast_exp(__fsub_rn(xs[j], mx));
-                den = __fadd_rn(den, xs[j]);
-            }
-            const float inv_den = __fdiv_rn(1.0f, den);
-            float out = 0.f;
+                for (int jj = 0; jj < KK; ++jj) mx = fmaxf(mx, xs[jj]);
+                float den = 0.f;
 #pragma unroll
-            for (int j = 0; j < KK; ++j) out = __fmaf_rn(__fmul_rn(xs[j], inv_den), ts[j], out);
-            if (p < npts && (p & 1) == L.h) {              // both halves hold the result: each stores every other point
-                const int64_t pt = pt0 + p;
-                if (a.res_split) store_split(a.res, pt, D, L.col, out);
-                else a.res[pt * D + L.col] = out;
+                for (int jj = 0; jj < KK; ++jj) {
+                    xs[jj] = fast_exp(__fsub_rn(xs[jj], mx));
+                    den = __fadd_rn(den, xs[jj]);
+                }
+                const float inv_den = __fdiv_rn(1.0f, den);
+                float out = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < KK; ++jj) out = __fmaf_rn(__fmul_rn(xs[jj], inv_den), ts[jj], out);
+                if (p < npts && (p & 1) == L.h) {          // both halves hold the result: each stores every other point
+                    const int64_t pt = pt0 + p;
+                    if (a.res_split) store_split(a.res, pt, D, L.col[j], out);
+                    else a.res[pt * D + L.col[j]] = out;
+                }
             }
         }
     }
@@ -376,7 +431,7 @@ static int launch_chain_t(const ChainArgs& a, hipStream_t st) {
     const int64_t ngroups = (a.P + PPG - 1) / PPG;
     const int64_t grid = ngroups < 8 ? ngroups : ((ngroups + 7) / 8) * 8;      // 8 XCD ranges of equal slot count
     SAPCU_CHECK_ARG(grid < 0x7fffffffLL, "edge_chain: too many groups");
-    hipLaunchKernelGGL((fn_edge_chain_kernel<D, KK>), dim3((unsigned)grid), dim3(D * 2), lds, st, a);
+    hipLaunchKernelGGL((fn_edge_chain_kernel<D, KK>), dim3((unsigned)grid), dim3(ChainShape<D>::NW * 64), lds, st, a);
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
 }
