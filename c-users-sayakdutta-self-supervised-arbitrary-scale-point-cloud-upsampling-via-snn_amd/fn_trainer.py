@@ -171,11 +171,25 @@ class SyntheticPU1K(object):
             yield {"input": torch.from_numpy(np.stack([c[0] for c in clouds])), "normal": torch.from_numpy(np.stack([c[1] for c in clouds]))}
 
 
+def clamp_neuron_parameters(model):
+    """The post-step clamp of the neuron parameters the reference's fd training loop applies (trainfd.py:305-313); trainfn.py has
+    none — the forward clamps the values it uses either way (fn/snn_coder.py:87-110), this keeps the stored parameters in range."""
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if 'membrane_decay' in name:
+                prm.data.clamp_(0.1, 0.99)
+            elif 'threshold_adapt' in name:
+                prm.data.clamp_(0.001, 0.1)
+            elif 'refractory_decay' in name:
+                prm.data.clamp_(0.1, 0.95)
+
+
 def run_epoch(trainer, train_loader, it=0, epoch_it=0, lr=None, warmup_steps=0, warmup_factor=0.01, state_reset_freq=0, print_every=0,
-              log=print):
+              log=print, clamp_parameters=False):
     """One pass over ``train_loader`` — the batch loop of the reference's trainfn.py:253-330 without its logging / checkpoint
     side effects: iteration counter, SNN state reset every ``state_reset_freq`` iterations, linear learning-rate warm-up, skipped
-    invalid or non-finite batches, per-iteration losses, samples per second.  -> (it, losses, stats)."""
+    invalid or non-finite batches, per-iteration losses, samples per second; optionally the neuron-parameter clamp of the fd loop.
+    -> (it, losses, stats)."""
     model, optimizer = trainer.model, trainer.optimizer
     lr = optimizer.param_groups[0]["lr"] if lr is None else lr
     losses, skipped, start, seen = [], 0, time.time(), 0
@@ -190,6 +204,8 @@ def run_epoch(trainer, train_loader, it=0, epoch_it=0, lr=None, warmup_steps=0, 
             for g in optimizer.param_groups:
                 g["lr"] = lr * f
         loss, _ = trainer.train_step(batch)
+        if clamp_parameters:                                             # (trainfd.py:305-313; off = trainfn.py's behaviour)
+            clamp_neuron_parameters(model)
         if loss is None:
             skipped += 1
             continue

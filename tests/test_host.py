@@ -313,3 +313,25 @@ def test_shape_suite_seeds_match_the_reference_runs():
     assert np.array_equal(cloud, s16["norm_cloud"])
     assert np.array_equal(gen.dense_seeds(cloud, testing.SCALE16_CASE["spacing"]), s16["seeds"])
     assert s16["filtered"].shape[0] >= testing.SCALE16_CASE["ratio"] * testing.SCALE16_CASE["n"] == s16["fps_idx"].shape[0]
+
+
+def test_neuron_parameter_clamp_matches_the_reference_loop():
+    """fn_trainer.clamp_neuron_parameters = trainfd.py:305-313 (membrane_decay [0.1, 0.99], threshold_adapt [0.001, 0.1],
+    refractory_decay [0.1, 0.95]; threshold_base and everything else untouched)."""
+    from sapcu_amd import fn_trainer
+    m = sapcu_amd.ImprovedSNNNormalEstimation(**FN_KW)
+    with torch.no_grad():
+        for name, prm in m.named_parameters():
+            if any(k in name for k in ("membrane_decay", "threshold_adapt", "refractory_decay", "threshold_base")):
+                prm.copy_(torch.linspace(-1.0, 2.0, prm.numel()).view_as(prm))
+    before = {n: q.detach().clone() for n, q in m.named_parameters()}
+    fn_trainer.clamp_neuron_parameters(m)
+    for name, prm in m.named_parameters():
+        if "membrane_decay" in name:
+            assert float(prm.min()) == pytest.approx(0.1) and float(prm.max()) == pytest.approx(0.99)
+        elif "threshold_adapt" in name:
+            assert float(prm.min()) == pytest.approx(0.001) and float(prm.max()) == pytest.approx(0.1)
+        elif "refractory_decay" in name:
+            assert float(prm.min()) == pytest.approx(0.1) and float(prm.max()) == pytest.approx(0.95)
+        else:
+            assert torch.equal(prm, before[name]), name
