@@ -4,6 +4,10 @@
 Run in the build container only (needs /root/reference, which never travels):
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_fixtures.py [--skip-e2e]
+    ... --only-suite | --suite-shape NAME   shape_suite.npz: BASELINE config 3 stand-in, six 2048-point shapes through the
+                                            reference's Generator3D6.upsample (~15 min of CPU)
+    ... --only-scale16                      scale16.npz: config 4 stand-in, the 16x generate.py body on a 256-point cloud (~11 min)
+    ... --only-patch-knn                    patch_knn.npz incl. the score matrices the reference ranked
 
 What is committed is data: inputs, expected outputs and per-stage intermediates produced by
 ``fn.snn_coder`` / ``fd.snn_coder`` / ``generation`` imported from /root/reference, plus
