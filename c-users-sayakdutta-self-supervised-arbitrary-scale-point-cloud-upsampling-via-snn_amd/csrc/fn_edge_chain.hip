@@ -1,5 +1,5 @@
 // fn transformer block: the whole per-edge chain of MultiHeadSNNTransformerBlock.forward (fn/snn_coder.py:355-389) in ONE
-// kernel, for the blocks whose row panel fits the CU (d = 128, 256):
+// kernel, for all three blocks (d = 128, 256, 512):
 //
 //     pe1 = LIF(fc_delta(x_i - x_j))          VALU                       fn:310,355-358
 //     pe  = LIF(fc_delta2(pe1))               GEMM 1 + neuron epilogue   fn:360-363
@@ -10,22 +10,23 @@
 //
 // The unfused form (model.hip: fn_pe1 -> gemm<EPI_LIF_ATTN> -> gemm<EPI_LIF> -> gemm<EPI_BIAS> -> fn_softmax_agg) moves every
 // [rows, d] tensor through HBM: ten passes of rows*d*4 bytes per block.  Here a workgroup owns a GROUP of whole points
-// (floor(128 / kk) points = up to 128 edge rows) and keeps the group's activation panel in LDS between the GEMMs, as the
-// split-f16 A operand (hi | lo planes, [k32 step][plane][128 rows][32 halves], 16-byte chunks XOR-swizzled by (row>>2)&3 —
-// the operand-slot layout of gemm_sf16_bt.hip, so the fragment reads are the same conflict-free ds_read_b128).  Nothing of
-// the chain reaches HBM: the kernel reads xyz differences + neighbour rows (24 B per edge row), the q / k / v rows of the
-// patch (L2) and the pre-packed weights (L2), and writes res [points, d].
+// (floor(ROWS / kk) points; ROWS = 128 edge rows at d <= 256, 64 at d = 512) and keeps the group's activation panel in LDS
+// between the GEMMs, as the split-f16 A operand (hi | lo planes, [k32 step][plane][ROWS][32 halves], 16-byte chunks
+// XOR-swizzled by (row>>2)&3 — the operand-slot layout of gemm_sf16_bt.hip, so the fragment reads are the same conflict-free
+// ds_read_b128).  Nothing of the chain reaches HBM: the kernel reads xyz differences + neighbour rows (24 B per edge row), the
+// q / k / v rows of the patch (L2) and the pre-packed weights (L2), and writes res [points, d].
 //
-// Shape of the work.  d/32 waves per workgroup; wave w owns output columns 32w .. 32w+31 of all three GEMMs and all 128 rows:
-// wave tile 128 x 32 = 4 MFMA blocks of 32x32 (64 accumulator registers).  A wave's weight fragments are not shared with any
-// other wave, so they bypass LDS: pre-packed at model build in fragment order (one contiguous KiB per (column block, k16,
-// plane)), streamed L2 -> registers four k16 steps ahead.  No barrier inside a GEMM; five workgroup barriers per group.
+// Shape of the work.  d/32 waves per workgroup; wave w owns output columns 32w .. 32w+31 of all three GEMMs and all ROWS rows:
+// wave tile ROWS x 32 = 4 (2 at d = 512) MFMA blocks of 32x32.  A wave's weight fragments are not shared with any other wave,
+// so they bypass LDS: pre-packed at model build in fragment order (one contiguous KiB per (column block, k16, plane)),
+// streamed L2 -> registers four (two) k16 steps ahead.  No barrier inside a GEMM; six workgroup barriers per group.
 // The epilogues run in the accumulator layout (lane = column: bias and neuron parameters are per-lane constants; register
 // e of block i = row 32i + 8(e>>2) + 4h + (e&3)), pe stays in registers until the aggregation, the per-point softmax gets
 // its rows from the two lane halves with v_permlane32_swap and sums them in neighbour order — every value equals the
 // unfused chain's bit for bit (same split-f16 products in the same order, same neuron arithmetic, same softmax order).
-// d = 128: 256-thread workgroups, 67 KiB of LDS -> two per CU, whose phases (MFMA / VALU) drift apart and overlap.
-// d = 256: 512 threads, 131 KiB, one per CU.   d = 512 does not fit (a 128-row panel is 256 KiB) and stays unfused.
+// d = 128: 256-thread workgroups, 67 KiB of LDS -> two per CU.  d = 256: 512 threads, 131 KiB, one per CU.  d = 512: 1024
+// threads (16 waves of 128 registers), 131 KiB, a rolled k loop.  What bounds them (each pipe at its practical rate, the
+// kernel time their sum) and the overlap designs that were measured without gain: DESIGN.md section 4.1c.
 #include "common.h"
 #include "gemm_epi.h"
 #include "ops.h"

@@ -505,7 +505,13 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
                 SAPCU_CHECK_HIP(hipMemcpyAsync((int32_t*)taps[SAPCU_FD_TAP_KNN] + ((int64_t)(l - 1) * b + s) * mp * pl.kk,
                                                idl, P * pl.kk * 4, hipMemcpyDeviceToDevice, st));
             const int ew = FD_EDGE1_W + 3 * (l - 1);
-            SAPCU_TRY(gemm(m, F, P, cin[l], 960, m->p(ew), 2 * cout[l], nullptr, AB, 2 * cout[l], EPI_BIAS, st));
+            // the factored EdgeConv's GEMM reads the step-0 spikes as split rows when the neuron kernels wrote them (rows 0..P-1 of
+            // SPKS, same pitch and column offsets as the f32 slab): the all-DMA kernels instead of the f32-operand one, same sums
+            if (split_spikes)
+                SAPCU_TRY(gemm(m, SPKS + coff[l - 1], P, cin[l], 960, m->p(ew), 2 * cout[l], nullptr, AB, 2 * cout[l], EPI_BIAS, st,
+                               nullptr, 0, nullptr, 0, 1));
+            else
+                SAPCU_TRY(gemm(m, F, P, cin[l], 960, m->p(ew), 2 * cout[l], nullptr, AB, 2 * cout[l], EPI_BIAS, st));
             SAPCU_TRY(launch_fd_neuron(l == 1, 1, AB, 2 * cout[l], idl, pl.kk, mp, m->p(ew + 1), P, cout[l], m->p(ew + 2),
                                        T, SPK0, 960, coff[l], nullptr, m->gate_dev, st, SPKS));
         }

@@ -31,8 +31,8 @@ template <int BT>
 __global__ __launch_bounds__(256) void patch_knn_kernel(const float* __restrict__ feat, int64_t pstride, int m,
                                                         int c, int ld, const KnnOut out) {
     extern __shared__ float sm[];
-    float* S = sm;                      // [m][m+1]
-    float* xx = S + m * (m + 1);        // [m]
+    unsigned* K = reinterpret_cast<unsigned*>(sm);   // [m][m+1] score keys
+    float* xx = sm + m * (m + 1);       // [m]
     float* F = xx + m;                  // [16*BT][PK_CH+1]  (rows >= m zero)
     const int tid = threadIdx.x;
     const float* base = feat + (int64_t)blockIdx.x * pstride;
@@ -90,22 +90,53 @@ __global__ __launch_bounds__(256) void patch_knn_kernel(const float* __restrict_
             const int i = bi * BT + u, j = bj * BT + v;
             if (i < m && j < m) {
                 const float inner = __fmul_rn(-2.0f, acc[u][v]);
-                S[i * (m + 1) + j] = __fsub_rn(__fsub_rn(-xx[j], inner), xx[i]);
+                // stored as the order-preserving integer key of the score (+ 0.0f: -0 and +0 compare equal as floats)
+                K[i * (m + 1) + j] = float_max_key(__fadd_rn(__fsub_rn(__fsub_rn(-xx[j], inner), xx[i]), 0.0f));
             }
         }
     __syncthreads();
-    // rank by counting: one wave per row, lane owns columns lane and lane+64
+    // rank by counting: one wave per row, lane owns column lane (and lane + 64 when m > 64).  (score, index) pairs are compared as
+    // ONE 64-bit integer — key << 32 | ~index: greater = higher score, or equal score and lower index.  The row's keys sit in the
+    // lanes' registers; an inner iteration broadcasts one of them through a scalar register (v_readlane) and costs one 64-bit
+    // compare and one add per owned column (the float form took ~10 VALU instructions and an LDS read per pair, and this phase —
+    // m^3 compares per patch — is what bounds the kernel).
     const int lane = tid & 63, wave = tid >> 6;
     for (int i = wave; i < m; i += 4) {
-        const float* row = S + i * (m + 1);
+        const unsigned* row = K + i * (m + 1);
         const int j0 = lane, j1 = lane + 64;
-        const float s0 = j0 < m ? row[j0] : 0.f;
-        const float s1 = j1 < m ? row[j1] : 0.f;
+        const unsigned key0 = j0 < m ? row[j0] : 0u, key1 = j1 < m ? row[j1] : 0u;
+        const unsigned long long k0 = ((unsigned long long)key0 << 32) | (unsigned)~j0;
+        const unsigned long long k1 = ((unsigned long long)key1 << 32) | (unsigned)~j1;
         int r0 = 0, r1 = 0;
-        for (int jp = 0; jp < m; ++jp) {
-            const float sv = row[jp];
-            r0 += (sv > s0) || (sv == s0 && jp < j0);
-            r1 += (sv > s1) || (sv == s1 && jp < j1);
+        // chunks of 8 columns; columns >= m carry key 0, which is below every score's key, so padding a chunk is harmless
+        if (m <= 64) {
+            for (int jb = 0; jb < m; jb += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int jp = jb + u;
+                    const unsigned long long kv = ((unsigned long long)__builtin_amdgcn_readlane(key0, jp) << 32) | (unsigned)~jp;
+                    r0 += kv > k0;
+                }
+            }
+        } else {
+            for (int jb = 0; jb < 64; jb += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int jp = jb + u;
+                    const unsigned long long kv = ((unsigned long long)__builtin_amdgcn_readlane(key0, jp) << 32) | (unsigned)~jp;
+                    r0 += kv > k0;
+                    r1 += kv > k1;
+                }
+            }
+            for (int jb = 64; jb < m; jb += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int jp = jb + u;
+                    const unsigned long long kv = ((unsigned long long)__builtin_amdgcn_readlane(key1, jp - 64) << 32) | (unsigned)~jp;
+                    r0 += kv > k0;
+                    r1 += kv > k1;
+                }
+            }
         }
         for (int t = 0; t < out.n; ++t) {
             const int k = out.k[t];
@@ -763,51 +794,82 @@ __global__ __launch_bounds__(256) void fd_neuron_kernel(const float* __restrict_
 // staged in LDS once (m x 128 floats), so the k-neighbour max reads LDS instead of k gathers from L2 per
 // element (k = 32: 32x less L2 traffic — the old form was bound by it: 6.4 GB per launch for C = 512).
 constexpr int FDE_CH = 128;
+constexpr int FDE_NH = 2;    // threads per channel: the patch's 8-point groups alternate between them (twice the waves over the same LDS tile)
 
 template <bool EIF>
-__global__ __launch_bounds__(FDE_CH) void fd_edge_neuron_kernel(const float* __restrict__ in, int ldi,
+__global__ __launch_bounds__(FDE_CH * FDE_NH) void fd_edge_neuron_kernel(const float* __restrict__ in, int ldi,
                                                                 const int32_t* __restrict__ idx, int kk, int m,
                                                                 const float* __restrict__ shift, int64_t pts, int C,
                                                                 const float* __restrict__ prm, int T,
                                                                 float* __restrict__ spk, int ldo, int coff,
                                                                 int* __restrict__ gate_violations, float* __restrict__ spk_split) {
     extern __shared__ float sA[];                       // [m][FDE_CH]
-    const int tx = threadIdx.x;
+    const int tx = threadIdx.x % FDE_CH;
+    const int hf = __builtin_amdgcn_readfirstlane(threadIdx.x / FDE_CH);     // wave-uniform: the neighbour lists stay scalar loads
     const int c = blockIdx.y * FDE_CH + tx;
     const int64_t row0 = (int64_t)blockIdx.x * m;
     const bool live = c < C;
-    for (int i = 0; i < m; ++i) sA[i * FDE_CH + tx] = live ? in[(row0 + i) * ldi + c] : 0.f;
+    // Every global load of this kernel misses the caches (the [pts, 2C] operand is 0.8 GB at C = 512): they are issued in
+    // batches of 8 with nothing waiting in between — the one-load-one-wait form spent 3/4 of the kernel in HBM latency.
+    // Dead lanes (c >= C) replay the last channel so that the loads stay unconditional.
+    const float* col = in + row0 * ldi + (live ? c : C - 1);
+    for (int i0 = 8 * hf; i0 < m; i0 += 8 * FDE_NH) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = col[(int64_t)min(i0 + u, m - 1) * ldi];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u < m) sA[(i0 + u) * FDE_CH + tx] = t[u];
+    }
     __syncthreads();
     if (!live) return;
     const NeuronP p = EIF ? load_eif(prm, C, c) : load_lif(prm, C, c);
     const float sh = shift[c];
-    // two points per pass: their neuron chains share every packed instruction (an odd m repeats the last point)
-    for (int i = 0; i < m; i += 2) {
-        const int i1 = (i + 1 < m) ? i + 1 : i;
-        const int64_t ra = row0 + i, rb = row0 + i1;
-        const int32_t* ia = idx + ra * kk;
-        const int32_t* ib = idx + rb * kk;
-        float ma = -__builtin_huge_valf(), mb = ma;
-        for (int j = 0; j < kk; ++j) {
-            ma = fmaxf(ma, sA[ia[j] * FDE_CH + tx]);
-            mb = fmaxf(mb, sA[ib[j] * FDE_CH + tx]);
+    const float* xcol = col + C;                        // the x_i term of the factored EdgeConv
+    float xn[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xn[u] = xcol[(int64_t)min(8 * hf + u, m - 1) * ldi];
+    for (int g = 8 * hf; g < m; g += 8 * FDE_NH) {
+        float xc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xc[u] = xn[u];
+        if (g + 8 * FDE_NH < m) {                       // next group's x_i terms: in flight during this group's four passes
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xn[u] = xcol[(int64_t)min(g + 8 * FDE_NH + u, m - 1) * ldi];
         }
-        const f32x2 pre = f32x2{lrelu02(__fadd_rn(__fsub_rn(ma, in[ra * ldi + C + c]), sh)),
-                                lrelu02(__fadd_rn(__fsub_rn(mb, in[rb * ldi + C + c]), sh))};
-        NeuronStep2<EIF> ns(p);
-        for (int step = 0; step < T; ++step) {
-            if (step > 0 && ns.gate_open()) atomicAdd(gate_violations, 1);
-            const f32x2 sp = ns.step(step == 0 ? pre : f32x2{0.f, 0.f}, step == 0);
-            if (spk_split) {                             // (see fd_neuron_kernel)
-                store_split(spk_split, (int64_t)step * pts + ra, ldo, coff + c, sp.x);
-                if (i1 != i) store_split(spk_split, (int64_t)step * pts + rb, ldo, coff + c, sp.y);
-                if (step == 0) {
-                    spk[ra * ldo + coff + c] = sp.x;
-                    if (i1 != i) spk[rb * ldo + coff + c] = sp.y;
+        // two points per pass: their neuron chains share every packed instruction (an odd m repeats the last point)
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            const int i = g + u;
+            if (i < m) {
+                const bool two = i + 1 < m;
+                const int i1 = two ? i + 1 : i;
+                const int64_t ra = row0 + i, rb = row0 + i1;
+                const int32_t* ia = idx + ra * kk;
+                const int32_t* ib = idx + rb * kk;
+                float ma = -__builtin_huge_valf(), mb = ma;
+                for (int j = 0; j < kk; ++j) {
+                    ma = fmaxf(ma, sA[ia[j] * FDE_CH + tx]);
+                    mb = fmaxf(mb, sA[ib[j] * FDE_CH + tx]);
                 }
-            } else {
-                spk[((int64_t)step * pts + ra) * ldo + coff + c] = sp.x;
-                if (i1 != i) spk[((int64_t)step * pts + rb) * ldo + coff + c] = sp.y;
+                const f32x2 pre = f32x2{lrelu02(__fadd_rn(__fsub_rn(ma, xc[u]), sh)),
+                                        lrelu02(__fadd_rn(__fsub_rn(mb, two ? xc[u + 1] : xc[u]), sh))};
+                NeuronStep2<EIF> ns(p);
+                for (int step = 0; step < T; ++step) {
+                    if (step > 0 && ns.gate_open()) atomicAdd(gate_violations, 1);
+                    const f32x2 sp = ns.step(step == 0 ? pre : f32x2{0.f, 0.f}, step == 0);
+                    if (spk_split) {                             // (see fd_neuron_kernel)
+                        store_split(spk_split, (int64_t)step * pts + ra, ldo, coff + c, sp.x);
+                        if (two) store_split(spk_split, (int64_t)step * pts + rb, ldo, coff + c, sp.y);
+                        if (step == 0) {
+                            spk[ra * ldo + coff + c] = sp.x;
+                            if (two) spk[rb * ldo + coff + c] = sp.y;
+                        }
+                    } else {
+                        spk[((int64_t)step * pts + ra) * ldo + coff + c] = sp.x;
+                        if (two) spk[((int64_t)step * pts + rb) * ldo + coff + c] = sp.y;
+                    }
+                }
             }
         }
     }
@@ -821,10 +883,10 @@ int launch_fd_neuron(bool eif, int mode, const float* in, int ldi, const int32_t
         const dim3 g2((unsigned)(pts / m), (unsigned)((C + FDE_CH - 1) / FDE_CH));
         const size_t lds = (size_t)m * FDE_CH * sizeof(float);
         if (eif)
-            hipLaunchKernelGGL(fd_edge_neuron_kernel<true>, g2, dim3(FDE_CH), lds, st, in, ldi, idx, kk, m, shift, pts, C, prm,
+            hipLaunchKernelGGL(fd_edge_neuron_kernel<true>, g2, dim3(FDE_CH * FDE_NH), lds, st, in, ldi, idx, kk, m, shift, pts, C, prm,
                                T, spk, ldo, coff, gate_violations, spk_split);
         else
-            hipLaunchKernelGGL(fd_edge_neuron_kernel<false>, g2, dim3(FDE_CH), lds, st, in, ldi, idx, kk, m, shift, pts, C,
+            hipLaunchKernelGGL(fd_edge_neuron_kernel<false>, g2, dim3(FDE_CH * FDE_NH), lds, st, in, ldi, idx, kk, m, shift, pts, C,
                                prm, T, spk, ldo, coff, gate_violations, spk_split);
         SAPCU_CHECK_LAUNCH();
         return SAPCU_OK;

@@ -20,8 +20,10 @@ def main(d, title):
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         print("| `%s` | %d | %.2f | %.1f | %.1f |" % (k, len(v), sum(v) / 1e3, sum(v) / len(v), 100 * sum(v) / tot))
     print("\ntotal kernel time %.1f ms over %d dispatches\n" % (tot / 1e3, len(rows)))
-    # per-launch durations of the GEMM kernels in dispatch order (the three fn blocks alternate: d = 128, 256, 512)
-    seq = {k: [round(x, 1) for x in v] for k, v in agg.items() if k.startswith(("gemm_ring_kernel", "gemm_bt_kernel"))}
+    # per-launch durations (us, dispatch order) of every kernel that is launched with more than one shape per step and matters
+    # (GEMMs: the three fn blocks alternate d = 128, 256, 512; in-patch kNN: xyz and 64 / 128 / 256-d feature space; ...)
+    seq = {k: [round(x, 1) for x in v] for k, v in agg.items()
+           if len(v) <= 64 and sum(v) / len(v) >= 20.0 and not k.startswith(("void at::", "__amd"))}
     if len(sys.argv) > 3:
         import json
         json.dump(seq, open(sys.argv[3], "w"))
