@@ -342,7 +342,8 @@ __device__ __forceinline__ float float_from_max_key(unsigned k) { return __uint_
 // GEMM (gemm_f32.hip):  C[r,n] = epi( pro(A)[r,k] * W[n,k]^T + bias[n] )
 // ---------------------------------------------------------------------------------------------
 enum GemmEpi { EPI_BIAS = 0, EPI_LIF = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_LRELU = 4, EPI_RESID_GELU = 5, EPI_LIF_ATTN = 6,
-               EPI_LRELU_MAX = 7 };   // gemm_sf16.hip only: LeakyReLU, then max over groups of max_m rows instead of storing C
+               EPI_LRELU_MAX = 7,     // LeakyReLU, then max over groups of max_m rows instead of storing C (gemm_sf16 / gemm_sf16_bt)
+               EPI_LIF_MAX = 8 };     // gemm_sf16.hip only: T-step neuron, then the same max (fn conv_final -> max over points)
 
 struct GemmArgs {
     const float* a;      // [r, lda]
@@ -372,7 +373,8 @@ struct GemmArgs {
     int* ovf;            // device counter raised when an activation tile exceeds the f16 range (may be null)
     // "split rows" (gemm_epi.h): A already split by its producer -> all-DMA ring kernel; outputs to be split
     int a_split, c_split, c2_split;
-    // EPI_LRELU_MAX (fd/snn_coder.py:476-480: multi_scale_conv -> max over the patch's points): C is never stored;
+    // EPI_LRELU_MAX (fd/snn_coder.py:476-480: multi_scale_conv -> max over the patch's points) and EPI_LIF_MAX
+    // (fn/snn_coder.py:465-472: conv_final + LIF -> max over the patch's points): C is never stored;
     // max_keys[(row / max_m) * n + col] = max over the group's rows of the order-preserving integer key of the value
     // (float_max_key; the buffer starts at 0 = below every key; launch_decode_max_keys turns it into floats)
     unsigned* max_keys;

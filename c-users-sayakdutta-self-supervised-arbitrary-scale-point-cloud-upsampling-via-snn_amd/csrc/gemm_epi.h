@@ -59,7 +59,7 @@ __device__ __forceinline__ void epilogue_group(const GemmArgs& g, const float (&
     }
 #pragma unroll
     for (int u = 0; u < W; ++u) v[u] = __fadd_rn(acc[u], bias);
-    if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) lif_selfloop_n<W>(v, np, g.lif_T);
+    if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN || EPI == EPI_LIF_MAX) lif_selfloop_n<W>(v, np, g.lif_T);
 #pragma unroll
     for (int u = 0; u < W; ++u) {
         if (EPI == EPI_GELU) v[u] = gelu_erf(v[u]);
@@ -67,7 +67,7 @@ __device__ __forceinline__ void epilogue_group(const GemmArgs& g, const float (&
         if (EPI == EPI_RESID) v[u] = __fadd_rn(v[u], res[u]);
         if (EPI == EPI_RESID_GELU) v[u] = gelu_erf(__fadd_rn(v[u], res[u]));
     }
-    if (EPI == EPI_LRELU_MAX) {
+    if (EPI == EPI_LRELU_MAX || EPI == EPI_LIF_MAX) {
         // max over the row groups instead of a store: consecutive rows of one group are combined in registers, one
         // integer atomicMax per (group, column) and lane (the maximum does not depend on the order: exact)
         int64_t cur = -1;

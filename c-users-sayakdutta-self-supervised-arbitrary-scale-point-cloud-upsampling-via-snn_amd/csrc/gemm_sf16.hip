@@ -237,7 +237,7 @@ __global__ __launch_bounds__(1024) void gemm_sf16_kernel(const GemmArgs g) {
                 ccol[j] = cons_work && col < g.n;
                 cbias[j] = settle((ccol[j] && g.bias) ? g.bias[col] : 0.f);
                 cnp[j] = NeuronP{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) {
+                if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN || EPI == EPI_LIF_MAX) {
                     cnp[j] = load_lif(g.lif, g.n, ccol[j] ? col : 0);
                     cnp[j].theta0 = settle(cnp[j].theta0);
                 }
@@ -368,6 +368,9 @@ int launch_gemm_sf16(const GemmArgs& g, hipStream_t st) {
         case EPI_LRELU_MAX:
             SAPCU_CHECK_ARG(g.max_keys && g.max_m >= 1, "gemm_sf16: EPI_LRELU_MAX needs max_keys and max_m");
             return launch_t16<EPI_LRELU_MAX>(g, st);
+        case EPI_LIF_MAX:
+            SAPCU_CHECK_ARG(g.max_keys && g.max_m >= 1 && g.lif, "gemm_sf16: EPI_LIF_MAX needs max_keys, max_m and neuron parameters");
+            return launch_t16<EPI_LIF_MAX>(g, st);
         case EPI_RESID_GELU: return launch_t16<EPI_RESID_GELU>(g, st);
         case EPI_LIF_ATTN:
             SAPCU_CHECK_ARG(g.ldq > 0 && g.tab && g.q && g.kf && g.c2, "gemm_sf16: bad attn operands");

@@ -372,9 +372,23 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
             ldin = 192;
         }
         // conv_final + LIF x T_enc, max over points, fc_out                          fn:465-475
-        SAPCU_TRY(gemm(m, cat, P, 192, 192, m->p(FN_FINAL_W), m->emb, m->p(FN_FINAL_B), B1, m->emb, EPI_LIF, st,
-                       m->p(FN_FINAL_LIF), m->T));
-        SAPCU_TRY(launch_rowgroup_max(B1, cb, mp, m->emb, pooled, st));
+        const char* fmx = getenv("SAPCU_FN_MAXFUSE");          // read per call: the parity test flips it inside one process
+        if (m->sf16 && !(fmx && strcmp(fmx, "0") == 0)) {
+            // the max over the patch's points inside the GEMM's epilogue (integer atomicMax on order-preserving keys, as fd's
+            // multi_scale_conv): the [P, emb] activation is never written.  Keys live at the head of the unused B1 area.
+            GemmArgs g;
+            memset(&g, 0, sizeof(g));
+            g.a = cat; g.r = P; g.k = 192; g.lda = 192; g.w = m->p(FN_FINAL_W); g.n = m->emb; g.bias = m->p(FN_FINAL_B);
+            g.ldc = m->emb; g.epi = EPI_LIF_MAX; g.lif = m->p(FN_FINAL_LIF); g.lif_T = m->T;
+            g.max_keys = reinterpret_cast<unsigned*>(B1); g.max_m = mp;
+            SAPCU_CHECK_HIP(hipMemsetAsync(g.max_keys, 0, (size_t)cb * m->emb * 4, st));
+            SAPCU_TRY(run_gemm(m, g, st));
+            SAPCU_TRY(launch_decode_max_keys(g.max_keys, cb * m->emb, pooled, st));
+        } else {
+            SAPCU_TRY(gemm(m, cat, P, 192, 192, m->p(FN_FINAL_W), m->emb, m->p(FN_FINAL_B), B1, m->emb, EPI_LIF, st,
+                           m->p(FN_FINAL_LIF), m->T));
+            SAPCU_TRY(launch_rowgroup_max(B1, cb, mp, m->emb, pooled, st));
+        }
         SAPCU_TRY(tap_copy(taps, SAPCU_FN_TAP_POOLED, s * m->emb * 4, pooled, cb * m->emb * 4, st));
         SAPCU_TRY(gemm(m, pooled, cb, m->emb, m->emb, m->p(FN_FCOUT_W), 2048, m->p(FN_FCOUT_B), enc, 2048, EPI_BIAS, st));
         SAPCU_TRY(tap_copy(taps, SAPCU_FN_TAP_ENC, s * 2048 * 4, enc, cb * 2048 * 4, st));

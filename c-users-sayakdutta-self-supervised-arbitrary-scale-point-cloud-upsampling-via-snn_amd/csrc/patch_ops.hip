@@ -724,9 +724,97 @@ __global__ __launch_bounds__(256) void fd_edge0_patch_kernel(const float* __rest
     }
 }
 
+// Same stage once more, for up to four scales: a lane owns column c of EVERY scale (24 weights in registers), a wave walks pairs
+// of points, and everything that is the same for all lanes — neighbour indices, coordinates — arrives through scalar loads (the
+// scalar cache) instead of LDS broadcasts, which cost an LDS pass per wave and were what bounded the one-wave-per-scale form.
+// The position differences are formed once per edge for all scales, the two points of a pair share packed multiply-adds, a scale
+// stops at its own k (its neighbours are a prefix of the sorted list).  Same operations in the same order per output.
+template <int NS>
+__global__ __launch_bounds__(256) void fd_edge0_scalar_kernel(const float* __restrict__ patch, const int32_t* __restrict__ idx,
+                                                              int kmax, int m, const int32_t* __restrict__ ks /*[NS] device*/,
+                                                              const float* __restrict__ w /*[NS][64][6]*/,
+                                                              const float* __restrict__ bias /*[NS][64]*/,
+                                                              float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t pt0 = (int64_t)blockIdx.x * m;
+    const float* __restrict__ pp = patch + pt0 * 3;
+    const int32_t* __restrict__ ip = idx + pt0 * kmax;
+    float wt[NS][6], bb[NS];
+    int kuse[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) wt[s][t] = w[((int64_t)s * 64 + lane) * 6 + t];
+        bb[s] = bias[s * 64 + lane];
+        kuse[s] = min(ks[s], m);
+    }
+    constexpr int cs = 64 * NS;
+    for (int i = 2 * wv; i < m; i += 8) {
+        const int i1 = (i + 1 < m) ? i + 1 : i;
+        const f32x2 xi = f32x2{pp[3 * i], pp[3 * i1]}, yi = f32x2{pp[3 * i + 1], pp[3 * i1 + 1]},
+                    zi = f32x2{pp[3 * i + 2], pp[3 * i1 + 2]};
+        const int32_t* __restrict__ ia = ip + (int64_t)i * kmax;
+        const int32_t* __restrict__ ib = ip + (int64_t)i1 * kmax;
+        f32x2 mx[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) mx[s] = f32x2{-__builtin_huge_valf(), -__builtin_huge_valf()};
+        for (int j0 = 0; j0 < kmax; j0 += 4) {
+            // four edges per point: their (scalar) index and coordinate loads are issued together
+            int na[4], nb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = min(j0 + u, kmax - 1);
+                na[u] = ia[j];
+                nb[u] = ib[j];
+            }
+            f32x2 xj[4], yj[4], zj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xj[u] = f32x2{pp[3 * na[u]], pp[3 * nb[u]]};
+                yj[u] = f32x2{pp[3 * na[u] + 1], pp[3 * nb[u] + 1]};
+                zj[u] = f32x2{pp[3 * na[u] + 2], pp[3 * nb[u] + 2]};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u;
+                const f32x2 dx = xj[u] - xi, dy = yj[u] - yi, dz = zj[u] - zi;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if (j < kuse[s]) {
+                        f32x2 v = f32x2{wt[s][0], wt[s][0]} * dx;
+                        v = pk_fma(f32x2{wt[s][1], wt[s][1]}, dy, v);
+                        v = pk_fma(f32x2{wt[s][2], wt[s][2]}, dz, v);
+                        v = pk_fma(f32x2{wt[s][3], wt[s][3]}, xj[u], v);
+                        v = pk_fma(f32x2{wt[s][4], wt[s][4]}, yj[u], v);
+                        v = pk_fma(f32x2{wt[s][5], wt[s][5]}, zj[u], v);
+                        mx[s] = f32x2{fmaxf(mx[s].x, v.x), fmaxf(mx[s].y, v.y)};
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            out[(pt0 + i) * cs + s * 64 + lane] = lrelu02(__fadd_rn(mx[s].x, bb[s]));
+            if (i1 != i) out[(pt0 + i1) * cs + s * 64 + lane] = lrelu02(__fadd_rn(mx[s].y, bb[s]));
+        }
+    }
+}
+
 int launch_fd_edge0(const float* patch, const int32_t* idx, int kmax, int64_t pts, int m, int nscale,
                     const int32_t* ks_dev, const float* w, const float* bias, float* out, hipStream_t st) {
     if (pts == 0) return SAPCU_OK;
+    if (pts % m == 0 && nscale >= 1 && nscale <= 4 && pts * 3 < 0x7fffffffLL) {
+        const dim3 g((unsigned)(pts / m)), b(256);
+#define SAPCU_E0(NS) hipLaunchKernelGGL(fd_edge0_scalar_kernel<NS>, g, b, 0, st, patch, idx, kmax, m, ks_dev, w, bias, out)
+        if (nscale == 1) SAPCU_E0(1);
+        else if (nscale == 2) SAPCU_E0(2);
+        else if (nscale == 3) SAPCU_E0(3);
+        else SAPCU_E0(4);
+#undef SAPCU_E0
+        SAPCU_CHECK_LAUNCH();
+        return SAPCU_OK;
+    }
     if (m <= FDE0_MAXM && kmax <= FDE0_MAXK && pts % m == 0) {
         hipLaunchKernelGGL(fd_edge0_patch_kernel, dim3((unsigned)(pts / m)), dim3(256), 0, st, patch, idx, kmax, m, nscale,
                            ks_dev, w, bias, out);

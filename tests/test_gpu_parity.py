@@ -1329,6 +1329,29 @@ def test_fused_edge_chain_equals_the_unfused_chain_bit_for_bit(weights, monkeypa
     assert fn.gemm_mode() == (True, 0)
 
 
+def test_fn_max_over_points_fused_into_the_gemm_is_bit_identical(weights, monkeypatch):
+    """fn's conv_final + LIF + max over the patch's points (fn/snn_coder.py:465-472): (default) the GEMM's epilogue runs the neuron
+    and takes the max by integer atomicMax on order-preserving keys — the [P, emb] activation is never written; SAPCU_FN_MAXFUSE=0:
+    GEMM + rowgroup_max.  Identical pooled features and normals for full patches, M = 100, M = 5 (groups that do not align with the
+    4-row register groups) and a single patch."""
+    fn, _, _, _ = U.build_gpu_models(weights)
+    fn.knn_cache_mode = "fresh"
+    emb = fn.emb_dims
+    for nq, mpts in ((40, 48), (7, 100), (70, 5), (1, 48)):
+        patch = U.sphere_patches(nq, mpts, skip=900).to(U.dev())
+        outs = []
+        for env in ({}, {"SAPCU_FN_MAXFUSE": "0"}):
+            monkeypatch.delenv("SAPCU_FN_MAXFUSE", raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            taps = {"pooled": torch.full((nq, emb), float("nan"), device=U.dev())}
+            n = fn(patch, taps=taps)
+            torch.cuda.synchronize()
+            outs.append((n, taps["pooled"]))
+        assert not bool(torch.isnan(outs[0][1]).any()) and not bool(torch.isnan(outs[0][0]).any())
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0]), (nq, mpts)
+
+
 def test_fd_max_over_points_fused_into_the_gemm_is_bit_identical(weights, monkeypatch):
     """fd's multi_scale_conv in its three forms: (default) the neuron kernels write the spikes as split rows, the big-tile GEMM
     streams them by LDS-DMA and takes the max over the patch's points in its epilogue (integer atomicMax on order-preserving keys:
