@@ -17,15 +17,15 @@
 // q / k / v rows of the patch (L2) and the pre-packed weights (L2), and writes res [points, d].
 //
 // Shape of the work.  d/32 waves per workgroup; wave w owns output columns 32w .. 32w+31 of all three GEMMs and all ROWS rows:
-// wave tile ROWS x 32 = 4 (2 at d = 512) MFMA blocks of 32x32.  A wave's weight fragments are not shared with any other wave,
+// wave tile ROWS x 32 = 4 MFMA blocks of 32x32 (d = 512: d/64 waves, 64 x 64 = 4 blocks).  A wave's weight fragments are not shared with any other wave,
 // so they bypass LDS: pre-packed at model build in fragment order (one contiguous KiB per (column block, k16, plane)),
 // streamed L2 -> registers four (two) k16 steps ahead.  No barrier inside a GEMM; six workgroup barriers per group.
 // The epilogues run in the accumulator layout (lane = column: bias and neuron parameters are per-lane constants; register
 // e of block i = row 32i + 8(e>>2) + 4h + (e&3)), pe stays in registers until the aggregation, the per-point softmax gets
 // its rows from the two lane halves with v_permlane32_swap and sums them in neighbour order — every value equals the
 // unfused chain's bit for bit (same split-f16 products in the same order, same neuron arithmetic, same softmax order).
-// d = 128: 256-thread workgroups, 67 KiB of LDS -> two per CU.  d = 256: 512 threads, 131 KiB, one per CU.  d = 512: 1024
-// threads (16 waves of 128 registers), 131 KiB, a rolled k loop.  What bounds them (each pipe at its practical rate, the
+// d = 128: 256-thread workgroups, 67 KiB of LDS -> two per CU.  d = 256: 512 threads, 131 KiB, one per CU.  d = 512: 512
+// threads (wave tile 64 x 64), 131 KiB, a rolled k loop.  What bounds them (each pipe at its practical rate, the
 // kernel time their sum) and the overlap designs that were measured without gain: DESIGN.md section 4.1c.
 #include "common.h"
 #include "gemm_epi.h"
@@ -36,21 +36,24 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // Shape of a workgroup's work.  ROWS = MFMA rows per group: 128 for d = 128 / 256; 64 for d = 512 (a 128-row panel of 512 columns
 // would be 256 KiB).  One plane of one k32 step is [ROWS][32 halves]; a k32 step = hi plane | lo plane.  A wave owns CB column
-// blocks of 32 and all ROWS rows: RB x CB accumulator blocks.  CB = 1 everywhere: d = 128: two 4-wave workgroups per CU and
-// d = 256: one 8-wave workgroup, 256 registers per wave; d = 512: 16 waves of 128 registers (epilogue units of 4 elements,
-// weights 2 k16 steps ahead).  Measured at d = 512: CB = 2 (8 waves of 256 registers, wave tile 64 x 64) 18.4 ms against
-// 17.6 ms for CB = 1 — the extra waves hide more latency than the larger wave tile saves in LDS reads.
+// blocks of 32 and all ROWS rows: RB x CB accumulator blocks, 256 registers per wave everywhere.  d = 128: CB = 1, two 4-wave
+// workgroups per CU; d = 256: CB = 1, one 8-wave workgroup; d = 512: CB = 2 (wave tile 64 x 64), one 8-wave workgroup — half
+// the LDS fragment reads of the 16-wave form and room for t = v + pe in registers (the 16-wave form, 128 registers per wave,
+// parked it in scratch: 10 GB of HBM traffic per step).  Measured at d = 512, ms per launch: 16 waves 17.3; 16 waves with the
+// weight ring refilled in place and unconditionally (exact wait counts in the rolled k loop) 17.2; 8 waves, same loop 16.6;
+// 8 waves, epilogue units of 8 elements 16.3.  (Before the wait counts were exact the 8-wave form lost: 18.4 against 17.6.)
 template <int D> struct ChainShape {
     static constexpr int ROWS = D <= 256 ? 128 : 64;
     static constexpr int RB = ROWS / 32;              // 32-row MFMA blocks per wave tile
-    static constexpr int CB = 1;                      // 32-column blocks per wave
+    static constexpr int CB = D == 512 ? 2 : 1;       // 32-column blocks per wave
     static constexpr int NB = RB * CB;                // accumulator blocks per wave (block b: rows i = b / CB, columns j = b % CB)
     static constexpr int NW = D / (32 * CB);          // waves per workgroup
     static constexpr int PLANE = ROWS * 64;
     static constexpr int KSTEP = 2 * PLANE;
     static constexpr int LDS = ROWS * D * 4 + ROWS * 16 + ROWS * 8;
-    static constexpr int US = D <= 256 ? 8 : 4;       // elements per lane of one epilogue unit
-    static constexpr int WD = D <= 256 ? 4 : 2;       // weight fragments this many k16 steps ahead (x CB column blocks x hi, lo)
+    static constexpr int US = 8;                      // elements per lane of one epilogue unit
+    static constexpr int WD = D <= 128 ? 4 : 2;       // weight fragments this many k16 steps ahead (x CB column blocks x hi, lo);
+                                                      // d >= 256: the rolled k loop's body is WD steps
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -162,17 +165,43 @@ __device__ __forceinline__ void chain_gemm(const unsigned char* X, const half8* 
         _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                                      \
             acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / CB], cwh[b % CB], acc[b], 0, 0, 0);                      \
     }
-    if constexpr (D <= 256) {                              // 8 / 16 steps: fully unrolled
+    if constexpr (D <= 128) {                              // 8 steps: fully unrolled (measured: d = 128 4.55 unrolled / 4.64 rolled, d = 256 8.27 / 8.10)
 #pragma unroll
         for (int s = 0; s < NK16; ++s) SAPCU_CHAIN_STEP(s, s & (WD - 1))
     } else {
-        // d = 512: 32 steps — a rolled loop of WD-step bodies keeps the weight ring's indices static without letting the
-        // scheduler hoist 32 steps' worth of operands
+        // d = 256 / 512: 16 / 32 steps — a rolled loop of WD-step bodies keeps the weight ring's indices static without letting
+        // the scheduler hoist all the steps' operands
+        // ... and a ring slot is refilled BEHIND the MFMAs that read it (no copy of the fragments)
+#define SAPCU_CHAIN_STEP_INPLACE(S, SJ)                                                                                     \
+    {                                                                                                                       \
+        const int s_ = (S);                                                                                                 \
+        const unsigned ko = (unsigned)((s_ >> 1) * CH_KSTEP + ((((s_ & 1) * 2 + h) ^ sw) * 16));                            \
+        half8 ah[RB], al[RB];                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                                                    \
+            ah[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048);                                                    \
+            al[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048 + CH_PLANE);                                         \
+        }                                                                                                                   \
+        _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                                      \
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b / CB], W.wh[SJ][b % CB], acc[b], 0, 0, 0);                 \
+        _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                                      \
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / CB], W.wl[SJ][b % CB], acc[b], 0, 0, 0);                 \
+        _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                                      \
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / CB], W.wh[SJ][b % CB], acc[b], 0, 0, 0);                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+        /* unconditional (the last WD steps re-load the last fragment): with a branch around the loads the compiler's wait  \
+           counts at the loop head degrade to vmcnt(0), i.e. every iteration waits for the loads it has just issued */      \
+        const int sn_ = s_ + WD < NK16 ? s_ + WD : NK16 - 1;                                                                \
+        _Pragma("unroll") for (int j = 0; j < CB; ++j) {                                                                    \
+            W.wh[SJ][j] = chain_w_frag<D>(wp, cb0 + j, sn_, 0, lane);                                                       \
+            W.wl[SJ][j] = chain_w_frag<D>(wp, cb0 + j, sn_, 1, lane);                                                       \
+        }                                                                                                                   \
+    }
 #pragma unroll 1
         for (int s0 = 0; s0 < NK16; s0 += WD) {
 #pragma unroll
-            for (int sj = 0; sj < WD; ++sj) SAPCU_CHAIN_STEP(s0 + sj, sj)
+            for (int sj = 0; sj < WD; ++sj) SAPCU_CHAIN_STEP_INPLACE(s0 + sj, sj)
         }
+#undef SAPCU_CHAIN_STEP_INPLACE
     }
 #undef SAPCU_CHAIN_STEP
 }
