@@ -24,6 +24,8 @@ def main():
         g = torch.Generator(device="cpu").manual_seed(0)
         patch = (torch.randn((B, M, 3), generator=g) * 0.05).to(dev)
         idx = torch.stack([torch.randperm(M, generator=g)[:kk] for _ in range(P)]).to(torch.int32).to(dev)
+        if os.environ.get("SAPCU_AB_ZERO_IDX"):        # every neighbour = point 0 of the patch: the k / v gathers always hit
+            idx.zero_()
         qkv = torch.rand((P, 3 * d), generator=g).to(dev)
 
         def lin(n, k, gain):
