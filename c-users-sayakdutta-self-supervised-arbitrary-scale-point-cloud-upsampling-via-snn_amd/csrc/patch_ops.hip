@@ -26,7 +26,7 @@ struct KnnOut {
 // Thread (bi, bj) of the 16 x 16 thread grid owns the BT x BT block of pairs (i, j), i in [bi*BT, bi*BT+BT), j likewise:
 // per channel it reads BT + BT values from LDS for BT*BT FMAs (one-pair-per-thread needed 2 reads per FMA and was bound
 // by LDS bandwidth in feature space, c = 64..256).  Every pair still sees ITS chain in ascending channel order, so the
-// scores are bit-identical.  BT = ceil(m / 16): 3 for the model's 48-point patches, up to 8 for m = 128.
+// scores are bit-identical.  BT = ceil(m / 16): 3 for the model's 48-point patches, 7 for the reference's default m = 100, up to 8.
 template <int BT>
 __global__ __launch_bounds__(256) void patch_knn_kernel(const float* __restrict__ feat, int64_t pstride, int m,
                                                         int c, int ld, const KnnOut out) {
@@ -95,44 +95,59 @@ __global__ __launch_bounds__(256) void patch_knn_kernel(const float* __restrict_
             }
         }
     __syncthreads();
-    // rank by counting: one wave per row, lane owns column lane (and lane + 64 when m > 64).  (score, index) pairs are compared as
-    // ONE 64-bit integer — key << 32 | ~index: greater = higher score, or equal score and lower index.  The row's keys sit in the
-    // lanes' registers; an inner iteration broadcasts one of them through a scalar register (v_readlane) and costs one 64-bit
-    // compare and one add per owned column (the float form took ~10 VALU instructions and an LDS read per pair, and this phase —
-    // m^3 compares per patch — is what bounds the kernel).
+    // rank by counting: one wave per row, lane owns column lane (and lane + 64 when m > 64); the row's keys sit in the lanes'
+    // registers and an inner iteration broadcasts one of them through a scalar register (v_readlane) — no LDS read — and costs
+    // one compare and one add per owned column (the float form took ~10 VALU instructions and an LDS read per pair; this phase,
+    // m^3 compares per patch, is what bounds the kernel).  Fast pass: 32-bit compares of the score keys alone.  Its ranks are a
+    // permutation exactly when the row has no two equal scores (tied columns do not count each other, so the ranks then sum to
+    // less than m (m - 1) / 2); otherwise the row is redone with (score, index) pairs compared as ONE 64-bit integer — key << 32 |
+    // ~index: greater = higher score, or equal score and lower index.
     const int lane = tid & 63, wave = tid >> 6;
+    const int full = m * (m - 1) / 2;
     for (int i = wave; i < m; i += 4) {
         const unsigned* row = K + i * (m + 1);
         const int j0 = lane, j1 = lane + 64;
         const unsigned key0 = j0 < m ? row[j0] : 0u, key1 = j1 < m ? row[j1] : 0u;
-        const unsigned long long k0 = ((unsigned long long)key0 << 32) | (unsigned)~j0;
-        const unsigned long long k1 = ((unsigned long long)key1 << 32) | (unsigned)~j1;
         int r0 = 0, r1 = 0;
         // chunks of 8 columns; columns >= m carry key 0, which is below every score's key, so padding a chunk is harmless
         if (m <= 64) {
             for (int jb = 0; jb < m; jb += 8) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int jp = jb + u;
-                    const unsigned long long kv = ((unsigned long long)__builtin_amdgcn_readlane(key0, jp) << 32) | (unsigned)~jp;
-                    r0 += kv > k0;
-                }
+                for (int u = 0; u < 8; ++u) r0 += (unsigned)__builtin_amdgcn_readlane(key0, jb + u) > key0;
             }
         } else {
             for (int jb = 0; jb < 64; jb += 8) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int jp = jb + u;
-                    const unsigned long long kv = ((unsigned long long)__builtin_amdgcn_readlane(key0, jp) << 32) | (unsigned)~jp;
-                    r0 += kv > k0;
-                    r1 += kv > k1;
+                    const unsigned kv = (unsigned)__builtin_amdgcn_readlane(key0, jb + u);
+                    r0 += kv > key0;
+                    r1 += kv > key1;
                 }
             }
             for (int jb = 64; jb < m; jb += 8) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
+                    const unsigned kv = (unsigned)__builtin_amdgcn_readlane(key1, jb + u - 64);
+                    r0 += kv > key0;
+                    r1 += kv > key1;
+                }
+            }
+        }
+        int tot = (j0 < m ? r0 : 0) + (j1 < m ? r1 : 0);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+        if (tot != full) {                              // (wave-uniform) equal scores in this row: exact (score, index) order
+            const unsigned long long k0 = ((unsigned long long)key0 << 32) | (unsigned)~j0;
+            const unsigned long long k1 = ((unsigned long long)key1 << 32) | (unsigned)~j1;
+            r0 = 0;
+            r1 = 0;
+            for (int jb = 0; jb < m; jb += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
                     const int jp = jb + u;
-                    const unsigned long long kv = ((unsigned long long)__builtin_amdgcn_readlane(key1, jp - 64) << 32) | (unsigned)~jp;
+                    const unsigned kk32 = jp < 64 ? (unsigned)__builtin_amdgcn_readlane(key0, jp & 63)
+                                                  : (unsigned)__builtin_amdgcn_readlane(key1, jp & 63);
+                    const unsigned long long kv = ((unsigned long long)kk32 << 32) | (unsigned)~jp;
                     r0 += kv > k0;
                     r1 += kv > k1;
                 }
@@ -159,14 +174,18 @@ int launch_patch_knn_multi(const float* feat, int64_t b, int64_t pstride, int m,
         if (t < ntab) SAPCU_CHECK_ARG(ks[t] >= 1 && ks[t] <= m && idx[t], "patch_knn: need 1<=k<=m (k=%d m=%d)", ks[t], m);
     }
     const int bt = (m + 15) / 16;                                   // 1..8
-    const int btk = bt <= 3 ? 3 : (bt <= 4 ? 4 : 8);
+    const int btk = bt <= 3 ? 3 : bt;                               // pair block per thread: 16 * btk >= m rows / columns
     const size_t lds = (size_t)(m * (m + 1) + m + 16 * btk * (PK_CH + 1)) * sizeof(float);
-    if (btk == 3)
-        hipLaunchKernelGGL(patch_knn_kernel<3>, dim3((unsigned)b), dim3(256), lds, st, feat, pstride, m, c, ld, out);
-    else if (btk == 4)
-        hipLaunchKernelGGL(patch_knn_kernel<4>, dim3((unsigned)b), dim3(256), lds, st, feat, pstride, m, c, ld, out);
-    else
-        hipLaunchKernelGGL(patch_knn_kernel<8>, dim3((unsigned)b), dim3(256), lds, st, feat, pstride, m, c, ld, out);
+#define SAPCU_PK(BT) hipLaunchKernelGGL(patch_knn_kernel<BT>, dim3((unsigned)b), dim3(256), lds, st, feat, pstride, m, c, ld, out)
+    switch (btk) {
+        case 3: SAPCU_PK(3); break;
+        case 4: SAPCU_PK(4); break;
+        case 5: SAPCU_PK(5); break;
+        case 6: SAPCU_PK(6); break;
+        case 7: SAPCU_PK(7); break;
+        default: SAPCU_PK(8); break;
+    }
+#undef SAPCU_PK
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
 }

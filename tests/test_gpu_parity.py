@@ -180,6 +180,32 @@ def test_patch_knn_xyz_exact_and_feature_space_flips():
           % (total_flips, total_rows, worst_ulps))
 
 
+def test_patch_knn_exact_ties_resolve_by_ascending_index():
+    """Rows with equal scores: the kernel ranks with 32-bit compares of the score keys first and redoes a row whose ranks are not a
+    permutation with (score, index) pairs — include/sapcu.h: "descending score, equal scores by ascending index".  xyz patches
+    with duplicated points (whole columns of the score matrix equal), m = 48 (one column per lane) and m = 100 (two), against a
+    stable sort of the oracle's scores (c = 3: the device scores equal torch's bit for bit)."""
+    from sapcu_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    for m, k in ((48, 24), (48, 48), (100, 32), (7, 7)):
+        b = 6
+        pts = rng.normal(size=(b, m, 3)).astype(np.float32)
+        for p in range(b):                                   # p duplicated pairs / triples per patch (patch 0: none)
+            for q in range(p):
+                src, dst = rng.integers(0, m, 2)
+                pts[p, dst] = pts[p, src]
+            if p == b - 1 and m > 3:
+                pts[p, 1] = pts[p, 0]
+                pts[p, m - 1] = pts[p, 0]                    # a triple
+        sc = O.inpatch_knn_scores(torch.from_numpy(np.ascontiguousarray(pts.transpose(0, 2, 1)))).numpy()     # [b,m,m]
+        want = np.argsort(-sc, axis=-1, kind="stable")[..., :k]
+        out = torch.empty((b, m, k), dtype=torch.int32, device=U.dev())
+        feat = _dev(pts)
+        _lib.check(lib.sapcu_patch_knn(_lib.ptr(feat), b, m, 3, 3, k, _lib.ptr(out), _lib.current_stream()))
+        assert np.array_equal(out.cpu().numpy().astype(np.int64), want), (m, k)
+
+
 # ------------------------------------------------------------------------------- GEMM
 def _run_gemm(a, w, bias, split):
     """split: False = exact-f32 MFMA kernel; True = split-f16 with f32 A; "ring" = split-f16 ring kernel (A as split rows)."""
