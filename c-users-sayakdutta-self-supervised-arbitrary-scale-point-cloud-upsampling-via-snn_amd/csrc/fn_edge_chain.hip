@@ -215,6 +215,15 @@ __device__ __forceinline__ void chain_put(unsigned char* X, const ChainLane<CB>&
     *reinterpret_cast<_Float16*>(p + PLANE) = (_Float16)(v - (float)hi);
 }
 
+// store_split (gemm_epi.h) with non-temporal stores: the result rows are streamed out once and must not push the weights and the
+// k / v rows out of L2 (measured at d = 512 together with the non-temporal q loads: 29 % fewer L2 misses per launch)
+__device__ __forceinline__ void chain_store_split_nt(float* base, int64_t row, int ld, int col, float v) {
+    _Float16* rp = reinterpret_cast<_Float16*>(base + row * ld);
+    const _Float16 hi = (_Float16)v;
+    __builtin_nontemporal_store(hi, &rp[split_hi_index(ld, col)]);
+    __builtin_nontemporal_store((_Float16)(v - (float)hi), &rp[split_lo_index(ld, col)]);
+}
+
 __device__ __forceinline__ NeuronP chain_lif(const float* __restrict__ lif, int d, int col) {
     NeuronP np;
     np.decay = clampf(lif[col], 0.1f, 0.99f);
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? 2 : 1)) void fn
 #pragma unroll
         for (int j = 0; j < CB; ++j)
 #pragma unroll
-            for (int p = 0; p < PPG; ++p) qp[j][p] = a.qkv[(pt0 + (p < npts ? p : 0)) * a.ldq + L.col[j]];
+            for (int p = 0; p < PPG; ++p) qp[j][p] = __builtin_nontemporal_load(&a.qkv[(pt0 + (p < npts ? p : 0)) * a.ldq + L.col[j]]);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int b = u / UPB, i = b / CB, j = b % CB, e0 = US * (u % UPB);
@@ -440,8 +449,8 @@ __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? 2 : 1)) void fn
                 for (int jj = 0; jj < KK; ++jj) out = __fmaf_rn(__fmul_rn(xs[jj], inv_den), ts[jj], out);
                 if (p < npts && (p & 1) == L.h) {          // both halves hold the result: each stores every other point
                     const int64_t pt = pt0 + p;
-                    if (a.res_split) store_split(a.res, pt, D, L.col[j], out);
-                    else a.res[pt * D + L.col[j]] = out;
+                    if (a.res_split) chain_store_split_nt(a.res, pt, D, L.col[j], out);
+                    else __builtin_nontemporal_store(out, &a.res[pt * D + L.col[j]]);
                 }
             }
         }
