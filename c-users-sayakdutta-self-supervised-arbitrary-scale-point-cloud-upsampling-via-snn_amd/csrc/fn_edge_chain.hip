@@ -10,22 +10,22 @@
 //
 // The unfused form (model.hip: fn_pe1 -> gemm<EPI_LIF_ATTN> -> gemm<EPI_LIF> -> gemm<EPI_BIAS> -> fn_softmax_agg) moves every
 // [rows, d] tensor through HBM: ten passes of rows*d*4 bytes per block.  Here a workgroup owns a GROUP of whole points
-// (floor(ROWS / kk) points; ROWS = 128 edge rows at d <= 256, 64 at d = 512) and keeps the group's activation panel in LDS
+// (floor(ROWS / kk) points; ROWS = 96 / 128 / 64 edge rows at d = 128 / 256 / 512) and keeps the group's activation panel in LDS
 // between the GEMMs, as the split-f16 A operand (hi | lo planes, [k32 step][plane][ROWS][32 halves], 16-byte chunks
 // XOR-swizzled by (row>>2)&3 — the operand-slot layout of gemm_sf16_bt.hip, so the fragment reads are the same conflict-free
 // ds_read_b128).  Nothing of the chain reaches HBM: the kernel reads xyz differences + neighbour rows (24 B per edge row), the
 // q / k / v rows of the patch (L2) and the pre-packed weights (L2), and writes res [points, d].
 //
 // Shape of the work.  d/32 waves per workgroup; wave w owns output columns 32w .. 32w+31 of all three GEMMs and all ROWS rows:
-// wave tile ROWS x 32 = 4 MFMA blocks of 32x32 (d = 512: d/64 waves, 64 x 64 = 4 blocks).  A wave's weight fragments are not shared with any other wave,
+// wave tile ROWS x 32 = 3 / 4 MFMA blocks of 32x32 (d = 512: d/64 waves, 64 x 64 = 4 blocks).  A wave's weight fragments are not shared with any other wave,
 // so they bypass LDS: pre-packed at model build in fragment order (one contiguous KiB per (column block, k16, plane)),
-// streamed L2 -> registers four (two) k16 steps ahead.  No barrier inside a GEMM; six workgroup barriers per group.
+// streamed L2 -> registers two k16 steps ahead.  No barrier inside a GEMM; six workgroup barriers per group.
 // The epilogues run in the accumulator layout (lane = column: bias and neuron parameters are per-lane constants; register
 // e of block i = row 32i + 8(e>>2) + 4h + (e&3)), pe stays in registers until the aggregation, the per-point softmax gets
 // its rows from the two lane halves with v_permlane32_swap and sums them in neighbour order — every value equals the
 // unfused chain's bit for bit (same split-f16 products in the same order, same neuron arithmetic, same softmax order).
-// d = 128: 256-thread workgroups, 67 KiB of LDS -> two per CU.  d = 256: 512 threads, 131 KiB, one per CU.  d = 512: 512
-// threads (wave tile 64 x 64), 131 KiB, a rolled k loop.  What bounds them (each pipe at its practical rate, the
+// d = 128: 256-thread workgroups, 51 KiB of LDS -> three per CU.  d = 256: 512 threads, 131 KiB, one per CU.  d = 512: 512
+// threads (wave tile 64 x 64), 131 KiB.  The k loops are rolled (two k16 steps per iteration).  What bounds them (each pipe at its practical rate, the
 // kernel time their sum) and the overlap designs that were measured without gain: DESIGN.md section 4.1c.
 #include "common.h"
 #include "gemm_epi.h"
@@ -34,16 +34,19 @@
 namespace sapcu {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-// Shape of a workgroup's work.  ROWS = MFMA rows per group: 128 for d = 128 / 256; 64 for d = 512 (a 128-row panel of 512 columns
-// would be 256 KiB).  One plane of one k32 step is [ROWS][32 halves]; a k32 step = hi plane | lo plane.  A wave owns CB column
-// blocks of 32 and all ROWS rows: RB x CB accumulator blocks, 256 registers per wave everywhere.  d = 128: CB = 1, two 4-wave
-// workgroups per CU; d = 256: CB = 1, one 8-wave workgroup; d = 512: CB = 2 (wave tile 64 x 64), one 8-wave workgroup — half
-// the LDS fragment reads of the 16-wave form and room for t = v + pe in registers (the 16-wave form, 128 registers per wave,
-// parked it in scratch: 10 GB of HBM traffic per step).  Measured at d = 512, ms per launch: 16 waves 17.3; 16 waves with the
-// weight ring refilled in place and unconditionally (exact wait counts in the rolled k loop) 17.2; 8 waves, same loop 16.6;
-// 8 waves, epilogue units of 8 elements 16.3.  (Before the wait counts were exact the 8-wave form lost: 18.4 against 17.6.)
+// Shape of a workgroup's work.  ROWS = MFMA rows per group = whole points: d = 128: 96 rows = 4 points of 24 neighbours (no idle
+// row; 51 KiB of LDS -> THREE 4-wave workgroups per CU, 168 registers per wave), d = 256: 128 rows = 7 points of 18 (one 8-wave
+// workgroup, 256 registers), d = 512: 64 rows = 5 points of 12 (a 128-row panel of 512 columns would be 256 KiB; one 8-wave
+// workgroup, 256 registers).  One plane of one k32 step is [ROWS][32 halves]; a k32 step = hi plane | lo plane.  A wave owns CB
+// column blocks of 32 and all ROWS rows: RB x CB accumulator blocks.  CB = 2 at d = 512 (wave tile 64 x 64): half the LDS
+// fragment reads of a 16-wave form and room for t = v + pe in registers (the 16-wave form, 128 registers per wave, parked it in
+// scratch: 10 GB of HBM traffic per step).  Measured, ms per launch at 4096 x 48 points — d = 512: 16 waves 17.3; 16 waves with
+// the weight ring refilled in place and unconditionally (exact wait counts in the rolled k loop) 17.2; 8 waves, same loop 16.6;
+// 8 waves, epilogue units of 8 elements 16.3 (before the wait counts were exact the 8-wave form lost: 18.4 against 17.6).
+// d = 256: fully unrolled k loop 8.27, rolled 8.10.  d = 128: 128-row groups (5 points + 8 idle rows), two workgroups per CU,
+// unrolled loop 4.64; 96-row groups, three per CU, rolled loop 4.42.
 template <int D> struct ChainShape {
-    static constexpr int ROWS = D <= 256 ? 128 : 64;
+    static constexpr int ROWS = D == 128 ? 96 : (D == 256 ? 128 : 64);
     static constexpr int RB = ROWS / 32;              // 32-row MFMA blocks per wave tile
     static constexpr int CB = D == 512 ? 2 : 1;       // 32-column blocks per wave
     static constexpr int NB = RB * CB;                // accumulator blocks per wave (block b: rows i = b / CB, columns j = b % CB)
@@ -51,9 +54,9 @@ template <int D> struct ChainShape {
     static constexpr int PLANE = ROWS * 64;
     static constexpr int KSTEP = 2 * PLANE;
     static constexpr int LDS = ROWS * D * 4 + ROWS * 16 + ROWS * 8;
-    static constexpr int US = 8;                      // elements per lane of one epilogue unit
-    static constexpr int WD = D <= 128 ? 4 : 2;       // weight fragments this many k16 steps ahead (x CB column blocks x hi, lo);
-                                                      // d >= 256: the rolled k loop's body is WD steps
+    static constexpr int US = D == 128 ? 4 : 8;       // elements per lane of one epilogue unit (d = 128: 168 registers per wave)
+    static constexpr int WD = 2;                      // weight fragments this many k16 steps ahead (x CB column blocks x hi, lo) = the
+                                                      // body of the rolled k loop
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -139,39 +142,9 @@ __device__ __forceinline__ void chain_gemm(const unsigned char* X, const half8* 
     for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
-    // one k16 step S; SJ = its slot of the weight ring (S % WD, a compile-time value in both loop forms below)
-#define SAPCU_CHAIN_STEP(S, SJ)                                                                                             \
-    {                                                                                                                       \
-        const int s_ = (S);                                                                                                 \
-        const unsigned ko = (unsigned)((s_ >> 1) * CH_KSTEP + ((((s_ & 1) * 2 + h) ^ sw) * 16));                            \
-        half8 ah[RB], al[RB], cwh[CB], cwl[CB];                                                                             \
-        _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                                                    \
-            ah[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048);                                                    \
-            al[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048 + CH_PLANE);                                         \
-        }                                                                                                                   \
-        _Pragma("unroll") for (int j = 0; j < CB; ++j) {                                                                    \
-            cwh[j] = W.wh[SJ][j];                                                                                           \
-            cwl[j] = W.wl[SJ][j];                                                                                           \
-            if (s_ + WD < NK16) { /* WD k16 steps ahead */                                                                  \
-                W.wh[SJ][j] = chain_w_frag<D>(wp, cb0 + j, s_ + WD, 0, lane);                                               \
-                W.wl[SJ][j] = chain_w_frag<D>(wp, cb0 + j, s_ + WD, 1, lane);                                               \
-            }                                                                                                               \
-        }                                                                                                                   \
-        /* per accumulator: a_lo.w_hi, a_hi.w_lo, a_hi.w_hi — the order of gemm_sf16_ring.hip / gemm_sf16_bt.hip */         \
-        _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                                      \
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b / CB], cwh[b % CB], acc[b], 0, 0, 0);                      \
-        _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                                      \
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / CB], cwl[b % CB], acc[b], 0, 0, 0);                      \
-        _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                                      \
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / CB], cwh[b % CB], acc[b], 0, 0, 0);                      \
-    }
-    if constexpr (D <= 128) {                              // 8 steps: fully unrolled (measured: d = 128 4.55 unrolled / 4.64 rolled, d = 256 8.27 / 8.10)
-#pragma unroll
-        for (int s = 0; s < NK16; ++s) SAPCU_CHAIN_STEP(s, s & (WD - 1))
-    } else {
-        // d = 256 / 512: 16 / 32 steps — a rolled loop of WD-step bodies keeps the weight ring's indices static without letting
-        // the scheduler hoist all the steps' operands
-        // ... and a ring slot is refilled BEHIND the MFMAs that read it (no copy of the fragments)
+    // One k16 step S; SJ = its slot of the weight ring (S % WD, a compile-time value: the loop is rolled with a body of WD steps,
+    // which keeps the ring's indices static without letting the scheduler hoist all the steps' operands).  A ring slot is refilled
+    // BEHIND the MFMAs that read it, in place (no copy of the fragments).
 #define SAPCU_CHAIN_STEP_INPLACE(S, SJ)                                                                                     \
     {                                                                                                                       \
         const int s_ = (S);                                                                                                 \
@@ -197,13 +170,11 @@ __device__ __forceinline__ void chain_gemm(const unsigned char* X, const half8* 
         }                                                                                                                   \
     }
 #pragma unroll 1
-        for (int s0 = 0; s0 < NK16; s0 += WD) {
+    for (int s0 = 0; s0 < NK16; s0 += WD) {
 #pragma unroll
-            for (int sj = 0; sj < WD; ++sj) SAPCU_CHAIN_STEP_INPLACE(s0 + sj, sj)
-        }
-#undef SAPCU_CHAIN_STEP_INPLACE
+        for (int sj = 0; sj < WD; ++sj) SAPCU_CHAIN_STEP_INPLACE(s0 + sj, sj)
     }
-#undef SAPCU_CHAIN_STEP
+#undef SAPCU_CHAIN_STEP_INPLACE
 }
 
 // write v (row = 32 i + 8 q + 4 h + u, k = this lane's column) into the panel as the split-f16 operand of the next GEMM
@@ -235,9 +206,9 @@ __device__ __forceinline__ NeuronP chain_lif(const float* __restrict__ lif, int 
     return np;
 }
 
-// threads = 64 x (d / 32 / CB).  d = 128: two 256-thread workgroups per CU
+// threads = 64 x (d / 32 / CB).  d = 128: three 256-thread workgroups per CU
 template <int D, int KK>
-__global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? 2 : 1)) void fn_edge_chain_kernel(const ChainArgs a) {
+__global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? 3 : 1)) void fn_edge_chain_kernel(const ChainArgs a) {
     using S = ChainShape<D>;
     constexpr int CH_ROWS = S::ROWS, RB = S::RB, CB = S::CB, NB = S::NB, CH_PLANE = S::PLANE, CH_KSTEP = S::KSTEP;
     constexpr int PPG = CH_ROWS / KK;                      // points per group
