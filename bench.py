@@ -226,8 +226,9 @@ def m100_leg(fn, fd, dev, cloud, seeds, steps=3):
             "unit": "query-points/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps}
 
 
-def cpu_baseline(sdn, sdd, sample=64):
-    """Oracle on `sample` of the same queries (kNN + fn + rotate + fd + displace), all host threads."""
+def cpu_baseline(sdn, sdd, sample=256):
+    """Oracle on `sample` of the same queries (kNN + fn + rotate + fd + displace), all host threads.  256 = ONE full chunk of the
+    reference's own batching (generate.py:135 batch_size=256), ~45 s on the GPU box's 16 host cores."""
     from sapcu_amd import testing as T
     from oracle import geom_path as G, snn_path as O
     fn_hp = dict(FN_KW)
@@ -249,7 +250,7 @@ def cpu_baseline(sdn, sdd, sample=64):
     G.upsample_core(cloud, q, fn_fwd, fd_fwd, M_PTS, sample, "fresh")
     dt = time.perf_counter() - t0
     return {"value": round(sample / dt, 3), "unit": "query-points/s", "cores": cores, "kind": "port",
-            "sample": "%d of the %d queries, one chunk, oracle (torch-CPU restatement), %.1f s" % (sample, B_PER_GPU, dt)}
+            "sample": "%d of the %d queries = one reference-sized chunk (generate.py:135 batch_size=256), oracle (torch-CPU restatement), %.1f s" % (sample, B_PER_GPU, dt)}
 
 
 def spawn_ranks(args):
@@ -300,9 +301,17 @@ def main():
     rehearse = os.environ.get("SAPCU_BENCH_REHEARSE") == "1"
     dev = torch.device("cuda", 0 if rehearse else local)
     torch.cuda.set_device(dev)
-    if world > 1:
+    # SAPCU_BENCH_NCCL1=1: the N = 1 run also builds the process group of the N > 1 runs (nccl = RCCL, device_id) and sends its
+    # barrier / all-gather / all-reduce through it — the RCCL contact a one-GPU box allows (tests/test_gpu_parity.py)
+    use_pg = world > 1 or os.environ.get("SAPCU_BENCH_NCCL1") == "1"
+    if use_pg:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -326,7 +335,7 @@ def main():
     def weak_step():
         with torch.no_grad():
             refined, _, _ = gen.refine(cloud, seeds)
-            if world > 1:
+            if use_pg:
                 refined = sdist.gather_refined(refined, B_PER_GPU * world)   # the one collective of the path
         return refined
 
@@ -335,14 +344,14 @@ def main():
         s, e = sdist.shard_range(n, rank, world)
         with torch.no_grad():
             refined, _, _ = gen.refine(cloud, all_seeds[s:e])
-            if world > 1:
+            if use_pg:
                 refined = sdist.gather_refined(refined, n)
         return refined
 
     step = strong_step if strong else weak_step
 
     def barrier():
-        if world > 1:
+        if use_pg:
             import torch.distributed as dist
             dist.barrier()
 
@@ -362,7 +371,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         assert torch.isfinite(out).all()
-        if world > 1:
+        if use_pg:
             import torch.distributed as dist
             tt = torch.tensor([dt], dtype=torch.float64, device=torch.device("cpu") if rehearse else dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -383,7 +392,7 @@ def main():
     if want_strong_leg and not strong:
         # one whole-cloud pass (385 582 seeds sharded over the ranks + the all-gather), after one untimed pass at N > 1 so
         # that RCCL's buffers for this message size exist
-        if world > 1:
+        if use_pg:
             strong_step()
         dts, outs = timed(strong_step, 1)
         strong_leg = {"seeds": int(all_seeds.shape[0]), "n_gpus": world, "ms_per_pass": round(dts * 1e3, 2),
@@ -415,6 +424,9 @@ def main():
         }
         if rehearse:
             line["rehearsal"] = True
+        if use_pg:
+            import torch.distributed as dist
+            line["collective_backend"] = dist.get_backend()
         if strong_leg:
             line["strong_scaling"] = strong_leg
         if not args.no_roofline:
@@ -430,7 +442,7 @@ def main():
     barrier()
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_pg:
         import torch.distributed as dist
         dist.destroy_process_group()
 

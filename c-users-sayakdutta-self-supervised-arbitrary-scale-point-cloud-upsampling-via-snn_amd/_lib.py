@@ -69,6 +69,7 @@ _SIGNATURES = {
     "sapcu_posenc_gemm_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                       c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "sapcu_model_gemm_mode": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "sapcu_model_fused_blocks": (c_int, [c_void_p, c_int, POINTER(c_int)]),
     "sapcu_fn_edge_chain_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
     "sapcu_fn_edge_chain_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int] + [c_void_p] * 12 + [c_int, c_int, c_void_p, c_void_p,
                                         c_int64, c_void_p]),

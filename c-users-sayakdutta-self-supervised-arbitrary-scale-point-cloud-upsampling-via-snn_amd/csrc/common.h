@@ -30,6 +30,41 @@ void set_error(const char* fmt, ...);
 
 #define SAPCU_CHECK_LAUNCH() SAPCU_CHECK_HIP(hipGetLastError())
 
+// Per-device, thread-safe launch state (include/sapcu.h promises concurrent forwards on different streams and host threads).
+//  * DeviceOnce: one bit per HIP device ordinal; `SAPCU_SET_MAX_LDS(once, kernel, bytes)` raises the kernel's dynamic-LDS limit
+//    on the CURRENT device the first time the kernel is launched there.  hipFuncSetAttribute is idempotent, so two threads
+//    racing through the first launch both set the same value; the bit is published after the call (release / acquire).
+//  * device_cu_count(): multiProcessorCount of the current device, cached per ordinal.
+struct DeviceOnce {
+    unsigned long long done[4] = {0, 0, 0, 0};      // 256 device ordinals
+    bool test(int dev) const { return (__atomic_load_n(&done[(dev >> 6) & 3], __ATOMIC_ACQUIRE) >> (dev & 63)) & 1ull; }
+    void set(int dev) { __atomic_fetch_or(&done[(dev >> 6) & 3], 1ull << (dev & 63), __ATOMIC_RELEASE); }
+};
+
+#define SAPCU_SET_MAX_LDS(once, kernel, bytes)                                                                          \
+    do {                                                                                                                \
+        int _dev = 0;                                                                                                   \
+        SAPCU_CHECK_HIP(hipGetDevice(&_dev));                                                                           \
+        if (!(once).test(_dev)) {                                                                                       \
+            SAPCU_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),                                  \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)));                  \
+            (once).set(_dev);                                                                                           \
+        }                                                                                                               \
+    } while (0)
+
+inline int device_cu_count() {
+    static int cus[256];                              // 0 = not read yet; written once per ordinal with the same value by any thread
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int v = __atomic_load_n(&cus[dev & 255], __ATOMIC_ACQUIRE);
+    if (v == 0) {
+        hipDeviceProp_t prop;
+        v = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        __atomic_store_n(&cus[dev & 255], v, __ATOMIC_RELEASE);
+    }
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Neuron arithmetic.  Every product/sum is an explicitly rounded f32 operation in the op order of
 // fn/snn_coder.py:125-146 (ATen evaluates each Python operator as its own rounded kernel), so the
@@ -385,7 +420,7 @@ int launch_gemm_sf16(const GemmArgs& g, hipStream_t st);   // 3 x f16 MFMA, f32-
 int launch_gemm_sf16_ring(const GemmArgs& g, hipStream_t st);   // same arithmetic, A in split rows, 4-slot LDS-DMA ring
 int launch_gemm_sf16_bt(const GemmArgs& g, hipStream_t st);     // same arithmetic and results, 256 x 256/128 tiles (gemm_sf16_bt.hip)
 bool gemm_sf16_bt_ok(const GemmArgs& g);                        // ... for the shapes / epilogues it takes
-int launch_gemm_split_rows(const GemmArgs& g, hipStream_t st);  // picks between the two (model.hip; SAPCU_BT=0/1)
+int launch_gemm_split_rows(const GemmArgs& g, hipStream_t st, bool allow_bt = true);  // picks between the two (model.hip; allow_bt = false: ring only)
 int launch_split_weights(const float* w, int64_t count, void* hi, void* lo, int* ovf, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------

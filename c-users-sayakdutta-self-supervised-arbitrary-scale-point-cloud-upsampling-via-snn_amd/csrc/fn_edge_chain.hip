@@ -431,12 +431,8 @@ __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? 3 : 1)) void fn
 template <int D, int KK>
 static int launch_chain_t(const ChainArgs& a, hipStream_t st) {
     constexpr int lds = ChainShape<D>::LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SAPCU_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fn_edge_chain_kernel<D, KK>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    static DeviceOnce lds_once;                         // one per kernel instantiation, one bit per device
+    SAPCU_SET_MAX_LDS(lds_once, (&fn_edge_chain_kernel<D, KK>), lds);
     constexpr int PPG = ChainShape<D>::ROWS / KK;
     const int64_t ngroups = (a.P + PPG - 1) / PPG;
     const int64_t grid = ngroups < 8 ? ngroups : ((ngroups + 7) / 8) * 8;      // 8 XCD ranges of equal slot count

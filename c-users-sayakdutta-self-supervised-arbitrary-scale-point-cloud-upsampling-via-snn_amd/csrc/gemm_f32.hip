@@ -253,23 +253,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmArgs g) {
     }
 }
 
-static int g_num_cus = 0;
-
 template <int EPI>
 static int launch_t(const GemmArgs& g, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        SAPCU_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
-    }
-    if (g_num_cus == 0) {
-        int dev = 0;
-        SAPCU_CHECK_HIP(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        SAPCU_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    static DeviceOnce lds_once;                         // one per kernel instantiation, one bit per device
+    SAPCU_SET_MAX_LDS(lds_once, (&gemm_kernel<EPI>), LDS_BYTES);
+    const int g_num_cus = device_cu_count();
     const int64_t tiles = ((g.r + BM - 1) / BM) * ((g.n + BN - 1) / BN);
     const int64_t grid = tiles < g_num_cus ? tiles : g_num_cus;
     hipLaunchKernelGGL((gemm_kernel<EPI>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, g);

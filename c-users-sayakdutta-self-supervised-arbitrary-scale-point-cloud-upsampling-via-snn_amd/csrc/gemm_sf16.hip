@@ -329,23 +329,11 @@ int launch_split_weights(const float* w, int64_t count, void* hi, void* lo, int*
     return SAPCU_OK;
 }
 
-static int g_num_cus16 = 0;
-
 template <int EPI>
 static int launch_t16(const GemmArgs& g, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        SAPCU_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sf16_kernel<EPI>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, SF16_LDS_BYTES));
-        attr_set = true;
-    }
-    if (g_num_cus16 == 0) {
-        int dev = 0;
-        SAPCU_CHECK_HIP(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        SAPCU_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        g_num_cus16 = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    static DeviceOnce lds_once;                         // one per kernel instantiation, one bit per device
+    SAPCU_SET_MAX_LDS(lds_once, (&gemm_sf16_kernel<EPI>), SF16_LDS_BYTES);
+    const int g_num_cus16 = device_cu_count();
     const int64_t tiles = ((g.r + SBM - 1) / SBM) * ((g.n + SBN - 1) / SBN);
     const int64_t grid = tiles < g_num_cus16 ? tiles : g_num_cus16;
     hipLaunchKernelGGL((gemm_sf16_kernel<EPI>), dim3((unsigned)grid), dim3(1024), SF16_LDS_BYTES, st, g);

@@ -435,24 +435,12 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
     }
 }
 
-static int g_num_cus_bt = 0;
-
 template <int EPI, int BN>
 static int launch_bt_t(const GemmArgs& g, hipStream_t st) {
     constexpr int LDS = TA_SLOTS * TA_SLOT + TW_SLOTS * 2 * BN * TBK * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SAPCU_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bt_kernel<EPI, BN>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
-    if (g_num_cus_bt == 0) {
-        int dev = 0;
-        SAPCU_CHECK_HIP(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        SAPCU_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        g_num_cus_bt = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    static DeviceOnce lds_once;                         // one per kernel instantiation, one bit per device
+    SAPCU_SET_MAX_LDS(lds_once, (&gemm_bt_kernel<EPI, BN>), LDS);
+    const int g_num_cus_bt = device_cu_count();
     const int64_t tiles = ((g.r + TBM - 1) / TBM) * (g.n / BN);
     const int64_t grid = tiles < g_num_cus_bt ? tiles : g_num_cus_bt;
     hipLaunchKernelGGL((gemm_bt_kernel<EPI, BN>), dim3((unsigned)grid), dim3(512), LDS, st, g);

@@ -366,23 +366,11 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
     }
 }
 
-static int g_num_cus_ring = 0;
-
 template <int EPI, bool VEC>
 static int launch_ring_tv(const GemmArgs& g, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        SAPCU_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<EPI, VEC>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES));
-        attr_set = true;
-    }
-    if (g_num_cus_ring == 0) {
-        int dev = 0;
-        SAPCU_CHECK_HIP(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        SAPCU_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        g_num_cus_ring = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    static DeviceOnce lds_once;                         // one per kernel instantiation, one bit per device
+    SAPCU_SET_MAX_LDS(lds_once, (&gemm_ring_kernel<EPI, VEC>), RING_LDS_BYTES);
+    const int g_num_cus_ring = device_cu_count();
     const int row_step = RBM;
     const int64_t tiles = ((g.r + row_step - 1) / row_step) * ((g.n + RBN - 1) / RBN);
     const int64_t grid = tiles < g_num_cus_ring ? tiles : g_num_cus_ring;

@@ -89,6 +89,13 @@ struct sapcu_model {
     int emb, T, heads;
     int64_t chunk;             // patches per chunk: SAPCU_CHUNK, or 0 = from the workspace budget (ws_budget bytes per forward)
     int64_t ws_budget;
+    // parity / ablation switches, read from the environment ONCE, at sapcu_model_create (a handle is immutable afterwards: a
+    // forward never calls getenv; tests build a second handle under another environment instead of flipping it mid-process)
+    bool opt_bt;               // SAPCU_BT=0: split-row GEMMs on the ring kernel only
+    bool opt_chain;            // SAPCU_CHAIN=0: fn blocks as the five-kernel edge chain
+    bool opt_fn_maxfuse;       // SAPCU_FN_MAXFUSE=0: conv_final GEMM + rowgroup_max
+    bool opt_fd_maxfuse;       // SAPCU_FD_MAXFUSE=0: multi_scale_conv GEMM + rowgroup_max
+    bool opt_fd_split;         // SAPCU_FD_SPLIT=0: fd spikes as f32 rows for every step
     float* blob;
     int64_t blob_floats;
     std::vector<int64_t> dir;
@@ -112,16 +119,19 @@ struct Arena {
 static inline int64_t imax(int64_t a, int64_t b) { return a > b ? a : b; }
 static inline int imin(int a, int b) { return a < b ? a : b; }
 
-// GEMM on split rows: the big-tile kernel for the shapes it takes (SAPCU_BT=0 keeps everything on the ring kernel; the two
-// are bit-identical), else the 128x128 ring kernel.
-static bool split_rows_gemm_on_big_tile(const GemmArgs& g) {
-    const char* e = getenv("SAPCU_BT");                 // read per call: the parity test flips it inside one process
-    return !(e && strcmp(e, "0") == 0) && gemm_sf16_bt_ok(g);
+// GEMM on split rows: the big-tile kernel for the shapes it takes (allow_bt = false — a handle created under SAPCU_BT=0, or a raw
+// entry point asked for the ring kernel — keeps everything on the ring kernel; the two are bit-identical), else the 128x128
+// ring kernel.
+static bool split_rows_gemm_on_big_tile(const GemmArgs& g, bool allow_bt) { return allow_bt && gemm_sf16_bt_ok(g); }
+
+int launch_gemm_split_rows(const GemmArgs& g, hipStream_t st, bool allow_bt) {
+    if (split_rows_gemm_on_big_tile(g, allow_bt)) return launch_gemm_sf16_bt(g, st);
+    return launch_gemm_sf16_ring(g, st);
 }
 
-int launch_gemm_split_rows(const GemmArgs& g, hipStream_t st) {
-    if (split_rows_gemm_on_big_tile(g)) return launch_gemm_sf16_bt(g, st);
-    return launch_gemm_sf16_ring(g, st);
+static bool env_off(const char* name) {
+    const char* e = getenv(name);
+    return e && strcmp(e, "0") == 0;
 }
 
 // Route a GEMM to the split-f16 kernel when the model carries pre-split weights, else to the f32 MFMA kernel.
@@ -132,7 +142,7 @@ static int run_gemm(const sapcu_model* m, GemmArgs& g, hipStream_t st) {
         g.w16_hi = (const _Float16*)m->w16_hi + off;
         g.w16_lo = (const _Float16*)m->w16_lo + off;
         g.ovf = m->ovf_dev;
-        if (g.a_split) return launch_gemm_split_rows(g, st);         // A already split by its producer: all-DMA kernels
+        if (g.a_split) return launch_gemm_split_rows(g, st, m->opt_bt);   // A already split by its producer: all-DMA kernels
         if (g.k % 64 == 0) return launch_gemm_sf16(g, st);
     }
     if (g.a_split || g.c_split || g.c2_split) {
@@ -174,11 +184,10 @@ struct FnPlan {
     int64_t edge_floats, edge_floats23;   // per-chunk size of edge buffer 1 (also conv_final's output) and of buffers 2, 3
 };
 
-// does block l run its edge chain fused (fn_edge_chain.hip)?  Decided per call (SAPCU_CHAIN is read per call: the parity tests
-// flip it inside one process); the workspace plan and the forward use the same answer.
+// does block l run its edge chain fused (fn_edge_chain.hip)?  The workspace plan and the forward use the same answer
+// (SAPCU_CHAIN=0 at model creation keeps the five-kernel chain).
 static bool fn_block_fused(const sapcu_model* m, int l, int mp) {
-    const char* che = getenv("SAPCU_CHAIN");
-    return m->sf16 && m->chain_w && fn_edge_chain_ok(128 << l, imin(m->kv[l], mp)) && !(che && strcmp(che, "0") == 0);
+    return m->sf16 && m->chain_w && m->opt_chain && fn_edge_chain_ok(128 << l, imin(m->kv[l], mp));
 }
 
 // floats of one [rows, d] edge buffer per patch: only the unfused blocks materialise edge tensors; buffer 1 also holds
@@ -372,8 +381,7 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
             ldin = 192;
         }
         // conv_final + LIF x T_enc, max over points, fc_out                          fn:465-475
-        const char* fmx = getenv("SAPCU_FN_MAXFUSE");          // read per call: the parity test flips it inside one process
-        if (m->sf16 && !(fmx && strcmp(fmx, "0") == 0)) {
+        if (m->sf16 && m->opt_fn_maxfuse) {
             // the max over the patch's points inside the GEMM's epilogue (integer atomicMax on order-preserving keys, as fd's
             // multi_scale_conv): the [P, emb] activation is never written.  Keys live at the head of the unused B1 area.
             GemmArgs g;
@@ -407,15 +415,26 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
 struct FdPlan {
     int64_t cb;
     int kmax0, kk;
+    bool maxfuse;              // multi_scale_conv's max over points inside the GEMM: the [T*P, emb] aggregate is never written
+    int64_t agg_rows(int mp) const { return maxfuse ? 1 : mp; }   // rows of the AGG area per (step, patch): keys only, or the aggregate
 };
+
+// does the encoder run as ONE LDS-resident kernel per patch (fd_encoder.hip)?  Same answer for the workspace plan and the forward.
+static bool fd_encoder_fused(const sapcu_model* m, int mp) {
+    (void)m; (void)mp;
+    return false;
+}
 
 static FdPlan fd_plan(const sapcu_model* m, int64_t b, int mp) {
     FdPlan pl;
-    // fd intermediates: T x (960 spikes + emb aggregate) + 1024 + block-0 features per point, neighbour tables
+    pl.maxfuse = m->sf16 && m->opt_fd_maxfuse;
+    // fd intermediates: T x 960 spikes (+ the T x emb aggregate per point only when the max is NOT taken inside the GEMM) + 960 +
+    // 1024 + block-0 features per point, neighbour tables
     int kmax0 = 1;
     for (int i = 0; i < m->nscale; ++i) kmax0 = kmax0 > m->ks[i] ? kmax0 : m->ks[i];
-    const int64_t per_patch = (int64_t)mp * (((int64_t)m->T * (960 + m->emb) + 960 + 1024 + 64 * (m->nscale + 1)) * 4 +
+    const int64_t per_patch = (int64_t)mp * (((int64_t)m->T * 960 + 960 + 1024 + 64 * (m->nscale + 1)) * 4 +
                                             (int64_t)(imin(kmax0, mp) + 3 * imin(m->k, mp)) * 4) +
+                              (int64_t)m->T * pl.agg_rows(mp) * m->emb * 4 +
                               ((int64_t)(m->T + 1) * m->emb + 256 + 3 * 128 + 3 * 64 + 192 + 64) * 4;
     pl.cb = chunk_patches(m, b, per_patch);
     int kmax = 1;
@@ -432,7 +451,7 @@ static int64_t fd_ws_bytes(const sapcu_model* m, int64_t b, int mp) {
     auto add = [&](int64_t n, int64_t esz) { fl += ((n * esz) + 255) & ~(int64_t)255; };
     add(P * pl.kmax0, 4); add(3 * P * pl.kk, 4);
     add(P * 64 * m->nscale, 4); add(P * 64, 4);
-    add((int64_t)m->T * P * 960, 4); add(P * 960, 4); add(P * 1024, 4); add((int64_t)m->T * P * m->emb, 4);
+    add((int64_t)m->T * P * 960, 4); add(P * 960, 4); add(P * 1024, 4); add((int64_t)m->T * pl.cb * pl.agg_rows(mp) * m->emb, 4);
     add((int64_t)m->T * pl.cb * m->emb, 4); add(pl.cb * m->emb, 4);
     add(pl.cb * 256, 4);
     for (int i = 0; i < 3; ++i) add(pl.cb * 128, 4);
@@ -461,7 +480,7 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
         float* SPK = A.take<float>((int64_t)T * pl.cb * mp * 960);
         float* F0 = A.take<float>(pl.cb * mp * 960);
         float* AB = A.take<float>(pl.cb * mp * 1024);
-        float* AGG = A.take<float>((int64_t)T * pl.cb * mp * emb);
+        float* AGG = A.take<float>((int64_t)T * pl.cb * pl.agg_rows(mp) * emb);       // maxfuse: T*cb*emb keys only
         float* POOLED = A.take<float>((int64_t)T * pl.cb * emb);
         float* ENC = A.take<float>(pl.cb * emb);
         float* D1 = A.take<float>(pl.cb * 256);
@@ -490,16 +509,14 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
         memset(&mg, 0, sizeof(mg));
         mg.a = SPK; mg.r = (int64_t)T * P; mg.k = 960; mg.lda = 960; mg.w = m->p(FD_MSC_W); mg.n = emb; mg.bias = m->p(FD_MSC_B);
         mg.c = nullptr; mg.ldc = emb; mg.epi = EPI_LRELU_MAX; mg.max_keys = reinterpret_cast<unsigned*>(AGG); mg.max_m = mp;
-        const char* mxe = getenv("SAPCU_FD_MAXFUSE");        // read per call: the parity tests flip these inside one process
-        const char* spe = getenv("SAPCU_FD_SPLIT");
-        const bool maxfuse = m->sf16 && !(mxe && strcmp(mxe, "0") == 0);
+        const bool maxfuse = pl.maxfuse;
         bool split_spikes = false;
-        if (maxfuse && !(spe && strcmp(spe, "0") == 0) && !(taps && taps[SAPCU_FD_TAP_SPIKES])) {
+        if (maxfuse && m->opt_fd_split && !(taps && taps[SAPCU_FD_TAP_SPIKES])) {
             GemmArgs probe = mg;
             probe.a_split = 1;
             probe.w16_hi = (const _Float16*)m->w16_hi + (mg.w - m->blob);
             probe.w16_lo = (const _Float16*)m->w16_lo + (mg.w - m->blob);
-            split_spikes = split_rows_gemm_on_big_tile(probe);     // (the ring kernel has no max-over-rows epilogue)
+            split_spikes = split_rows_gemm_on_big_tile(probe, m->opt_bt);     // (the ring kernel has no max-over-rows epilogue)
         }
         float* const SPKS = split_spikes ? SPK : nullptr;       // [T*P, 960] split rows (same buffer, other format)
         float* const SPK0 = split_spikes ? F0 : SPK;            // where the step-0 f32 spikes live ([P, 960] slab)
@@ -674,7 +691,8 @@ int sapcu_gemm_f32(const float* a, int64_t r, int k, int lda, const float* w, in
     g.a_split = a_split_rows ? 1 : 0; g.c_split = c_split_rows ? 1 : 0;
     if (w16_ws && (g.a_split || k % 64 == 0)) {   // f32-A split-f16 kernel steps k by 64; other depths run on exact f32
         SAPCU_TRY(split_into_ws(w, (int64_t)n * k, w16_ws, g, (hipStream_t)stream));
-        return g.a_split ? launch_gemm_split_rows(g, (hipStream_t)stream) : launch_gemm_sf16(g, (hipStream_t)stream);
+        // a_split_rows = 2: the ring kernel even where the big-tile kernel takes the shape (bit-identical; parity tests)
+        return g.a_split ? launch_gemm_split_rows(g, (hipStream_t)stream, a_split_rows != 2) : launch_gemm_sf16(g, (hipStream_t)stream);
     }
     SAPCU_CHECK_ARG(!g.c_split, "gemm: split-row output needs k %% 64 == 0 on the f32-A path");
     return launch_gemm(g, (hipStream_t)stream);
@@ -703,7 +721,7 @@ int sapcu_posenc_gemm_f32(const float* pe1, int64_t r, int d, const float* w, co
         if (split_rows) {     // the production form: pe1 arrives as split rows, attn_in leaves as split rows
             g.a_split = 1;
             g.c2_split = 1;
-            return launch_gemm_split_rows(g, (hipStream_t)stream);
+            return launch_gemm_split_rows(g, (hipStream_t)stream, split_rows != 2);     // split_rows = 2: ring kernel only
         }
         return launch_gemm_sf16(g, (hipStream_t)stream);
     }
@@ -776,6 +794,11 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
     m->ovf_dev = nullptr;
     const char* ge = getenv("SAPCU_GEMM");
     m->sf16 = !(ge && strcmp(ge, "f32") == 0);
+    m->opt_bt = !env_off("SAPCU_BT");
+    m->opt_chain = !env_off("SAPCU_CHAIN");
+    m->opt_fn_maxfuse = !env_off("SAPCU_FN_MAXFUSE");
+    m->opt_fd_maxfuse = !env_off("SAPCU_FD_MAXFUSE");
+    m->opt_fd_split = !env_off("SAPCU_FD_SPLIT");
     const char* ce = getenv("SAPCU_CHUNK");
     m->chunk = ce ? atoll(ce) : 0;
     if (m->chunk < 0) m->chunk = 0;
@@ -920,6 +943,19 @@ int sapcu_model_gemm_mode(sapcu_model_t m, int* split_f16_host, int* range_overf
     *split_f16_host = m->sf16 ? 1 : 0;
     *range_overflows_host = 0;
     if (m->ovf_dev) SAPCU_CHECK_HIP(hipMemcpy(range_overflows_host, m->ovf_dev, sizeof(int), hipMemcpyDeviceToHost));
+    return SAPCU_OK;
+}
+
+int sapcu_model_fused_blocks(sapcu_model_t m, int m_pts, int* mask_host) {
+    SAPCU_CHECK_ARG(m && mask_host && m_pts >= 1 && m_pts <= 128, "fused_blocks: bad argument");
+    int mask = 0;
+    if (m->kind == SAPCU_KIND_FN) {
+        for (int l = 0; l < 3; ++l)
+            if (fn_block_fused(m, l, m_pts)) mask |= 1 << l;
+    } else if (fd_encoder_fused(m, m_pts)) {
+        mask = 1;
+    }
+    *mask_host = mask;
     return SAPCU_OK;
 }
 

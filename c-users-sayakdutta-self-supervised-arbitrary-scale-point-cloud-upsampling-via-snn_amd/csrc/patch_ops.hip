@@ -176,7 +176,13 @@ int launch_patch_knn_multi(const float* feat, int64_t b, int64_t pstride, int m,
     const int bt = (m + 15) / 16;                                   // 1..8
     const int btk = bt <= 3 ? 3 : bt;                               // pair block per thread: 16 * btk >= m rows / columns
     const size_t lds = (size_t)(m * (m + 1) + m + 16 * btk * (PK_CH + 1)) * sizeof(float);
-#define SAPCU_PK(BT) hipLaunchKernelGGL(patch_knn_kernel<BT>, dim3((unsigned)b), dim3(256), lds, st, feat, pstride, m, c, ld, out)
+    // m > ~110 needs more than the default 64 KiB of dynamic LDS (m = 128: 83 KiB): raised once per device
+#define SAPCU_PK(BT)                                                                                                  \
+    do {                                                                                                              \
+        static DeviceOnce once;                                                                                       \
+        if (lds > 65536) SAPCU_SET_MAX_LDS(once, (&patch_knn_kernel<BT>), 98304);                                      \
+        hipLaunchKernelGGL(patch_knn_kernel<BT>, dim3((unsigned)b), dim3(256), lds, st, feat, pstride, m, c, ld, out); \
+    } while (0)
     switch (btk) {
         case 3: SAPCU_PK(3); break;
         case 4: SAPCU_PK(4); break;

@@ -184,8 +184,16 @@ int64_t sapcu_wgrad_bf16_workspace_bytes(int64_t rows, int n, int k) {
 
 int sapcu_conv1x1_wgrad_bf16(const float* grad_y, int ldy, const float* x, int ldx, int64_t rows, int n, int k, float* grad_w,
                              float* grad_bias, void* workspace, int64_t workspace_bytes, void* stream) {
-    SAPCU_CHECK_ARG(grad_y && x && grad_w && rows >= 1 && n >= 1 && k >= 1 && ldy >= n && ldx >= k, "wgrad_bf16: bad argument");
+    SAPCU_CHECK_ARG(grad_y && x && grad_w && rows >= 0 && n >= 1 && k >= 1 && ldy >= n && ldx >= k, "wgrad_bf16: bad argument");
+    if (rows == 0) {        // an empty batch: zero gradients (sapcu_gemm_bf16 accepts r == 0 too, so forward and backward agree)
+        SAPCU_CHECK_HIP(hipMemsetAsync(grad_w, 0, (size_t)n * k * sizeof(float), (hipStream_t)stream));
+        if (grad_bias) SAPCU_CHECK_HIP(hipMemsetAsync(grad_bias, 0, (size_t)n * sizeof(float), (hipStream_t)stream));
+        return SAPCU_OK;
+    }
     const int64_t slabs = (rows + BF_WGRAD_SLAB - 1) / BF_WGRAD_SLAB;
+    const int64_t cslabs_chk = (rows + BF_COLSUM_SLAB - 1) / BF_COLSUM_SLAB;
+    SAPCU_CHECK_ARG(slabs <= 65535 && cslabs_chk <= 65535, "wgrad_bf16: %lld rows exceed the grid limit (65535 slabs of %d rows)",
+                    (long long)rows, (int)BF_WGRAD_SLAB);
     if (workspace_bytes < sapcu_wgrad_bf16_workspace_bytes(rows, n, k) || !workspace) {
         set_error("wgrad_bf16: workspace %lld B < required %lld B", (long long)workspace_bytes,
                   (long long)sapcu_wgrad_bf16_workspace_bytes(rows, n, k));

@@ -642,8 +642,13 @@ int sapcu_bn_train_backward(const float* y, const float* grad_z, int64_t rows, i
 
 int sapcu_conv1x1_wgrad_f32(const float* grad_y, int ldy, const float* x, int ldx, int64_t rows, int n, int k, float* grad_w,
                             float* grad_bias, void* workspace, int64_t workspace_bytes, void* stream) {
-    SAPCU_CHECK_ARG(grad_y && x && grad_w && workspace && rows >= 1 && n >= 1 && k >= 1 && ldy >= n && ldx >= k,
-                    "conv1x1_wgrad: bad argument");
+    SAPCU_CHECK_ARG(grad_y && x && grad_w && rows >= 0 && n >= 1 && k >= 1 && ldy >= n && ldx >= k, "conv1x1_wgrad: bad argument");
+    if (rows == 0) {        // an empty batch: zero gradients (the forward GEMMs accept r == 0 as well)
+        SAPCU_CHECK_HIP(hipMemsetAsync(grad_w, 0, (size_t)n * k * sizeof(float), (hipStream_t)stream));
+        if (grad_bias) SAPCU_CHECK_HIP(hipMemsetAsync(grad_bias, 0, (size_t)n * sizeof(float), (hipStream_t)stream));
+        return SAPCU_OK;
+    }
+    SAPCU_CHECK_ARG(workspace != nullptr, "conv1x1_wgrad: null workspace");
     SAPCU_CHECK_ARG(workspace_bytes >= sapcu_train_workspace_bytes(rows, n, k), "conv1x1_wgrad: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     if (grad_bias) {                                   // db = column sums of dY (needs a dense dY for the shared reduction)

@@ -244,13 +244,17 @@ class GraphedTrainStep:
         model, opt = tr.model, tr.optimizer
         model.train()
 
+        precision = "bf16" if tr.use_amp else "f32"          # the same GEMM arithmetic as Trainer.train_step (warm-up AND capture)
+        self.gemm_precision = precision
+
         def core():
             opt.zero_grad(set_to_none=True)
             gtn = F.normalize(self.gt, dim=-1)
-            pred = F.normalize(model(self.pts), dim=-1)
-            xyz = self.pts.mean(dim=2) if self.pts.ndim == 4 else self.pts
-            loss, conf = T.angular_loss_with_consistency(pred, gtn, xyz)
-            loss.backward()
+            with T.gemm_precision(precision):
+                pred = F.normalize(model(self.pts), dim=-1)
+                xyz = self.pts.mean(dim=2) if self.pts.ndim == 4 else self.pts
+                loss, conf = T.angular_loss_with_consistency(pred, gtn, xyz)
+                loss.backward()
             if tr.grad_clip is not None and tr.grad_clip_type == 'norm':
                 total = torch.nn.utils.clip_grad_norm_(model.parameters(), tr.grad_clip, foreach=True)
             else:

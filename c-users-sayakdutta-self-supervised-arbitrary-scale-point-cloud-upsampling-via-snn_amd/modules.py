@@ -121,6 +121,15 @@ class _HipModel(nn.Module):
         _lib.check(_lib.load().sapcu_model_gemm_mode(self._engine(), ctypes.byref(a), ctypes.byref(b)))
         return bool(a.value), b.value
 
+    def fused_blocks(self, m_pts):
+        """Bit mask of the stages that run as fused LDS-resident kernels for patches of `m_pts` points (sapcu.h
+        sapcu_model_fused_blocks): fn bit l = transformer block l+1 on csrc/fn_edge_chain.hip — only for the reference's
+        (d, k) pairs (128, 24), (256, 18), (512, 12), other k_values or patches smaller than k run the five-kernel chain;
+        fd bit 0 = the whole encoder on csrc/fd_encoder.hip.  Speed and workspace differ, results do not."""
+        mask = ctypes.c_int(0)
+        _lib.check(_lib.load().sapcu_model_fused_blocks(self._engine(), int(m_pts), ctypes.byref(mask)))
+        return mask.value
+
     @staticmethod
     def _taps_array(names, taps):
         if not taps:

@@ -187,7 +187,11 @@ int sapcu_patch_knn(const float* feat, int64_t b, int m, int c, int ld, int k, i
  * blob: packed f32 parameters on the device (BatchNorm folded, see sapcu_amd/packing.py);
  * dir_host: int64 offsets (in floats) into blob, one per slot of the kind's slot table
  * (SAPCU_FN_SLOTS / SAPCU_FD_SLOTS entries, order fixed by packing.py and model.hip).
- * The library copies the blob; the caller may free it after the call returns. */
+ * The library copies the blob; the caller may free it after the call returns.
+ * A handle is immutable after creation: the environment switches (SAPCU_GEMM=f32, SAPCU_CHUNK, SAPCU_WS_BUDGET_MB and the
+ * parity / ablation switches SAPCU_BT, SAPCU_CHAIN, SAPCU_FN_MAXFUSE, SAPCU_FD_MAXFUSE, SAPCU_FD_SPLIT, SAPCU_FD_FUSED = 0) are
+ * read HERE, once; a forward never reads the environment.  Forwards of one handle (or of several) may run concurrently on
+ * different streams / host threads as long as each has its own workspace; launch attributes are set once per device. */
 int sapcu_model_create(int kind, const int32_t* hparams_host, int n_hparams, const float* blob,
                        int64_t blob_floats, const int64_t* dir_host, int n_dir, sapcu_model_t* out);
 int sapcu_model_destroy(sapcu_model_t m);
@@ -241,9 +245,16 @@ int sapcu_model_gate_violations(sapcu_model_t m, int* count_host);
 
 /* Which GEMM kernels the handle uses (1 = split-f16: every f32 operand as hi + lo*2^-11 halves, three f16
  * MFMAs per product, f32-quality results at 5.3x the f32-MFMA rate; 0 = exact-f32 MFMA, selected by the
- * environment variable SAPCU_GEMM=f32 or automatically when a parameter exceeds the f16 range), and how
+ * environment variable SAPCU_GEMM=f32 at sapcu_model_create or automatically when a parameter exceeds the f16 range), and how
  * many activation tiles exceeded the f16 range in forwards so far (must be 0).  Synchronises the device. */
 int sapcu_model_gemm_mode(sapcu_model_t m, int* split_f16_host, int* range_overflows_host);
+
+/* Which stages of the handle run as fused LDS-resident kernels for patches of m_pts points (no device work):
+ * fn: bit l (0..2) of *mask_host set = transformer block l+1 runs csrc/fn_edge_chain.hip (else the five-kernel chain);
+ * fd: bit 0 set = the encoder (blocks 0-3 + multi_scale_conv) runs csrc/fd_encoder.hip (else the per-stage kernels through HBM).
+ * The choice depends on the hyper-parameters, on m_pts and on the switches read at sapcu_model_create (SAPCU_CHAIN=0,
+ * SAPCU_FD_FUSED=0, SAPCU_GEMM=f32 disable them); it changes speed and workspace size, not results. */
+int sapcu_model_fused_blocks(sapcu_model_t m, int m_pts, int* mask_host);
 
 /* out = in / max(||in||_2, 1e-12) row-wise for [b,3] — the extra F.normalize of generation.py:139. */
 int sapcu_l2_normalize3(const float* in, float* out, int64_t b, void* stream);
@@ -255,7 +266,9 @@ int sapcu_l2_normalize3(const float* in, float* out, int64_t b, void* stream);
  * w16_ws == NULL: exact-f32 MFMA kernel.  Otherwise 4*n*k + 16 bytes of scratch: W is split into f16
  * hi/lo halves there and a split-f16 kernel runs (3 x f16 MFMA per product; last 4 bytes of the
  * scratch = count of activation values beyond the f16 range).
- * a_split_rows: A is in "split rows" (see sapcu_to_split_rows) -> the all-DMA ring kernel (lda % 8 == 0);
+ * a_split_rows != 0: A is in "split rows" (see sapcu_to_split_rows) -> the all-DMA kernels (lda % 8 == 0): 1 = the kernel
+ * the models would pick for the shape (big-tile for >= 1024 rows, else the 128x128 ring kernel), 2 = the ring kernel
+ * whatever the shape (the two are bit-identical; the parity tests compare them);
  * c_split_rows: write C as split rows (needs w16_ws). */
 int sapcu_gemm_f32(const float* a, int64_t r, int k, int lda, const float* w, int n, const float* bias,
                    const float* lif4, int lif_steps, float* c, int ldc, void* w16_ws, int a_split_rows,
@@ -275,14 +288,17 @@ int sapcu_to_split_rows(const float* in, int64_t rows, int k, int ld_in, float* 
  * edge_table_ws: 8*r bytes of scratch (row -> (q row, k row) table, rebuilt by every call).
  * w16_ws: NULL -> exact-f32 MFMA kernel; else 4*d*d + 16 bytes of scratch -> split-f16 (3 x f16 MFMA) kernel.
  * split_rows != 0 (needs w16_ws): pe1 is in split rows and attn_in_out is written as split rows — the form the
- * models run (all-DMA ring kernel). */
+ * models' unfused chain runs (all-DMA kernels; 1 = big-tile kernel where it takes the shape, 2 = ring kernel only). */
 int sapcu_posenc_gemm_f32(const float* pe1, int64_t r, int d, const float* w, const float* bias,
                           const float* lif4, int lif_steps, const float* qkv, const int32_t* idx, int kk,
                           int m_pts, float* pe_out, float* attn_in_out, void* edge_table_ws, void* w16_ws,
                           int split_rows, void* stream);
 
 /* The whole per-edge chain of one fn transformer block in ONE kernel, activations in LDS (csrc/fn_edge_chain.hip) — what the
- * models run for the blocks with d = 128 (kk = 24) and d = 256 (kk = 18); fn/snn_coder.py:355-389:
+ * models run for all three blocks at the reference's neighbour counts: (d, kk) = (128, 24), (256, 18), (512, 12) EXACTLY.  A
+ * block with any other k_values entry — or a patch of fewer than kk points, which clamps kk — falls back to the five-kernel
+ * chain (same results bit for bit, ~6x the workspace, slower); sapcu_model_fused_blocks reports which blocks of a handle run
+ * fused for a given patch size.  fn/snn_coder.py:355-389:
  *   pe1 = LIF_x4(fc_delta(x_i - x_j)), pe = LIF_x4(fc_delta2(pe1)), attn_in = q_i - k_j + pe, g = LIF_x4(fc_gamma(attn_in)),
  *   a = fc_gamma2(g), res[i,:] = sum_j softmax_j(a / sqrt(d / heads)) * (v_j + pe)
  * patch [points,3] f32 (points = patches * m_pts, patch-major); idx [points*kk] int32 in-patch neighbours; qkv [points, 3d]

@@ -1,6 +1,10 @@
 """Worker of tests/test_gpu_parity.py::test_sharded_upsample_two_ranks_on_one_gpu — run under torch.distributed.run with
 2 ranks, BOTH on cuda:0, gloo backend (a one-GPU box cannot host two RCCL ranks): the real Generator3D6 + upsample_sharded
-+ gather_refined; every rank checks the gathered cloud against its own single-rank refine of all seeds, bit for bit."""
++ gather_refined; every rank checks the gathered cloud against its own single-rank refine of all seeds, bit for bit.
+
+`dist_rehearsal.py nccl` (test_rccl_world1_sharded_upsample_on_device_tensors): ONE rank with the nccl (= RCCL) backend and
+device_id=cuda:0 — the branch of dist.gather_refined that keeps the f64 slabs on the device and the
+init_process_group("nccl", device_id=...) call of bench.py, which no gloo rehearsal reaches."""
 import os
 import sys
 
@@ -20,7 +24,11 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = sys.argv[1] if len(sys.argv) > 1 else "gloo"
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         fn = sapcu_amd.ImprovedSNNNormalEstimation(**FN_KW)
         fd = sapcu_amd.EnhancedSNNDistanceEstimation(**FD_KW)
@@ -35,12 +43,19 @@ def main():
             assert fn.knn_cache_mode == "reference"
             fn.knn_cache_mode = "fresh"
             single, _, _ = gen.refine(cloud, seeds)
-        assert gathered.shape == single.shape and gathered.is_cuda
+        assert gathered.shape == single.shape and gathered.is_cuda and gathered.dtype == torch.float64
+        if backend == "nccl":
+            assert dist.get_backend() == "nccl"
+            # the collective itself on device tensors, uneven slabs (last rank short): every rank's rows come back in place
+            probe = torch.arange(7 * 3, dtype=torch.float64, device=dev).view(7, 3) + 100.0 * rank
+            s0, e0 = sdist.shard_range(7 * world - 2, rank, world)
+            got = sdist.gather_refined(probe[: e0 - s0], 7 * world - 2)
+            assert got.is_cuda and torch.equal(got[s0:e0], probe[: e0 - s0])
         assert torch.equal(gathered, single), "rank %d: gathered cloud differs from the single-rank refine" % rank
         assert (s, e) == sdist.shard_range(333, rank, world)
         dist.barrier()
         if rank == 0:
-            print("REHEARSAL_OK ranks=%d seeds=333 shard0=%d..%d" % (world, s, e), flush=True)
+            print("REHEARSAL_OK ranks=%d backend=%s seeds=333 shard0=%d..%d" % (world, dist.get_backend(), s, e), flush=True)
     finally:
         dist.destroy_process_group()
 

@@ -24,6 +24,19 @@ def build_gpu_models(weights, fn_over=None, fd_over=None):
     return fn.to(dev()), fd.to(dev()), sdn, sdd
 
 
+def build_gpu_models_under(weights, monkeypatch, env, fn_over=None, fd_over=None):
+    """Models whose HANDLES were created under the environment switches `env` (sapcu_model_create reads SAPCU_* once; a forward
+    never reads the environment): the switches are set, both engines are built, the switches are removed again."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    out = build_gpu_models(weights, fn_over, fd_over)
+    out[0]._engine(), out[1]._engine()
+    for k in env:
+        monkeypatch.delenv(k, raising=False)
+    out[0].knn_cache_mode = "fresh"
+    return out
+
+
 def sphere_patches(nq, k, n=5000, qseed=0, skip=0):
     from sapcu_amd import testing as T
     cloud = T.sphere_cloud(n, 0)

@@ -412,21 +412,28 @@ def test_fd_stage_taps_against_reference_vectors(models):
     z = lambda *s: torch.empty(s, dtype=torch.float32, device=U.dev())
     taps = {"fused0": z(b, m, 64), "spikes": z(T, b, m, 960), "knn": torch.empty((3, b, m, 32), dtype=torch.int32, device=U.dev()),
             "pooled": z(T, b, 768), "enc": z(b, 768)}
-    d = fd(_dev(g["patch"]), taps=taps)
+    # (1) the comparison with the reference's own stage outputs ALWAYS happens: the feature-space neighbour tables the
+    #     reference itself chose (fixture knn1..3) are forced, so a near-tie flip cannot skip it
+    force = torch.from_numpy(np.stack([g["knn%d" % i].astype(np.int32) for i in (1, 2, 3)])).to(U.dev())
+    d = fd(_dev(g["patch"]), taps=taps, knn_force=force)
     torch.cuda.synchronize()
     assert fd.gate_violations() == 0
+    assert torch.equal(taps["knn"], force)
     np.testing.assert_allclose(taps["fused0"].cpu().numpy(), g["fused0"], rtol=0, atol=TOL)
-    knn = taps["knn"].cpu().numpy()
+    np.testing.assert_allclose(taps["spikes"][0].cpu().numpy(), g["spikes_t0"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(taps["spikes"][T - 1].cpu().numpy(), g["spikes_tlast"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(taps["pooled"].cpu().numpy(), g["pooled"], rtol=0, atol=TOL * 4)
+    np.testing.assert_allclose(taps["enc"].cpu().numpy(), g["enc"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(d.cpu().numpy(), g["dist"], rtol=0, atol=TOL)
+    # (2) free-running: the tables the device chooses itself, counted against the reference's
+    free = torch.empty_like(force)
+    d_free = fd(_dev(g["patch"]), taps={"knn": free})
+    knn = free.cpu().numpy()
     flips = sum(int((np.sort(knn[i], -1) != np.sort(g["knn%d" % (i + 1)].astype(np.int64), -1)).any(-1).sum()) for i in range(3))
-    print("fd taps: neighbour-set flips in %d of %d rows" % (flips, 3 * b * m))
+    print("fd taps: neighbour-set flips in %d of %d rows (free-running)" % (flips, 3 * b * m))
+    assert flips <= 3
     if flips == 0:
-        np.testing.assert_allclose(taps["spikes"][0].cpu().numpy(), g["spikes_t0"], rtol=0, atol=TOL)
-        np.testing.assert_allclose(taps["spikes"][T - 1].cpu().numpy(), g["spikes_tlast"], rtol=0, atol=TOL)
-        np.testing.assert_allclose(taps["pooled"].cpu().numpy(), g["pooled"], rtol=0, atol=TOL * 4)
-        np.testing.assert_allclose(taps["enc"].cpu().numpy(), g["enc"], rtol=0, atol=TOL)
-        np.testing.assert_allclose(d.cpu().numpy(), g["dist"], rtol=0, atol=TOL)
-    else:
-        assert flips <= 3
+        np.testing.assert_allclose(d_free.cpu().numpy(), g["dist"], rtol=0, atol=TOL)
 
 
 def test_fd_forward_256_patches_forced_neighbour_protocol(models):
@@ -791,6 +798,31 @@ def test_generator_edge_cases(weights):
     np.testing.assert_allclose(full1[0], full_big[0], rtol=0, atol=2e-4)
     with pytest.raises(ValueError):
         gen.upsample_seeds(cloud[:40], q)                                      # 40 points < 48 neighbours
+
+
+@pytest.mark.gpu
+def test_multi_scale_upsample_equals_chained_upsample_calls(weights):
+    """SNNPointCloudGenerator.multi_scale_upsample (generation.py:191-220): num_passes passes, each feeding its refined cloud
+    to the next — two passes on a 256-point cloud equal two chained upsample() calls, and one pass equals upsample()."""
+    import sapcu_amd
+    from sapcu_amd import testing as T
+    from sapcu_amd.generation import SNNPointCloudGenerator
+    fn_gpu, fd_gpu, _, _ = U.build_gpu_models(weights)
+    fn_gpu.knn_cache_mode = "fresh"
+    kw = dict(k_neighbors=48, batch_size=64, dense_spacing=0.03)
+    gen = SNNPointCloudGenerator(fn_gpu, fd_gpu, U.dev(), upsampling_ratio=4, **kw)
+    assert gen.upsampling_ratio == 4 and isinstance(gen, sapcu_amd.Generator3D6)
+    cloud = T.sphere_cloud(256, 0)
+    one = gen.multi_scale_upsample(cloud, num_passes=1)
+    first = np.asarray(gen.upsample(cloud[None]))
+    np.testing.assert_array_equal(one, first)
+    assert 256 < first.shape[0] <= 5000 and first.shape[1] == 3          # a pass's output is the next pass's input cloud (dense.cpp: <= 5000 points)
+    two = gen.multi_scale_upsample(cloud, num_passes=2)
+    chained = np.asarray(gen.upsample(first[None]))
+    np.testing.assert_array_equal(two, chained)
+    assert two.dtype == np.float64 and np.isfinite(two).all()
+    np.testing.assert_array_equal(gen.multi_scale_upsample(cloud[None], num_passes=1), first)      # [1,N,3] input as upsample() takes it
+    assert gen.multi_scale_upsample(cloud, num_passes=0) is cloud
 
 
 def test_fused_batches_equal_batch_by_batch(weights):
@@ -1221,8 +1253,8 @@ def test_training_epoch_bf16_tracks_the_f32_and_oracle_loss_curves():
 
 @pytest.mark.parametrize("r,k,n,lif,csplit", [(1024, 128, 128, 0, 0), (2048 + 77, 256, 256, 1, 1), (4096 + 3, 512, 512, 0, 0), (3000, 512, 512, 1, 0),
                                               (1500, 64, 384, 1, 1), (70000, 512, 512, 1, 1), (36864, 128, 128, 1, 1)])
-def test_big_tile_gemm_is_bit_identical_to_the_ring_kernel(r, k, n, lif, csplit, monkeypatch):
-    """gemm_sf16_bt.hip (256-row tiles, epilogue in the MFMA waves, SAPCU_BT=1) against gemm_sf16_ring.hip through the C ABI
+def test_big_tile_gemm_is_bit_identical_to_the_ring_kernel(r, k, n, lif, csplit):
+    """gemm_sf16_bt.hip (256-row tiles, epilogue in the MFMA waves) against gemm_sf16_ring.hip (a_split_rows = 2) through the C ABI
     on the same split-row operands: same products in the same order, so every output bit must agree — bias-only and
     neuron epilogues, f32 and split-row outputs, ragged last row tile, 1/2/3 column tiles."""
     from sapcu_amd import _lib
@@ -1235,12 +1267,11 @@ def test_big_tile_gemm_is_bit_identical_to_the_ring_kernel(r, k, n, lif, csplit,
     As = torch.empty_like(A)
     _lib.check(lib.sapcu_to_split_rows(_lib.ptr(A), r, k, k, _lib.ptr(As), k, _lib.current_stream()))
     outs = []
-    for bt in ("0", "1"):                        # ring / big tile
-        monkeypatch.setenv("SAPCU_BT", bt)
+    for a_split in (2, 1):                       # ring kernel only / the models' choice = big tile (sapcu.h: a_split_rows)
         C = torch.full((r, n), float("nan"), device=U.dev())
         ws = torch.zeros(4 * n * k + 16, dtype=torch.uint8, device=U.dev())
         _lib.check(lib.sapcu_gemm_f32(_lib.ptr(As), r, k, k, _lib.ptr(W), n, _lib.ptr(Bv), _lib.ptr(L) if lif else None, 4, _lib.ptr(C), n,
-                                      _lib.ptr(ws), 1, csplit, _lib.current_stream()))
+                                      _lib.ptr(ws), a_split, csplit, _lib.current_stream()))
         torch.cuda.synchronize()
         outs.append(C.cpu().view(torch.int32))
     assert not bool(torch.isnan(outs[1].view(torch.float32)).any()) or csplit
@@ -1248,9 +1279,9 @@ def test_big_tile_gemm_is_bit_identical_to_the_ring_kernel(r, k, n, lif, csplit,
 
 
 @pytest.mark.parametrize("b,m,kk,d", [(4, 48, 12, 512), (3, 48, 18, 256), (5, 48, 24, 128), (37, 48, 12, 512)])
-def test_big_tile_posenc_attention_gemm_is_bit_identical_to_the_ring_kernel(b, m, kk, d, monkeypatch):
+def test_big_tile_posenc_attention_gemm_is_bit_identical_to_the_ring_kernel(b, m, kk, d):
     """The production form of sapcu_posenc_gemm_f32 (split rows in, pe f32 + attn_in split rows out, q/k gathers) on the
-    big-tile kernel (SAPCU_BT=1) against the ring kernel: every bit of both outputs."""
+    big-tile kernel (split_rows = 1) against the ring kernel (split_rows = 2): every bit of both outputs."""
     from sapcu_amd import _lib
     lib = _lib.load()
     rng = np.random.default_rng(b * 1000 + d)
@@ -1262,14 +1293,13 @@ def test_big_tile_posenc_attention_gemm_is_bit_identical_to_the_ring_kernel(b, m
     P1s = torch.empty_like(P1)
     _lib.check(lib.sapcu_to_split_rows(_lib.ptr(P1), r, d, d, _lib.ptr(P1s), d, _lib.current_stream()))
     outs = []
-    for bt in ("0", "1"):
-        monkeypatch.setenv("SAPCU_BT", bt)
+    for split_rows in (2, 1):
         pe = torch.full((r, d), float("nan"), device=U.dev())
         att = torch.full((r, d), float("nan"), device=U.dev())
         tab = torch.empty((r, 2), dtype=torch.int32, device=U.dev())
         ws = torch.zeros(4 * d * d + 16, dtype=torch.uint8, device=U.dev())
         _lib.check(lib.sapcu_posenc_gemm_f32(_lib.ptr(P1s), r, d, _lib.ptr(W), _lib.ptr(Bv), _lib.ptr(L), 4, _lib.ptr(Q), _lib.ptr(I), kk, m,
-                                             _lib.ptr(pe), _lib.ptr(att), _lib.ptr(tab), _lib.ptr(ws), 1, _lib.current_stream()))
+                                             _lib.ptr(pe), _lib.ptr(att), _lib.ptr(tab), _lib.ptr(ws), split_rows, _lib.current_stream()))
         torch.cuda.synchronize()
         outs.append((pe.cpu().view(torch.int32), att.cpu().view(torch.int32)))
     assert not bool(torch.isnan(outs[1][0].view(torch.float32)).any())
@@ -1333,19 +1363,20 @@ def test_fused_edge_chain_entry_against_the_oracle_primitives(b, d, kk):
 
 def test_fused_edge_chain_equals_the_unfused_chain_bit_for_bit(weights, monkeypatch):
     """fn_edge_chain.hip (blocks 1 and 2: pe1 -> fc_delta2 -> attn_in -> fc_gamma -> fc_gamma2 -> softmax-aggregate in one kernel,
-    activations in LDS) against the five-kernel chain (SAPCU_CHAIN=0, read per launch): identical block outputs and normals,
+    activations in LDS) against the five-kernel chain (a second handle created under SAPCU_CHAIN=0): identical block outputs and normals,
     bit for bit — full groups, a ragged last group (points not a multiple of 5 / 7), one patch, M = 100 (the reference's
     default patch size) and M = 20 (block 1's kk = 20 is not a shape the fused kernel takes: that block stays unfused).
     All three blocks (d = 128 / 256 / 512) run fused."""
-    fn, _, _, _ = U.build_gpu_models(weights)
-    fn.knn_cache_mode = "fresh"
+    fn, _, _, _ = U.build_gpu_models_under(weights, monkeypatch, {})
+    fn_unfused, _, _, _ = U.build_gpu_models_under(weights, monkeypatch, {"SAPCU_CHAIN": "0"})
+    assert fn.fused_blocks(48) == 0b111 and fn.fused_blocks(100) == 0b111 and fn_unfused.fused_blocks(48) == 0
+    assert fn.fused_blocks(20) == 0b110                      # block 1's kk = min(24, 20) is not a shape the fused kernel takes
     for nq, mpts in ((64, 48), (37, 48), (1, 48), (9, 100), (11, 20)):
         patch = U.sphere_patches(nq, mpts, skip=1200).to(U.dev())
         outs = []
-        for chain in ("1", "0"):
-            monkeypatch.setenv("SAPCU_CHAIN", chain)
+        for model in (fn, fn_unfused):
             taps = {k: torch.full((nq, mpts, 64), float("nan"), device=U.dev()) for k in ("block1", "block2", "block3")}
-            n = fn(patch, taps=taps)
+            n = model(patch, taps=taps)
             torch.cuda.synchronize()
             outs.append((n, taps))
         for k in ("block1", "block2", "block3"):
@@ -1360,16 +1391,12 @@ def test_fn_max_over_points_fused_into_the_gemm_is_bit_identical(weights, monkey
     and takes the max by integer atomicMax on order-preserving keys — the [P, emb] activation is never written; SAPCU_FN_MAXFUSE=0:
     GEMM + rowgroup_max.  Identical pooled features and normals for full patches, M = 100, M = 5 (groups that do not align with the
     4-row register groups) and a single patch."""
-    fn, _, _, _ = U.build_gpu_models(weights)
-    fn.knn_cache_mode = "fresh"
-    emb = fn.emb_dims
+    variants = [U.build_gpu_models_under(weights, monkeypatch, env)[0] for env in ({}, {"SAPCU_FN_MAXFUSE": "0"})]
+    emb = variants[0].emb_dims
     for nq, mpts in ((40, 48), (7, 100), (70, 5), (1, 48)):
         patch = U.sphere_patches(nq, mpts, skip=900).to(U.dev())
         outs = []
-        for env in ({}, {"SAPCU_FN_MAXFUSE": "0"}):
-            monkeypatch.delenv("SAPCU_FN_MAXFUSE", raising=False)
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
+        for fn in variants:
             taps = {"pooled": torch.full((nq, emb), float("nan"), device=U.dev())}
             n = fn(patch, taps=taps)
             torch.cuda.synchronize()
@@ -1384,17 +1411,14 @@ def test_fd_max_over_points_fused_into_the_gemm_is_bit_identical(weights, monkey
     the [T*P, 768] aggregate is never written); SAPCU_FD_SPLIT=0: f32 spikes, the f32-A GEMM with the same epilogue;
     SAPCU_FD_MAXFUSE=0: GEMM + rowgroup_max.  Identical pooled features, encodings and distances, for full patches, M = 100,
     M = 5 (groups that do not align with the 4-row register groups) and batches too small for the big-tile kernel."""
-    _, fd, _, _ = U.build_gpu_models(weights)
+    variants = [U.build_gpu_models_under(weights, monkeypatch, dict(env, SAPCU_FD_FUSED="0"))[1]
+                for env in ({}, {"SAPCU_FD_SPLIT": "0"}, {"SAPCU_FD_MAXFUSE": "0"})]
     for nq, mpts in ((40, 48), (7, 100), (70, 5), (5, 5), (1, 48)):
         patch = U.sphere_patches(nq, mpts, skip=1500).to(U.dev())
         kk = min(32, mpts)
         knn = torch.empty((3, nq, mpts, kk), dtype=torch.int32, device=U.dev())
         outs = []
-        for env in ({}, {"SAPCU_FD_SPLIT": "0"}, {"SAPCU_FD_MAXFUSE": "0"}):
-            monkeypatch.delenv("SAPCU_FD_SPLIT", raising=False)
-            monkeypatch.delenv("SAPCU_FD_MAXFUSE", raising=False)
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
+        for fd in variants:
             taps = {"pooled": torch.full((4, nq, 768), float("nan"), device=U.dev()), "enc": torch.full((nq, 768), float("nan"), device=U.dev())}
             if not outs:
                 taps["knn"] = knn
@@ -1406,22 +1430,72 @@ def test_fd_max_over_points_fused_into_the_gemm_is_bit_identical(weights, monkey
         assert not bool(torch.isnan(outs[0][1]).any())
         for o in outs[1:]:
             assert torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][2], o[2]) and torch.equal(outs[0][0], o[0]), (nq, mpts)
-    assert fd.gate_violations() == 0
+    assert all(fd.gate_violations() == 0 for fd in variants)
 
 
 def test_models_on_the_big_tile_kernel_equal_the_ring_kernel_bit_for_bit(weights, monkeypatch):
     """Whole fn and fd forwards with the split-row GEMMs on the big-tile kernel (default) against the ring kernel only
-    (SAPCU_BT=0, read per launch): identical normals and distances, bit for bit — including a batch whose last row tile is
-    ragged (37 patches) and one below the big-tile threshold."""
-    fn, fd, _, _ = U.build_gpu_models(weights)
-    fn.knn_cache_mode = "fresh"
+    (handles created under SAPCU_BT=0): identical normals and distances, bit for bit — including a batch whose last row tile is
+    ragged (37 patches) and one below the big-tile threshold.  (fd on its per-stage kernels: the fused encoder has no split-row
+    GEMM launches.)"""
+    fn, fd, _, _ = U.build_gpu_models_under(weights, monkeypatch, {"SAPCU_FD_FUSED": "0"})
+    fn_ring, fd_ring, _, _ = U.build_gpu_models_under(weights, monkeypatch, {"SAPCU_BT": "0", "SAPCU_FD_FUSED": "0"})
     for nq in (64, 37, 1):
         patch = U.sphere_patches(nq, 48, skip=500).to(U.dev())
-        monkeypatch.setenv("SAPCU_BT", "1")
         n1, d1 = fn(patch), fd(patch)
-        monkeypatch.setenv("SAPCU_BT", "0")
-        n0, d0 = fn(patch), fd(patch)
+        n0, d0 = fn_ring(patch), fd_ring(patch)
         assert torch.equal(n0, n1) and torch.equal(d0, d1), nq
+
+
+def test_concurrent_forwards_of_one_handle_on_two_streams(weights):
+    """include/sapcu.h: a handle is immutable after create, so forwards of ONE handle may run concurrently from different host
+    threads on different streams, each with its own workspace (launch attributes are per device and set thread-safely, no
+    forward reads the environment).  Two threads x two streams x 6 forwards each of fn and fd through the C ABI against the
+    single-threaded results, bit for bit."""
+    import ctypes
+    import threading
+    from sapcu_amd import _lib
+    lib = _lib.load()
+    fn, fd, _, _ = U.build_gpu_models(weights)
+    fn.knn_cache_mode = "fresh"
+    dev = U.dev()
+    patches = [U.sphere_patches(48, 48, skip=2100 + 100 * i).to(dev) for i in range(2)]
+    want = [(fn(p).clone(), fd(p).clone()) for p in patches]
+    torch.cuda.synchronize()
+    hn, hd = fn._engine(), fd._engine()
+    errors, results = [], [None, None]
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            p = patches[i]
+            b, m = p.shape[0], p.shape[1]
+            wsn = torch.empty(int(lib.sapcu_workspace_bytes(hn, b, m)), dtype=torch.uint8, device=dev)
+            wsd = torch.empty(int(lib.sapcu_workspace_bytes(hd, b, m)), dtype=torch.uint8, device=dev)
+            outs = []
+            with torch.cuda.stream(st):             # the NaN fills of the outputs run on this thread's stream too
+                for _ in range(6):
+                    n = torch.full((b, 3), float("nan"), device=dev)
+                    d = torch.full((b,), float("nan"), device=dev)
+                    sp = ctypes.c_void_p(st.cuda_stream)
+                    _lib.check(lib.sapcu_fn_forward(hn, _lib.ptr(p), b, m, None, None, _lib.ptr(n), _lib.ptr(wsn), wsn.numel(), None, sp))
+                    _lib.check(lib.sapcu_fd_forward(hd, _lib.ptr(p), b, m, None, _lib.ptr(d), _lib.ptr(wsd), wsd.numel(), None, sp))
+                    outs.append((n, d))
+            st.synchronize()
+            results[i] = outs
+        except Exception as e:          # noqa: BLE001 - reported by the main thread
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        for n, d in results[i]:
+            assert torch.equal(n, want[i][0]) and torch.equal(d, want[i][1]), i
+    assert fd.gate_violations() == 0 and fn.gemm_mode() == (True, 0) and fd.gemm_mode() == (True, 0)
 
 
 def test_graph_captured_training_step_equals_the_eager_step():
@@ -1490,6 +1564,40 @@ def test_sharded_upsample_two_ranks_on_one_gpu():
            "--master-port", str(_free_port()), os.path.join(root, "tests", "dist_rehearsal.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0 and "REHEARSAL_OK ranks=2" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.gpu
+def test_rccl_world1_sharded_upsample_on_device_tensors():
+    """RCCL contact on ONE GPU: a child rank with init_process_group("nccl", world_size=1, device_id=cuda:0) runs
+    upsample_sharded + gather_refined on device tensors (the nccl branch of sapcu_amd/dist.py: f64 slabs stay on the device,
+    all_gather_into_tensor over RCCL) and holds the gathered cloud to the single-process 'fresh' refine, bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_rehearsal.py"), "nccl"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and "REHEARSAL_OK ranks=1 backend=nccl" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.gpu
+def test_bench_gpus_1_takes_the_rccl_branch_when_asked():
+    """SAPCU_BENCH_NCCL1=1 python bench.py --gpus 1: the N = 1 bench with the process group of the N > 1 runs (nccl, device_id)
+    — barrier, the all-gather of the refined cloud and the max-over-ranks all-reduce all go through RCCL on one GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SAPCU_BENCH_REHEARSE")}
+    env.update(SAPCU_BENCH_NCCL1="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-roofline", "--no-strong-leg"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["collective_backend"] == "nccl" and line["value"] > 0
 
 
 @pytest.mark.gpu
