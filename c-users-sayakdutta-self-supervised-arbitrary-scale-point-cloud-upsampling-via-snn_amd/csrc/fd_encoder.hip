@@ -1,0 +1,748 @@
+// fd encoder: EnhancedTemporalSNN_DGCNN_fd.forward (fd/snn_coder.py:392-480) from the rotated patch to the per-step pooled
+// features, in ONE kernel — one 512-thread workgroup per patch, the patch resident in LDS / registers from the first neighbour
+// search to the last max over points:
+//
+//     block 0   xyz kNN (all scales are prefixes of one sorted list) -> multi-scale EdgeConv(6->64)+BN+LReLU, max over the
+//               ks nearest -> scale_fusion (64 S -> 64)+BN+LReLU -> EIF                                     fd:411-444
+//     block l   kNN in the feature space of block l-1's step-0 spikes -> EdgeConv(2C -> C')+BN+LReLU, max over the k
+//     = 1..3    neighbours (factored: W.cat(xj - xi, xj) = (W1 + W2) xj - W1 xi, BN scale folded) -> EIF / LIF / LIF   fd:447-474
+//     all t     cat(64 + 128 + 256 + 512 = 960) -> multi_scale_conv (960 -> emb)+BN+LReLU -> max over the points    fd:476-480
+//
+// The per-stage form (model.hip: ~20 launches) writes the [T, points, 960] spike tensor (3 GB at 4096 patches), the [points, 2C']
+// EdgeConv operands and the block-0 features to HBM and reads them back.  Here nothing of the encoder reaches HBM: the kernel reads
+// the patch (576 B), the packed weights (L2) and writes pooled [T, emb] per patch.
+//
+// What makes that fit.  In eval mode a neuron's input gate is closed from step 1 on (violations are counted),
+// so ALL T spikes of a (point, channel) are a function of its ONE pre-activation x0 at t = 0.  The kernel therefore keeps x0 —
+// 48 x 960 floats: blocks 0-2 in LDS (84 KiB), block 3 in registers (48 per lane) — and regenerates the spikes where they are
+// consumed: step-0 spikes as the f32 features of the next block's neighbour search and as the split-f16 operand of its EdgeConv
+// GEMM; all steps as the operand of multi_scale_conv.  That contraction stacks the T steps as ROWS (row = 48 t + point: 192 rows
+// = six 32x32 MFMA row blocks, no padded row at T = 4) and walks N in passes of 256 columns (one column block per wave, 96
+// accumulator registers), K in rounds of 64 columns: per round every thread runs the T-step neuron loop of six (point, channel)
+// elements with the state in registers, writes the spikes into a 48 KiB split-f16 panel and the waves multiply the panel with
+// weight fragments streamed L2 -> registers in fragment order (the fn_edge_chain.hip recipe).  The max over the points is taken
+// in the accumulator layout on order-preserving integer keys, like the GEMM epilogue it replaces.
+//
+// Bit-identical to the per-stage path (tests/test_gpu_parity.py::test_fused_fd_encoder_equals_the_per_stage_path_bit_for_bit):
+// same score chains and tie rule in the neighbour searches, same split-f16 products in the same k order, same neuron arithmetic
+// (block 0: neuron_step<true>, blocks 1-3: NeuronStep2), same max.  Taken for patches of <= 48 points, <= 4 scales, emb % 256 == 0;
+// anything else runs the per-stage kernels.
+#include "common.h"
+#include "gemm_epi.h"
+#include "ops.h"
+
+namespace sapcu {
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr int FE_M = 48;                 // points per patch (rows of every per-patch table)
+constexpr int FE_NT = 512;               // threads: 8 waves, 256 registers each
+constexpr int FE_XLD = 448;              // x0 of blocks 0..2: [48][448] f32
+constexpr int FE_OFF_R2 = FE_M * FE_XLD * 4;               // 86016: 64 KiB phase buffer (score keys / GEMM panels / staging)
+constexpr int FE_R2_BYTES = 65536;
+constexpr int FE_OFF_XYZ = FE_OFF_R2 + FE_R2_BYTES;        // float4[48]
+constexpr int FE_OFF_IDX0 = FE_OFF_XYZ + FE_M * 16;        // u8[48][48]: xyz neighbours, ascending distance
+constexpr int FE_OFF_IDXL = FE_OFF_IDX0 + FE_M * FE_M;     // u8[48][48]: feature-space neighbours of the current block
+constexpr int FE_OFF_XX = FE_OFF_IDXL + FE_M * FE_M;       // float[64]
+constexpr int FE_LDS = FE_OFF_XX + 256;                    // 157 184 B
+constexpr int FE_F_LD = 33;                                // score staging [64][33] f32 at R2 + 0, keys [m][m+1] behind it
+constexpr int FE_KEYS_OFF = 64 * FE_F_LD * 4;
+static_assert(FE_LDS <= 163840, "fd encoder: LDS budget");
+static_assert(FE_KEYS_OFF + FE_M * (FE_M + 1) * 4 <= FE_R2_BYTES, "fd encoder: score keys");
+
+// ---- split-f16 operand panel: [k32 step][plane hi | lo][ROWS][32 halves], 16-byte chunks XOR-swizzled by (row >> 2) & 3 (the
+// operand-slot layout of gemm_sf16_bt.hip / fn_edge_chain.hip: conflict-free ds_read_b128 fragments)
+template <int ROWS>
+__device__ __forceinline__ unsigned fe_panel_off(int row, int k) {
+    return (unsigned)((k >> 5) * (ROWS * 128) + row * 64 + ((((k >> 3) & 3) ^ ((row >> 2) & 3)) << 4) + (k & 7) * 2);
+}
+// The value is made opaque first: with the producing FMA visible, the compiler folds "(f16) fma(a, b, c)" into v_fma_mixlo_f16 —
+// ONE rounding of the exact result to f16 — where the per-stage path rounds to f32 (the spike it stores) and then to f16; the two
+// differ in rare double-rounding cases (measured: 1 element in ~50 000), which is enough to break bit-identity downstream.
+template <int ROWS>
+__device__ __forceinline__ void fe_put(unsigned char* X, int row, int k, float v) {
+    unsigned char* p = X + fe_panel_off<ROWS>(row, k);
+    v = settle(v);
+    const _Float16 hi = (_Float16)v;
+    *reinterpret_cast<_Float16*>(p) = hi;
+    *reinterpret_cast<_Float16*>(p + ROWS * 64) = (_Float16)(v - (float)hi);
+}
+
+__device__ __forceinline__ NeuronP fe_load_np(const float* __restrict__ nprm, int col) {   // clamped at model build (pack kernel)
+    const float* q = nprm + (int64_t)col * 8;      // (scalar loads: a float4-built struct made the compiler shuffle it through scratch)
+    NeuronP p;
+    p.decay = q[0];
+    p.adapt = q[1];
+    p.rdecay = q[2];
+    p.theta0 = q[3];
+    p.dT = q[4];
+    p.rh = q[5];
+    return p;
+}
+
+// neuron kinds: 0 = block 0 (EIF in neuron_step's operation order, as fd_neuron_kernel<true, 0>), 1 = EIF / 2 = LIF in
+// NeuronStep2's arithmetic (as fd_edge_neuron_kernel)
+// step-0 spikes of TWO elements of one channel (always real pairs: with one element per call the compiler re-vectorised the
+// scalarised half of the packed arithmetic and assembled its operand pairs through scratch memory)
+template <int KIND>
+__device__ __forceinline__ f32x2 fe_spike0(f32x2 x, const NeuronP& p) {
+    if (KIND == 0) {
+        NeuronS sa = neuron_init(p), sb = neuron_init(p);
+        return f32x2{neuron_step<true>(x.x, sa, p), neuron_step<true>(x.y, sb, p)};
+    }
+    NeuronStep2<KIND == 1> ns(p);
+    return ns.step(x, true);
+}
+
+// ---- fragment-ordered weights: frag (column block cb, k16 step s, plane) of a [n, k] matrix = 64 lanes x 8 halves
+__device__ __forceinline__ half8 fe_wfrag(const half8* __restrict__ wp, int nk16, int cb, int s, int plane, int lane) {
+    return wp[(((int64_t)cb * nk16 + s) * 2 + plane) * 64 + lane];
+}
+
+// C[64 rows, NCB column blocks] = panel[64, 16 nk16] . W^T for this wave's column blocks cb[]: both 32-row blocks, weights
+// L2 -> registers two k16 steps ahead, products (a_lo w_hi, a_hi w_lo, a_hi w_hi) per k16 step in ascending k — the order of
+// every split-f16 GEMM of the library.  acc[i * NCB + j] = row block i, column block cb[j].
+template <int NCB>
+__device__ __forceinline__ void fe_gemm64(const unsigned char* X, const half8* __restrict__ wp, int nk16, const int (&cb)[NCB],
+                                          int lane, f32x16 (&acc)[2 * NCB]) {
+    const int r32 = lane & 31, h = lane >> 5, sw = (r32 >> 2) & 3;
+    const unsigned char* xa = X + r32 * 64;
+#pragma unroll
+    for (int b = 0; b < 2 * NCB; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+    half8 wh[2][NCB], wl[2][NCB];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) {
+            wh[s][j] = fe_wfrag(wp, nk16, cb[j], s < nk16 ? s : nk16 - 1, 0, lane);
+            wl[s][j] = fe_wfrag(wp, nk16, cb[j], s < nk16 ? s : nk16 - 1, 1, lane);
+        }
+#define SAPCU_FE_STEP(S, SJ)                                                                                          \
+    {                                                                                                                 \
+        const int s_ = (S);                                                                                           \
+        const unsigned ko = (unsigned)((s_ >> 1) * 8192 + ((((s_ & 1) * 2 + h) ^ sw) * 16));                          \
+        half8 ah[2], al[2];                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                               \
+            ah[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048);                                              \
+            al[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048 + 4096);                                       \
+        }                                                                                                             \
+        _Pragma("unroll") for (int b = 0; b < 2 * NCB; ++b)                                                           \
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b / NCB], wh[SJ][b % NCB], acc[b], 0, 0, 0);           \
+        _Pragma("unroll") for (int b = 0; b < 2 * NCB; ++b)                                                           \
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / NCB], wl[SJ][b % NCB], acc[b], 0, 0, 0);           \
+        _Pragma("unroll") for (int b = 0; b < 2 * NCB; ++b)                                                           \
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / NCB], wh[SJ][b % NCB], acc[b], 0, 0, 0);           \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        const int sn_ = s_ + 2 < nk16 ? s_ + 2 : nk16 - 1;                                                            \
+        _Pragma("unroll") for (int j = 0; j < NCB; ++j) {                                                             \
+            wh[SJ][j] = fe_wfrag(wp, nk16, cb[j], sn_, 0, lane);                                                      \
+            wl[SJ][j] = fe_wfrag(wp, nk16, cb[j], sn_, 1, lane);                                                      \
+        }                                                                                                             \
+    }
+#pragma unroll 1
+    for (int s0 = 0; s0 < nk16; s0 += 2) {
+        SAPCU_FE_STEP(s0, 0)
+        SAPCU_FE_STEP(s0 + 1, 1)
+    }
+#undef SAPCU_FE_STEP
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// In-patch kNN (fd/snn_coder.py:25-32), the arithmetic of patch_knn_kernel<3> (patch_ops.hip): score[i][j] = (-xx[j] - (-2 <xi,xj>))
+// - xx[i] with <.,.> a channel-ascending f32 FMA chain and xx a sequential sum of rounded squares; top-k by descending score,
+// equal scores by ascending index.  `fill(c0, cw)` stages channels c0 .. c0+cw-1 of all 64 rows (rows >= m: 0) into F[row][33].
+// Scores: threads 0..255 as a 16 x 16 grid of 3 x 3 pair blocks; ranks: one wave per row, the row's keys broadcast through
+// scalar registers.  Output: idx_out[i][rank] (bytes, row pitch 48) and the optional int32 tap [m][k].
+// ---------------------------------------------------------------------------------------------
+template <typename Fill>
+__device__ __forceinline__ void fe_knn(unsigned char* R2, float* xx, unsigned char* idx_out, int m, int c, int k, Fill fill,
+                                       int32_t* __restrict__ tap, int tid) {
+    float* F = reinterpret_cast<float*>(R2);
+    unsigned* K = reinterpret_cast<unsigned*>(R2 + FE_KEYS_OFF);
+    const int bi = (tid >> 4) & 15, bj = tid & 15;
+    float acc[3][3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int v = 0; v < 3; ++v) acc[u][v] = 0.f;
+    float myxx = 0.f;
+    for (int c0 = 0; c0 < c; c0 += 32) {
+        const int cw = min(32, c - c0);
+        __syncthreads();
+        fill(c0, cw);
+        __syncthreads();
+        if (tid < 256) {
+            const float* fi = F + (bi * 3) * FE_F_LD;
+            const float* fj = F + (bj * 3) * FE_F_LD;
+            for (int cc = 0; cc < cw; ++cc) {
+                float a[3], bb[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    a[u] = fi[u * FE_F_LD + cc];
+                    bb[u] = fj[u * FE_F_LD + cc];
+                }
+                if (c0 == 0 && cc == 0) {
+#pragma unroll
+                    for (int u = 0; u < 3; ++u)
+#pragma unroll
+                        for (int v = 0; v < 3; ++v) acc[u][v] = __fmul_rn(a[u], bb[v]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 3; ++u)
+#pragma unroll
+                        for (int v = 0; v < 3; ++v) acc[u][v] = __fmaf_rn(a[u], bb[v], acc[u][v]);
+                }
+            }
+            if (tid < m) {
+                const float* fr = F + tid * FE_F_LD;
+                for (int cc = 0; cc < cw; ++cc) {
+                    const float sq = __fmul_rn(fr[cc], fr[cc]);
+                    myxx = (c0 == 0 && cc == 0) ? sq : __fadd_rn(myxx, sq);
+                }
+            }
+        }
+    }
+    if (tid < m) xx[tid] = myxx;
+    __syncthreads();
+    if (tid < 256) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const int i = bi * 3 + u, j = bj * 3 + v;
+                if (i < m && j < m) {
+                    const float inner = __fmul_rn(-2.0f, acc[u][v]);
+                    K[i * (m + 1) + j] = float_max_key(__fadd_rn(__fsub_rn(__fsub_rn(-xx[j], inner), xx[i]), 0.0f));
+                }
+            }
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int full = m * (m - 1) / 2;
+    for (int i = wave; i < m; i += FE_NT / 64) {
+        const unsigned key0 = lane < m ? K[i * (m + 1) + lane] : 0u;
+        int r0 = 0;
+        for (int jb = 0; jb < m; jb += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r0 += (unsigned)__builtin_amdgcn_readlane(key0, (jb + u) & 63) > key0;
+        }
+        int tot = lane < m ? r0 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+        if (tot != full) {                      // (wave-uniform) equal scores in this row: exact (score, index) order
+            const unsigned long long k0 = ((unsigned long long)key0 << 32) | (unsigned)~lane;
+            r0 = 0;
+            for (int jb = 0; jb < m; jb += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int jp = jb + u;
+                    const unsigned long long kv = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(key0, jp & 63) << 32) | (unsigned)~jp;
+                    r0 += kv > k0;
+                }
+            }
+        }
+        if (lane < m && r0 < k) {
+            idx_out[i * FE_M + r0] = (unsigned char)lane;
+            if (tap) tap[i * k + r0] = lane;
+        }
+    }
+}
+
+// T-step neuron loops of this thread's six (point, channel) elements of one K round of multi_scale_conv (rows row0 .. row0+5,
+// one channel): the steps [t0, t0 + nemit) go to the panel as split-f16 rows 48 (t - t0) + point, column kcol of the round
+// (steps before t0 — a second group of steps when T > 4 — are run for the state only).  fd:432-474 with the closed gate.
+template <int KIND>
+__device__ __forceinline__ void fe_emit6(const float (&x)[6], const NeuronP& p, int t0, int nemit, unsigned char* panel, int row0,
+                                         int kcol, int m, bool count, int* __restrict__ gate, float* __restrict__ tap,
+                                         int64_t tap_tstride) {
+    const int total = t0 + nemit;
+    if (KIND == 0) {
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            NeuronS s = neuron_init(p);
+            for (int step = 0; step < total; ++step) {
+                if (count && step > 0 && s.r <= 0.f && row0 + e < m) atomicAdd(gate, 1);
+                const float sp = neuron_step<true>(step == 0 ? x[e] : 0.f, s, p);
+                if (step >= t0) {
+                    fe_put<192>(panel, FE_M * (step - t0) + row0 + e, kcol, sp);
+                    if (tap && row0 + e < m) tap[(int64_t)step * tap_tstride + (int64_t)(row0 + e) * 960] = sp;
+                }
+            }
+        }
+    } else {
+        NeuronStep2<KIND == 1> n0(p), n1(p), n2(p);
+        for (int step = 0; step < total; ++step) {
+            const bool first = step == 0;
+            if (count && !first) {
+                int open = 0;
+                if (n0.gate_open() && row0 < m) ++open;
+                if (n1.gate_open() && row0 + 2 < m) ++open;
+                if (n2.gate_open() && row0 + 4 < m) ++open;
+                if (open) atomicAdd(gate, open);
+            }
+            const f32x2 z = f32x2{0.f, 0.f};
+            const f32x2 s0 = n0.step(first ? f32x2{x[0], x[1]} : z, first);
+            const f32x2 s1 = n1.step(first ? f32x2{x[2], x[3]} : z, first);
+            const f32x2 s2 = n2.step(first ? f32x2{x[4], x[5]} : z, first);
+            if (step >= t0) {
+                const int rb = FE_M * (step - t0) + row0;
+                fe_put<192>(panel, rb, kcol, s0.x);
+                fe_put<192>(panel, rb + 1, kcol, s0.y);
+                fe_put<192>(panel, rb + 2, kcol, s1.x);
+                fe_put<192>(panel, rb + 3, kcol, s1.y);
+                fe_put<192>(panel, rb + 4, kcol, s2.x);
+                fe_put<192>(panel, rb + 5, kcol, s2.y);
+                if (tap) {
+                    const float sv[6] = {s0.x, s0.y, s1.x, s1.y, s2.x, s2.y};
+#pragma unroll
+                    for (int e = 0; e < 6; ++e)
+                        if (row0 + e < m) tap[(int64_t)step * tap_tstride + (int64_t)(row0 + e) * 960] = sv[e];
+                }
+            }
+        }
+    }
+}
+
+// one K round (4 k16 steps, absolute steps 4 r ..) of multi_scale_conv for this wave's column block: 6 row blocks x 1 column block
+struct FeW {
+    half8 wh[2], wl[2];
+};
+__device__ __forceinline__ void fe_msc_round(const unsigned char* X, const half8* __restrict__ wp, int cb, int r, int lane, FeW& W,
+                                             f32x16 (&acc)[6]) {
+    const int r32 = lane & 31, h = lane >> 5, sw = (r32 >> 2) & 3;
+    const unsigned char* xa = X + r32 * 64;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const unsigned ko = (unsigned)((s >> 1) * (192 * 128) + ((((s & 1) * 2 + h) ^ sw) * 16));
+        // row blocks in two halves of three (24 fragment registers instead of 48); per accumulator the product order stays
+        // a_lo w_hi, a_hi w_lo, a_hi w_hi
+#pragma unroll
+        for (int i0 = 0; i0 < 6; i0 += 3) {
+            half8 ah[3], al[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                ah[i] = *reinterpret_cast<const half8*>(xa + ko + (i0 + i) * 2048);
+                al[i] = *reinterpret_cast<const half8*>(xa + ko + (i0 + i) * 2048 + 192 * 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[i0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], W.wh[s & 1], acc[i0 + i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[i0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], W.wl[s & 1], acc[i0 + i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[i0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], W.wh[s & 1], acc[i0 + i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int sa = r * 4 + s + 2;                       // refill the slot behind the MFMAs that read it (60 k16 steps in all)
+        const int sn = sa < 60 ? sa : 59;
+        W.wh[s & 1] = fe_wfrag(wp, 60, cb, sn, 0, lane);
+        W.wl[s & 1] = fe_wfrag(wp, 60, cb, sn, 1, lane);
+    }
+}
+
+__device__ __forceinline__ unsigned fe_half_max(unsigned x) {     // max of the two lane halves' values, in both halves
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return r[0] > r[1] ? r[0] : r[1];
+}
+
+// ---------------------------------------------------------------------------------------------
+// EdgeConv block L = 1..3 (fd:447-474 at t = 0): neighbour search on the step-0 spikes of block L-1, factored EdgeConv GEMM,
+// max over the neighbours, shift + LeakyReLU -> the block's pre-activation x0 (LDS for L <= 2, registers for L = 3).
+// ---------------------------------------------------------------------------------------------
+template <int L>
+__device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char* smem, int64_t patch_i, int tid, float (&x3)[8][6]) {
+    constexpr int CIN = 64 << (L - 1), COUT = 128 << (L - 1);
+    constexpr int COFF_IN = L == 1 ? 0 : (L == 2 ? 64 : 192), COFF_OUT = L == 1 ? 64 : (L == 2 ? 192 : 448);
+    constexpr int KIND_IN = L == 1 ? 0 : (L == 2 ? 1 : 2);
+    constexpr int NPW = L == 3 ? 2 : 1;                    // column-block pairs (W1 + W2 | W1) per wave
+    float* XS = reinterpret_cast<float*>(smem);
+    unsigned char* R2 = smem + FE_OFF_R2;
+    unsigned char* IDXL = smem + FE_OFF_IDXL;
+    float* xx = reinterpret_cast<float*>(smem + FE_OFF_XX);
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = a.m, kk = a.kk;
+
+    // (1) neighbour tables: forced (parity protocol) or ranked in the feature space of block L-1's step-0 spikes
+    const int64_t tab_off = (((int64_t)(L - 1) * a.b_total + a.s0 + patch_i) * m) * kk;
+    if (a.knn_force) {
+        __syncthreads();
+        for (int e = tid; e < m * kk; e += FE_NT) {
+            const int v = a.knn_force[tab_off + e];
+            IDXL[(e / kk) * FE_M + (e % kk)] = (unsigned char)v;
+            if (a.tap_knn) a.tap_knn[tab_off + e] = v;
+        }
+    } else {
+        auto fill = [&](int c0, int cw) {
+            // thread -> channel c0 + (tid & 31), rows (tid >> 5) + 16 n: one parameter load per chunk
+            float* F = reinterpret_cast<float*>(R2);
+            const int cc = tid & 31;
+            const NeuronP p = fe_load_np(a.nprm, COFF_IN + c0 + cc);
+#pragma unroll
+            for (int n = 0; n < 4; n += 2) {
+                const int ia = (tid >> 5) + 16 * n, ib = ia + 16;           // rows < 48 hold x0 (whatever it is beyond m)
+                const f32x2 sp = fe_spike0<KIND_IN>(f32x2{XS[(ia < FE_M ? ia : 0) * FE_XLD + COFF_IN + c0 + cc],
+                                                          XS[(ib < FE_M ? ib : 0) * FE_XLD + COFF_IN + c0 + cc]}, p);
+                F[ia * FE_F_LD + cc] = ia < m ? sp.x : 0.f;
+                F[ib * FE_F_LD + cc] = ib < m ? sp.y : 0.f;
+            }
+            (void)cw;
+        };
+        fe_knn(R2, xx, IDXL, m, CIN, kk, fill, a.tap_knn ? a.tap_knn + tab_off : nullptr, tid);
+    }
+    __syncthreads();
+    // (2) step-0 spikes of block L-1 as the split-f16 operand panel [64 rows][CIN] (rows >= m: whatever x0 holds there — the
+    //     GEMM's rows are independent and those outputs are never used)
+    {
+        const int cc = tid & 63;
+        for (int c0 = 0; c0 < CIN; c0 += 64) {
+            const NeuronP p = fe_load_np(a.nprm, COFF_IN + c0 + cc);
+#pragma unroll
+            for (int n = 0; n < 6; n += 2) {
+                const int ia = (tid >> 6) + 8 * n, ib = ia + 8;            // rows 0..47
+                const f32x2 sp = fe_spike0<KIND_IN>(f32x2{XS[ia * FE_XLD + COFF_IN + c0 + cc], XS[ib * FE_XLD + COFF_IN + c0 + cc]}, p);
+                fe_put<64>(R2, ia, c0 + cc, sp.x);
+                fe_put<64>(R2, ib, c0 + cc, sp.y);
+#ifdef FE_DEBUG_PANEL       // diagnostic build: the f32 values behind the panel, in place of block L-1's x0 in the x0 tap
+                if (a.tap_x0 && ia < m) a.tap_x0[((a.s0 + patch_i) * m + ia) * 960 + COFF_IN + c0 + cc] = sp.x;
+                if (a.tap_x0 && ib < m) a.tap_x0[((a.s0 + patch_i) * m + ib) * 960 + COFF_IN + c0 + cc] = sp.y;
+#endif
+            }
+        }
+    }
+    __syncthreads();
+    // (3) GEMM: pairs pr = w + 8 q; accumulators acc[q][rows i][A' | B]
+    const bool active = L != 1 || w < 4;                   // block 1 has only four pairs
+    f32x16 acc[NPW][4];                                    // [pair][i * 2 + (0: A' = (W1 + W2) x, 1: B = W1 x)]
+    if (active) {
+#pragma unroll
+        for (int q = 0; q < NPW; ++q) {
+            const int pr = w + 8 * q;
+            const int cbs[2] = {pr, COUT / 32 + pr};
+            fe_gemm64<2>(R2, reinterpret_cast<const half8*>(a.edge_wp[L - 1]), CIN / 16, cbs, lane, acc[q]);
+        }
+    }
+    __syncthreads();                                       // every wave has read the panel: R2 becomes the staging area
+    // (4) per pair: stage A' (rows < 48) in this wave's private [48][32] tile, max over the kk neighbours per (point, channel),
+    //     pre = LeakyReLU((max - B) + shift)
+    float* SAw = reinterpret_cast<float*>(R2) + w * (FE_M * 32);
+    const int r32 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < NPW; ++q) {
+        float pre[2][16];
+        if (active) {
+            const int col = 32 * (w + 8 * q) + r32;            // channel of this lane inside the block
+            const float sh = a.shift[L - 1][col];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (32 * i + 8 * (e >> 2) >= FE_M) continue;              // 48 = 6 x 8: whole groups of 8 rows are in or out
+                    const int row = 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
+                    SAw[row * 32 + r32] = __fadd_rn(__fmul_rn(acc[q][i * 2][e], 0.0625f), 0.0f);    // the GEMM epilogue's value (no bias)
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (32 * i + 8 * (e >> 2) >= FE_M) continue;
+                    const int row = 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
+                    const unsigned char* ir = IDXL + row * FE_M;
+                    float mx = -__builtin_huge_valf();
+                    int j = 0;
+                    for (; j + 4 <= kk; j += 4) {
+                        const unsigned pk = *reinterpret_cast<const unsigned*>(ir + j);
+                        mx = fmaxf(mx, SAw[(pk & 255u) * 32 + r32]);
+                        mx = fmaxf(mx, SAw[((pk >> 8) & 255u) * 32 + r32]);
+                        mx = fmaxf(mx, SAw[((pk >> 16) & 255u) * 32 + r32]);
+                        mx = fmaxf(mx, SAw[(pk >> 24) * 32 + r32]);
+                    }
+                    for (; j < kk; ++j) mx = fmaxf(mx, SAw[ir[j] * 32 + r32]);
+                    const float xb = __fadd_rn(__fmul_rn(acc[q][i * 2 + 1][e], 0.0625f), 0.0f);
+                    pre[i][e] = lrelu02(__fadd_rn(__fsub_rn(mx, xb), sh));
+#ifdef FE_DEBUG_AB          // diagnostic build: block 1's GEMM outputs A' | B in columns 192.. | 320.. of the x0 tap
+                    if (L == 1 && a.tap_x0 && row < m) {
+                        a.tap_x0[((a.s0 + patch_i) * m + row) * 960 + 192 + col] = SAw[row * 32 + r32];
+                        a.tap_x0[((a.s0 + patch_i) * m + row) * 960 + 320 + col] = xb;
+                    }
+#endif
+#ifdef FE_DEBUG_AB
+                    if (L == 1)
+#endif
+                    if (a.tap_x0 && row < m) a.tap_x0[((a.s0 + patch_i) * m + row) * 960 + COFF_OUT + col] = pre[i][e];
+                }
+            __builtin_amdgcn_wave_barrier();               // this wave's reads of its tile are done before it is rewritten
+            if (L <= 2) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        if (32 * i + 8 * (e >> 2) >= FE_M) continue;
+                        const int row = 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
+                        XS[row * FE_XLD + COFF_OUT + col] = pre[i][e];
+                    }
+            } else {
+                // block 3: into the tile again, then every thread picks up its (channel, six rows) elements of multi_scale_conv's
+                // K rounds: round j of this half = columns 64 j .. 64 j + 63 = the tiles of waves 2 j, 2 j + 1
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        if (32 * i + 8 * (e >> 2) >= FE_M) continue;
+                        const int row = 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
+                        SAw[row * 32 + r32] = pre[i][e];
+                    }
+            }
+        }
+        if (L == 3) {
+            __syncthreads();
+            const float* SA = reinterpret_cast<const float*>(R2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 6; ++e)
+                    x3[4 * q + j][e] = SA[(2 * j + (lane >> 5)) * (FE_M * 32) + (6 * w + e) * 32 + (lane & 31)];
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    float* XS = reinterpret_cast<float*>(smem);
+    unsigned char* R2 = smem + FE_OFF_R2;
+    float4* XYZ = reinterpret_cast<float4*>(smem + FE_OFF_XYZ);
+    unsigned char* IDX0 = smem + FE_OFF_IDX0;
+    float* xx = reinterpret_cast<float*>(smem + FE_OFF_XX);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, h = lane >> 5;
+    const int m = a.m;
+    const int64_t patch_i = blockIdx.x;
+    const float* __restrict__ pp = a.patch + patch_i * m * 3;
+
+    // ---- patch coordinates; neighbour tables start as "point 0" so that rows >= m never index outside a staging tile
+    for (int e = tid; e < FE_M; e += FE_NT)
+        XYZ[e] = e < m ? make_float4(pp[3 * e], pp[3 * e + 1], pp[3 * e + 2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = tid; e < 2 * FE_M * FE_M / 4; e += FE_NT) reinterpret_cast<unsigned*>(IDX0)[e] = 0u;
+    __syncthreads();
+    // ---- block 0: xyz neighbours (one ranking serves all scales)                                          fd:411-417
+    {
+        auto fill = [&](int c0, int cw) {
+            float* F = reinterpret_cast<float*>(R2);
+            for (int e = tid; e < 64 * 3; e += FE_NT) {
+                const int i = e / 3, cc = e % 3;
+                const float4 v = XYZ[i < FE_M ? i : 0];
+                F[i * FE_F_LD + cc] = i < m ? (cc == 0 ? v.x : (cc == 1 ? v.y : v.z)) : 0.f;
+            }
+            (void)c0; (void)cw;
+        };
+        fe_knn(R2, xx, IDX0, m, 3, a.kmax0, fill, nullptr, tid);
+    }
+    __syncthreads();
+    // ---- block 0: EdgeConv(6 -> 64) per scale, max over the ks nearest, + bias, LeakyReLU -> split panel [64][64 S]   fd:413-420
+    {
+        float wt[4][6], bb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) wt[s][t] = s < a.nscale ? a.e0_w[((int64_t)s * 64 + lane) * 6 + t] : 0.f;
+            bb[s] = s < a.nscale ? a.e0_b[s * 64 + lane] : 0.f;
+        }
+        float big = 0.f;
+        for (int i = 2 * w; i < m; i += 16) {
+            const int i1 = (i + 1 < m) ? i + 1 : i;
+            const float4 pa = XYZ[i], pb = XYZ[i1];
+            const f32x2 xi = f32x2{pa.x, pb.x}, yi = f32x2{pa.y, pb.y}, zi = f32x2{pa.z, pb.z};
+            f32x2 mx[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mx[s] = f32x2{-__builtin_huge_valf(), -__builtin_huge_valf()};
+            for (int j = 0; j < a.kmax0; ++j) {
+                const float4 qa = XYZ[IDX0[i * FE_M + j]], qb = XYZ[IDX0[i1 * FE_M + j]];
+                const f32x2 xj = f32x2{qa.x, qb.x}, yj = f32x2{qa.y, qb.y}, zj = f32x2{qa.z, qb.z};
+                const f32x2 dx = xj - xi, dy = yj - yi, dz = zj - zi;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (s < a.nscale && j < a.ks[s]) {
+                        f32x2 v = f32x2{wt[s][0], wt[s][0]} * dx;
+                        v = pk_fma(f32x2{wt[s][1], wt[s][1]}, dy, v);
+                        v = pk_fma(f32x2{wt[s][2], wt[s][2]}, dz, v);
+                        v = pk_fma(f32x2{wt[s][3], wt[s][3]}, xj, v);
+                        v = pk_fma(f32x2{wt[s][4], wt[s][4]}, yj, v);
+                        v = pk_fma(f32x2{wt[s][5], wt[s][5]}, zj, v);
+                        mx[s] = f32x2{fmaxf(mx[s].x, v.x), fmaxf(mx[s].y, v.y)};
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s < a.nscale) {
+                    const float va = lrelu02(__fadd_rn(mx[s].x, bb[s])), vb = lrelu02(__fadd_rn(mx[s].y, bb[s]));
+                    fe_put<64>(R2, i, s * 64 + lane, va);
+                    if (i1 != i) fe_put<64>(R2, i1, s * 64 + lane, vb);
+                    big = fmaxf(big, fmaxf(fabsf(va), fabsf(vb)));
+                }
+            }
+        }
+        if (!(big < 65504.0f) && a.ovf) atomicAdd(a.ovf, 1);
+    }
+    __syncthreads();
+    // ---- block 0: scale_fusion (64 S -> 64) + BN + LeakyReLU = x0 of block 0                                fd:420-421
+    if (w < 2) {
+        f32x16 acc[2];
+        const int cbs[1] = {w};
+        fe_gemm64<1>(R2, reinterpret_cast<const half8*>(a.fuse_wp), 4 * a.nscale, cbs, lane, acc);
+        const int col = 32 * w + r32;
+        const float bias = a.fuse_b[col];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if (32 * i + 8 * (e >> 2) >= FE_M) continue;
+                const int row = 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
+                const float v = lrelu02(__fadd_rn(__fmul_rn(acc[i][e], 0.0625f), bias));
+                XS[row * FE_XLD + col] = v;
+                if (a.tap_fused0 && row < m) a.tap_fused0[((a.s0 + patch_i) * m + row) * 64 + col] = v;
+                if (a.tap_x0 && row < m) a.tap_x0[((a.s0 + patch_i) * m + row) * 960 + col] = v;
+            }
+    }
+    __syncthreads();
+    // ---- blocks 1..3                                                                                          fd:447-474
+    float x3[8][6];
+    fe_edge_block<1>(a, smem, patch_i, tid, x3);
+    fe_edge_block<2>(a, smem, patch_i, tid, x3);
+    fe_edge_block<3>(a, smem, patch_i, tid, x3);
+
+    // ---- multi_scale_conv over all steps + max over the points                                               fd:476-480
+    const int row0 = 6 * w;
+    const int npass = a.emb / 256;
+    const half8* __restrict__ mscw = reinterpret_cast<const half8*>(a.msc_wp);
+    const int64_t tap_tstride = a.b_total * (int64_t)m * 960;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int cb = pass * 8 + w;
+        const int col = 32 * cb + r32;
+        const float bias = a.msc_b[col];
+        for (int t0 = 0; t0 < a.T; t0 += 4) {
+            const int nemit = a.T - t0 < 4 ? a.T - t0 : 4;
+            const bool count = pass == 0 && t0 + nemit == a.T;         // the gate check runs once, over all T steps
+            float* tap = (a.tap_spikes && pass == 0) ? a.tap_spikes + (a.s0 + patch_i) * (int64_t)m * 960 : nullptr;
+            f32x16 acc[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+            FeW W;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                W.wh[s] = fe_wfrag(mscw, 60, cb, s, 0, lane);
+                W.wl[s] = fe_wfrag(mscw, 60, cb, s, 1, lane);
+            }
+            // rounds 0..6: blocks 0-2 from LDS (column 64 r + lane); a round's neuron parameters are loaded one round ahead
+            NeuronP pnext = fe_load_np(a.nprm, lane);
+            for (int r = 0; r < 7; ++r) {
+                const int c = 64 * r + lane;
+                const NeuronP p = pnext;
+                pnext = fe_load_np(a.nprm, c + 64);
+                float x[6];
+#pragma unroll
+                for (int e = 0; e < 6; ++e) x[e] = XS[(row0 + e) * FE_XLD + c];
+                if (r == 0) fe_emit6<0>(x, p, t0, nemit, R2, row0, lane, m, count, a.gate, tap ? tap + c : nullptr, tap_tstride);
+                else if (r < 3) fe_emit6<1>(x, p, t0, nemit, R2, row0, lane, m, count, a.gate, tap ? tap + c : nullptr, tap_tstride);
+                else fe_emit6<2>(x, p, t0, nemit, R2, row0, lane, m, count, a.gate, tap ? tap + c : nullptr, tap_tstride);
+                lds_barrier();
+                fe_msc_round(R2, mscw, cb, r, lane, W, acc);
+                lds_barrier();
+            }
+            // rounds 7..14: block 3 from registers
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = 448 + 64 * j + lane;
+                const NeuronP p = pnext;
+                pnext = fe_load_np(a.nprm, j < 7 ? c + 64 : c);
+                fe_emit6<2>(x3[j], p, t0, nemit, R2, row0, lane, m, count, a.gate, tap ? tap + c : nullptr, tap_tstride);
+                lds_barrier();
+                fe_msc_round(R2, mscw, cb, 7 + j, lane, W, acc);
+                lds_barrier();
+            }
+            // epilogue: + bias, LeakyReLU, max over the patch's points per step (row = 48 tt + point), integer keys
+            unsigned best[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rbase = 32 * i + 8 * (e >> 2);                  // 48 = 6 x 8: a group of 8 rows never straddles two steps
+                    const int tt = rbase / FE_M;
+                    const int pt = rbase % FE_M + 4 * h + (e & 3);
+                    if (pt < m) {
+                        const unsigned key = float_max_key(lrelu02(__fadd_rn(__fmul_rn(acc[i][e], 0.0625f), bias)));
+                        best[tt] = best[tt] > key ? best[tt] : key;
+                    }
+                }
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const unsigned k2 = fe_half_max(best[tt]);
+                if (h == 0 && tt < nemit) a.pooled[((int64_t)(t0 + tt) * a.b + patch_i) * a.emb + col] = float_from_max_key(k2);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// model-build helpers: weights in fragment order, clamped neuron parameters
+// ---------------------------------------------------------------------------------------------
+// out[((cb * nk16 + s) * 2 + plane) * 64 + lane][j] = w16_plane[32 cb + (lane & 31)][16 s + 8 (lane >> 5) + j],  w [n, k] row-major
+__global__ __launch_bounds__(256) void pack_frag_weights_kernel(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo,
+                                                                int n, int k, _Float16* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nk16 = k / 16;
+    const int64_t total = (int64_t)(n / 32) * nk16 * 2 * 64;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    const int plane = (int)((t >> 6) & 1);
+    const int64_t cs = t >> 7;
+    const int s = (int)(cs % nk16), cb = (int)(cs / nk16);
+    const _Float16* src = (plane ? lo : hi) + (int64_t)(32 * cb + (lane & 31)) * k + 16 * s + 8 * (lane >> 5);
+    *reinterpret_cast<half8*>(out + t * 8) = *reinterpret_cast<const half8*>(src);
+}
+
+int launch_pack_frag_weights(const void* w16_hi, const void* w16_lo, int n, int k, void* out, hipStream_t st) {
+    SAPCU_CHECK_ARG(n % 32 == 0 && k % 16 == 0, "pack_frag_weights: need n %% 32 == 0 and k %% 16 == 0 (n=%d k=%d)", n, k);
+    const int64_t total = (int64_t)(n / 32) * (k / 16) * 2 * 64;
+    hipLaunchKernelGGL(pack_frag_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const _Float16*)w16_hi,
+                       (const _Float16*)w16_lo, n, k, (_Float16*)out);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+// out[(coff + c) * 8 + ..] = clamped (decay, adapt, rdecay, theta0, dT, rh, 0, 0) of channel c of a raw [4 | 6][C] parameter block
+__global__ __launch_bounds__(256) void pack_fd_neuron_kernel(const float* __restrict__ raw, int C, int eif, int coff, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const NeuronP p = eif ? load_eif(raw, C, c) : load_lif(raw, C, c);
+    float* o = out + (int64_t)(coff + c) * 8;
+    o[0] = p.decay; o[1] = p.adapt; o[2] = p.rdecay; o[3] = p.theta0; o[4] = p.dT; o[5] = p.rh; o[6] = 0.f; o[7] = 0.f;
+}
+
+int launch_pack_fd_neuron(const float* raw, int C, int eif, int coff, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(pack_fd_neuron_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, raw, C, eif, coff, out);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+bool fd_encoder_ok(int m, int nscale, int emb, int T) { return m >= 1 && m <= FE_M && nscale >= 1 && nscale <= 4 && emb % 256 == 0 && emb >= 256 && T >= 1; }
+
+int launch_fd_encoder(const FdEncArgs& a, hipStream_t st) {
+    if (a.b == 0) return SAPCU_OK;
+    SAPCU_CHECK_ARG(fd_encoder_ok(a.m, a.nscale, a.emb, a.T), "fd_encoder: unsupported shape m=%d scales=%d emb=%d", a.m, a.nscale, a.emb);
+    SAPCU_CHECK_ARG(a.kk >= 1 && a.kk <= a.m && a.kmax0 >= 1 && a.kmax0 <= a.m && a.b < 0x7fffffffLL, "fd_encoder: bad neighbour counts");
+    static DeviceOnce lds_once;
+    SAPCU_SET_MAX_LDS(lds_once, (&fd_encoder_kernel), FE_LDS);
+    hipLaunchKernelGGL(fd_encoder_kernel, dim3((unsigned)a.b), dim3(FE_NT), FE_LDS, st, a);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+}  // namespace sapcu

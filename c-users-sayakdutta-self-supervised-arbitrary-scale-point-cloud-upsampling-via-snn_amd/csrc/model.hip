@@ -96,6 +96,12 @@ struct sapcu_model {
     bool opt_fn_maxfuse;       // SAPCU_FN_MAXFUSE=0: conv_final GEMM + rowgroup_max
     bool opt_fd_maxfuse;       // SAPCU_FD_MAXFUSE=0: multi_scale_conv GEMM + rowgroup_max
     bool opt_fd_split;         // SAPCU_FD_SPLIT=0: fd spikes as f32 rows for every step
+    bool opt_fd_fused;         // SAPCU_FD_FUSED=0: fd encoder on the per-stage kernels (through HBM) instead of fd_encoder.hip
+    // fd, fused encoder (fd_encoder.hip): scale_fusion | EdgeConv 1-3 | multi_scale_conv in MFMA-fragment order, clamped neuron
+    // parameters of the 960 encoder channels
+    void* fde_w;
+    int64_t fde_off[5];        // offsets (halves) of the five matrices inside fde_w
+    float* fde_nprm;
     float* blob;
     int64_t blob_floats;
     std::vector<int64_t> dir;
@@ -415,19 +421,30 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
 struct FdPlan {
     int64_t cb;
     int kmax0, kk;
+    bool fused;                // the whole encoder in fd_encoder.hip: no per-point intermediates in the workspace
     bool maxfuse;              // multi_scale_conv's max over points inside the GEMM: the [T*P, emb] aggregate is never written
     int64_t agg_rows(int mp) const { return maxfuse ? 1 : mp; }   // rows of the AGG area per (step, patch): keys only, or the aggregate
 };
 
 // does the encoder run as ONE LDS-resident kernel per patch (fd_encoder.hip)?  Same answer for the workspace plan and the forward.
 static bool fd_encoder_fused(const sapcu_model* m, int mp) {
-    (void)m; (void)mp;
-    return false;
+    return m->sf16 && m->opt_fd_fused && m->fde_w && m->fde_nprm && fd_encoder_ok(mp, m->nscale, m->emb, m->T);
 }
 
 static FdPlan fd_plan(const sapcu_model* m, int64_t b, int mp) {
     FdPlan pl;
+    pl.fused = fd_encoder_fused(m, mp);
     pl.maxfuse = m->sf16 && m->opt_fd_maxfuse;
+    if (pl.fused) {
+        // the encoder's intermediates never leave the CU: per patch only pooled [T, emb], the encoding and the decoder's rows
+        const int64_t per_patch_f = ((int64_t)(m->T + 1) * m->emb + 256 + 3 * 128 + 3 * 64 + 192 + 64) * 4;
+        pl.cb = chunk_patches(m, b, per_patch_f);
+        int kmaxf = 1;
+        for (int i = 0; i < m->nscale; ++i) kmaxf = kmaxf > m->ks[i] ? kmaxf : m->ks[i];
+        pl.kmax0 = imin(kmaxf, mp);
+        pl.kk = imin(m->k, mp);
+        return pl;
+    }
     // fd intermediates: T x 960 spikes (+ the T x emb aggregate per point only when the max is NOT taken inside the GEMM) + 960 +
     // 1024 + block-0 features per point, neighbour tables
     int kmax0 = 1;
@@ -449,9 +466,11 @@ static int64_t fd_ws_bytes(const sapcu_model* m, int64_t b, int mp) {
     const int64_t P = pl.cb * mp;
     int64_t fl = 0;
     auto add = [&](int64_t n, int64_t esz) { fl += ((n * esz) + 255) & ~(int64_t)255; };
-    add(P * pl.kmax0, 4); add(3 * P * pl.kk, 4);
-    add(P * 64 * m->nscale, 4); add(P * 64, 4);
-    add((int64_t)m->T * P * 960, 4); add(P * 960, 4); add(P * 1024, 4); add((int64_t)m->T * pl.cb * pl.agg_rows(mp) * m->emb, 4);
+    if (!pl.fused) {
+        add(P * pl.kmax0, 4); add(3 * P * pl.kk, 4);
+        add(P * 64 * m->nscale, 4); add(P * 64, 4);
+        add((int64_t)m->T * P * 960, 4); add(P * 960, 4); add(P * 1024, 4); add((int64_t)m->T * pl.cb * pl.agg_rows(mp) * m->emb, 4);
+    }
     add((int64_t)m->T * pl.cb * m->emb, 4); add(pl.cb * m->emb, 4);
     add(pl.cb * 256, 4);
     for (int i = 0; i < 3; ++i) add(pl.cb * 128, 4);
@@ -473,14 +492,16 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
         const int64_t cb = (b - s) < pl.cb ? (b - s) : pl.cb;
         const int64_t P = cb * mp;
         Arena A{(char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), ws_bytes, 0};
-        int32_t* idx0 = A.take<int32_t>(pl.cb * mp * pl.kmax0);
-        int32_t* idxb = A.take<int32_t>(3 * pl.cb * mp * pl.kk);
-        float* E0 = A.take<float>(pl.cb * mp * 64 * m->nscale);
-        float* FUSED = A.take<float>(pl.cb * mp * 64);
-        float* SPK = A.take<float>((int64_t)T * pl.cb * mp * 960);
-        float* F0 = A.take<float>(pl.cb * mp * 960);
-        float* AB = A.take<float>(pl.cb * mp * 1024);
-        float* AGG = A.take<float>((int64_t)T * pl.cb * pl.agg_rows(mp) * emb);       // maxfuse: T*cb*emb keys only
+        // per-point intermediates exist only on the per-stage path (the fused encoder keeps them on the CU)
+        const int64_t pp = pl.fused ? 0 : 1;
+        int32_t* idx0 = A.take<int32_t>(pp * pl.cb * mp * pl.kmax0);
+        int32_t* idxb = A.take<int32_t>(pp * 3 * pl.cb * mp * pl.kk);
+        float* E0 = A.take<float>(pp * pl.cb * mp * 64 * m->nscale);
+        float* FUSED = A.take<float>(pp * pl.cb * mp * 64);
+        float* SPK = A.take<float>(pp * (int64_t)T * pl.cb * mp * 960);
+        float* F0 = A.take<float>(pp * pl.cb * mp * 960);
+        float* AB = A.take<float>(pp * pl.cb * mp * 1024);
+        float* AGG = A.take<float>(pp * (int64_t)T * pl.cb * pl.agg_rows(mp) * emb);       // maxfuse: T*cb*emb keys only
         float* POOLED = A.take<float>((int64_t)T * pl.cb * emb);
         float* ENC = A.take<float>(pl.cb * emb);
         float* D1 = A.take<float>(pl.cb * 256);
@@ -494,6 +515,31 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
         float* ATT = A.take<float>(pl.cb * 64);
         const float* pc = patch + s * mp * 3;
 
+        if (pl.fused) {
+            // the whole encoder up to pooled [T, cb, emb] in ONE launch, one workgroup per patch (fd_encoder.hip)   fd:408-480
+            FdEncArgs ea;
+            memset(&ea, 0, sizeof(ea));
+            ea.patch = pc; ea.b = cb; ea.b_total = b; ea.s0 = s;
+            ea.m = mp; ea.T = T; ea.kk = pl.kk; ea.kmax0 = pl.kmax0; ea.nscale = m->nscale; ea.emb = emb;
+            for (int i = 0; i < 4; ++i) ea.ks[i] = i < m->nscale ? imin(m->ks[i], mp) : 0;
+            ea.e0_w = m->p(FD_E0_W); ea.e0_b = m->p(FD_E0_B);
+            const _Float16* fw = (const _Float16*)m->fde_w;
+            ea.fuse_wp = fw + m->fde_off[0]; ea.fuse_b = m->p(FD_FUSE_B);
+            for (int l = 0; l < 3; ++l) {
+                ea.edge_wp[l] = fw + m->fde_off[1 + l];
+                ea.shift[l] = m->p(FD_EDGE1_SHIFT + 3 * l);
+            }
+            ea.msc_wp = fw + m->fde_off[4]; ea.msc_b = m->p(FD_MSC_B);
+            ea.nprm = m->fde_nprm;
+            ea.pooled = POOLED;
+            ea.knn_force = knn_force;
+            ea.tap_knn = taps ? (int32_t*)taps[SAPCU_FD_TAP_KNN] : nullptr;
+            ea.tap_fused0 = taps ? (float*)taps[SAPCU_FD_TAP_FUSED0] : nullptr;
+            ea.tap_spikes = taps ? (float*)taps[SAPCU_FD_TAP_SPIKES] : nullptr;
+            ea.tap_x0 = taps ? (float*)taps[SAPCU_FD_TAP_X0] : nullptr;
+            ea.gate = m->gate_dev; ea.ovf = m->ovf_dev;
+            SAPCU_TRY(launch_fd_encoder(ea, st));
+        } else {
         // block 0: xyz kNN (all scales are prefixes of the sorted top-kmax list), EdgeConv x S,
         // scale fusion, EIF over T steps                                           fd:411-444
         SAPCU_TRY(launch_patch_knn(pc, cb, mp, 3, 3, pl.kmax0, idx0, st));
@@ -501,6 +547,8 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
         SAPCU_TRY(gemm(m, E0, P, 64 * m->nscale, 64 * m->nscale, m->p(FD_FUSE_W), 64, m->p(FD_FUSE_B), FUSED, 64,
                        EPI_LRELU, st));
         SAPCU_TRY(tap_copy(taps, SAPCU_FD_TAP_FUSED0, s * mp * 64 * 4, FUSED, P * 64 * 4, st));
+        float* const X0T = (taps && taps[SAPCU_FD_TAP_X0]) ? (float*)taps[SAPCU_FD_TAP_X0] + s * mp * 960 : nullptr;
+        if (X0T) SAPCU_CHECK_HIP(hipMemcpy2DAsync(X0T, 960 * 4, FUSED, 64 * 4, 64 * 4, (size_t)P, hipMemcpyDeviceToDevice, st));
         // multi_scale_conv's operand: split rows written by the neuron kernels themselves (the GEMM then streams them by LDS-DMA
         // on the big-tile kernel and takes the max over the points in its epilogue) whenever that kernel takes the shape; the
         // step-0 spikes also go to F0 as f32 for the next blocks' neighbour search and EdgeConv.  Otherwise (tiny batches,
@@ -545,6 +593,7 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
                 SAPCU_TRY(gemm(m, F, P, cin[l], 960, m->p(ew), 2 * cout[l], nullptr, AB, 2 * cout[l], EPI_BIAS, st));
             SAPCU_TRY(launch_fd_neuron(l == 1, 1, AB, 2 * cout[l], idl, pl.kk, mp, m->p(ew + 1), P, cout[l], m->p(ew + 2),
                                        T, SPK0, 960, coff[l], nullptr, m->gate_dev, st, SPKS));
+            if (X0T) SAPCU_TRY(launch_fd_pre(AB, 2 * cout[l], idl, pl.kk, mp, m->p(ew + 1), P, cout[l], X0T, 960, coff[l], st));
         }
         if (taps && taps[SAPCU_FD_TAP_SPIKES]) {
             for (int t = 0; t < T; ++t)
@@ -563,6 +612,7 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
             SAPCU_TRY(gemm(m, SPK, (int64_t)T * P, 960, 960, m->p(FD_MSC_W), emb, m->p(FD_MSC_B), AGG, emb, EPI_LRELU, st));
             SAPCU_TRY(launch_rowgroup_max(AGG, (int64_t)T * cb, mp, emb, POOLED, st));
         }
+        }   // per-stage encoder
         if (taps && taps[SAPCU_FD_TAP_POOLED]) {
             for (int t = 0; t < T; ++t)
                 SAPCU_CHECK_HIP(hipMemcpyAsync((float*)taps[SAPCU_FD_TAP_POOLED] + ((int64_t)t * b + s) * emb,
@@ -792,6 +842,8 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
     m->w16_lo = nullptr;
     m->chain_w = nullptr;
     m->ovf_dev = nullptr;
+    m->fde_w = nullptr;
+    m->fde_nprm = nullptr;
     const char* ge = getenv("SAPCU_GEMM");
     m->sf16 = !(ge && strcmp(ge, "f32") == 0);
     m->opt_bt = !env_off("SAPCU_BT");
@@ -799,6 +851,10 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
     m->opt_fn_maxfuse = !env_off("SAPCU_FN_MAXFUSE");
     m->opt_fd_maxfuse = !env_off("SAPCU_FD_MAXFUSE");
     m->opt_fd_split = !env_off("SAPCU_FD_SPLIT");
+    {   // (opt-in until it beats the per-stage kernels: SAPCU_FD_FUSED=1)
+        const char* fe = getenv("SAPCU_FD_FUSED");
+        m->opt_fd_fused = fe && strcmp(fe, "1") == 0;
+    }
     const char* ce = getenv("SAPCU_CHUNK");
     m->chunk = ce ? atoll(ce) : 0;
     if (m->chunk < 0) m->chunk = 0;
@@ -893,6 +949,29 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
             if (rc == SAPCU_OK) hip_ok(hipMemcpy(m->ks_dev, m->ks, 8 * sizeof(int32_t), hipMemcpyHostToDevice), "copy ks");
             if (rc == SAPCU_OK) hip_ok(hipMalloc((void**)&m->gate_dev, sizeof(int)), "hipMalloc(gate)");
             if (rc == SAPCU_OK) hip_ok(hipMemset(m->gate_dev, 0, sizeof(int)), "memset gate");
+            // the fused encoder's operands: five matrices in fragment order (hi | lo planes interleaved per fragment), neuron
+            // parameters clamped once
+            if (rc == SAPCU_OK && m->sf16 && m->nscale <= 4 && m->emb % 256 == 0) {
+                const int mats[5][3] = {{FD_FUSE_W, 64, 64 * m->nscale}, {FD_EDGE1_W, 256, 64}, {FD_EDGE2_W, 512, 128},
+                                        {FD_EDGE3_W, 1024, 256}, {FD_MSC_W, m->emb, 960}};
+                int64_t halves = 0;
+                for (int i = 0; i < 5; ++i) {
+                    m->fde_off[i] = halves;
+                    halves += (int64_t)2 * mats[i][1] * mats[i][2];
+                }
+                hip_ok(hipMalloc(&m->fde_w, (size_t)halves * 2), "hipMalloc(fde_w)");
+                if (rc == SAPCU_OK) hip_ok(hipMalloc((void**)&m->fde_nprm, 960 * 8 * sizeof(float)), "hipMalloc(fde_nprm)");
+                for (int i = 0; i < 5 && rc == SAPCU_OK; ++i) {
+                    const int64_t wo = m->dir[mats[i][0]];
+                    if (launch_pack_frag_weights((const _Float16*)m->w16_hi + wo, (const _Float16*)m->w16_lo + wo, mats[i][1], mats[i][2],
+                                                 (_Float16*)m->fde_w + m->fde_off[i], nullptr) != SAPCU_OK)
+                        rc = SAPCU_ERR_HIP;
+                }
+                static const int nslot[4] = {FD_SNN0, FD_SNN1, FD_SNN2, FD_SNN3}, nch[4] = {64, 128, 256, 512}, noff[4] = {0, 64, 192, 448};
+                for (int i = 0; i < 4 && rc == SAPCU_OK; ++i)
+                    if (launch_pack_fd_neuron(m->p(nslot[i]), nch[i], i < 2 ? 1 : 0, noff[i], m->fde_nprm, nullptr) != SAPCU_OK) rc = SAPCU_ERR_HIP;
+                if (rc == SAPCU_OK) hip_ok(hipDeviceSynchronize(), "pack fd encoder operands");
+            }
         }
     }
     if (rc != SAPCU_OK) {
@@ -903,6 +982,8 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
         if (m->blob) (void)hipFree(m->blob);
         if (m->ks_dev) (void)hipFree(m->ks_dev);
         if (m->gate_dev) (void)hipFree(m->gate_dev);
+        if (m->fde_w) (void)hipFree(m->fde_w);
+        if (m->fde_nprm) (void)hipFree(m->fde_nprm);
         delete m;
         return rc;
     }
@@ -919,6 +1000,8 @@ int sapcu_model_destroy(sapcu_model_t m) {
     if (m->blob) (void)hipFree(m->blob);
     if (m->ks_dev) (void)hipFree(m->ks_dev);
     if (m->gate_dev) (void)hipFree(m->gate_dev);
+    if (m->fde_w) (void)hipFree(m->fde_w);
+    if (m->fde_nprm) (void)hipFree(m->fde_nprm);
     delete m;
     return SAPCU_OK;
 }

@@ -58,6 +58,38 @@ int launch_fd_edge0(const float* patch, const int32_t* idx, int kmax, int64_t pt
 int launch_fd_neuron(bool eif, int mode, const float* in, int ldi, const int32_t* idx, int kk, int m,
                      const float* shift, int64_t pts, int C, const float* prm, int T, float* spk, int ldo, int coff,
                      float* pre_out, int* gate_violations, hipStream_t st, float* spk_split = nullptr);   // spk_split: see fd_neuron_kernel
+// fused fd encoder (fd_encoder.hip)
+typedef _Float16 fe_half8 __attribute__((ext_vector_type(8)));
+struct FdEncArgs {
+    const float* patch;          // [b, m, 3] rotated patches of this launch
+    int64_t b;                   // patches of this launch (pooled is [T, b, emb])
+    int64_t b_total, s0;         // the forward's batch and this launch's first patch in it (tap / knn_force indexing)
+    int m, T, kk, kmax0, nscale, emb;
+    int ks[4];                   // clamped to m
+    const float* e0_w;           // [S][64][6]
+    const float* e0_b;           // [S][64]
+    const _Float16* fuse_wp;     // scale_fusion [64, 64 S] in fragment order (launch_pack_frag_weights)
+    const float* fuse_b;
+    const _Float16* edge_wp[3];  // EdgeConv l: [2 C', C] in fragment order (rows 0..C'-1: W1 + W2, rows C'..: W1)
+    const float* shift[3];
+    const _Float16* msc_wp;      // multi_scale_conv [emb, 960] in fragment order
+    const float* msc_b;
+    const float* nprm;           // [960][8] clamped neuron parameters (decay, adapt, rdecay, theta0, dT, rh, 0, 0)
+    float* pooled;               // [T, b, emb]
+    const int32_t* knn_force;    // [3][b_total][m][kk] or null
+    int32_t* tap_knn;            // [3][b_total][m][kk] or null
+    float* tap_fused0;           // [b_total, m, 64] or null
+    float* tap_spikes;           // [T, b_total, m, 960] or null
+    float* tap_x0;               // [b_total, m, 960] or null
+    int* gate;                   // refractory gate found open at t >= 1 (must stay 0)
+    int* ovf;                    // a block-0 EdgeConv value beyond the f16 range of the split operand
+};
+bool fd_encoder_ok(int m, int nscale, int emb, int T);
+int launch_fd_encoder(const FdEncArgs& a, hipStream_t st);
+int launch_pack_frag_weights(const void* w16_hi, const void* w16_lo, int n, int k, void* out, hipStream_t st);
+int launch_pack_fd_neuron(const float* raw, int C, int eif, int coff, float* out, hipStream_t st);
+int launch_fd_pre(const float* in, int ldi, const int32_t* idx, int kk, int m, const float* shift, int64_t pts, int C, float* out,
+                  int ldo, int coff, hipStream_t st);      // x0 tap of the per-stage path (debug)
 int launch_fd_temporal(const float* pooled, int T, int64_t b, int emb, const float* tw, const float* lif, float* out,
                        hipStream_t st);
 int launch_fd_tail(const float* x, const float* qkv, int64_t b, int heads, const float* wo_t, const float* bo,

@@ -988,6 +988,30 @@ __global__ __launch_bounds__(FDE_CH * FDE_NH) void fd_edge_neuron_kernel(const f
     }
 }
 
+// debug tap (SAPCU_FD_TAP_X0) of the per-stage path: the MODE 1 pre-activation alone, out[row * ldo + coff + c]
+__global__ __launch_bounds__(256) void fd_pre_kernel(const float* __restrict__ in, int ldi, const int32_t* __restrict__ idx, int kk, int m,
+                                                     const float* __restrict__ shift, int64_t pts, int C, float* __restrict__ out, int ldo,
+                                                     int coff) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pts * C) return;
+    const int c = (int)(t % C);
+    const int64_t row = t / C;
+    const int64_t patch_i = row / m;
+    const int32_t* ir = idx + row * kk;
+    float mx = -__builtin_huge_valf();
+    for (int j = 0; j < kk; ++j) mx = fmaxf(mx, in[(patch_i * m + ir[j]) * ldi + c]);
+    out[row * ldo + coff + c] = lrelu02(__fadd_rn(__fsub_rn(mx, in[row * ldi + C + c]), shift[c]));
+}
+
+int launch_fd_pre(const float* in, int ldi, const int32_t* idx, int kk, int m, const float* shift, int64_t pts, int C, float* out,
+                  int ldo, int coff, hipStream_t st) {
+    if (pts == 0) return SAPCU_OK;
+    hipLaunchKernelGGL(fd_pre_kernel, dim3((unsigned)((pts * C + 255) / 256)), dim3(256), 0, st, in, ldi, idx, kk, m, shift, pts, C, out,
+                       ldo, coff);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
 int launch_fd_neuron(bool eif, int mode, const float* in, int ldi, const int32_t* idx, int kk, int m,
                      const float* shift, int64_t pts, int C, const float* prm, int T, float* spk, int ldo, int coff,
                      float* pre_out, int* gate_violations, hipStream_t st, float* spk_split) {
