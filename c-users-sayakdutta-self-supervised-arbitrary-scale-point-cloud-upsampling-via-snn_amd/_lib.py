@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsapcu_hip.so")
 
 FN_TAPS = ("stem", "block1", "block2", "block3", "pooled", "enc", "logits")
-FD_TAPS = ("fused0", "spikes", "knn", "pooled", "enc")
+FD_TAPS = ("fused0", "spikes", "knn", "pooled", "enc", "x0")
 KIND_FN, KIND_FD = 0, 1
 
 

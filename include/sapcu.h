@@ -217,7 +217,9 @@ enum {
     SAPCU_FD_TAP_KNN = 2,     /* [3][b,m,kk] int32 feature-space neighbours, blocks 1-3 (t=0) */
     SAPCU_FD_TAP_POOLED = 3,  /* [T,b,emb]     pooled_t                        fd:479  */
     SAPCU_FD_TAP_ENC = 4,     /* [b,emb]       encoder output                  fd:492  */
-    SAPCU_FD_TAP_COUNT = 5
+    SAPCU_FD_TAP_X0 = 5,      /* [b,m,960]     neuron inputs at t=0 of the four blocks (scale_fusion output | EdgeConv 1-3
+                                 after max + BN + LeakyReLU)                      fd:421,455-470 */
+    SAPCU_FD_TAP_COUNT = 6
 };
 
 /* fn forward — ImprovedSNNNormalEstimation.forward on [b,m,3] (fn/snn_coder.py:670-699)

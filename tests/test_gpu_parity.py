@@ -1433,6 +1433,47 @@ def test_fd_max_over_points_fused_into_the_gemm_is_bit_identical(weights, monkey
     assert all(fd.gate_violations() == 0 for fd in variants)
 
 
+def _fd_taps(nq, mpts, T, kk, emb=768):
+    z = lambda *sh: torch.full(sh, float("nan"), dtype=torch.float32, device=U.dev())
+    return {"fused0": z(nq, mpts, 64), "spikes": z(T, nq, mpts, 960), "knn": torch.full((3, nq, mpts, kk), -1, dtype=torch.int32, device=U.dev()),
+            "pooled": z(T, nq, emb), "enc": z(nq, emb)}
+
+
+@pytest.mark.parametrize("T", [4, 6])
+def test_fused_fd_encoder_equals_the_per_stage_path_bit_for_bit(weights, monkeypatch, T):
+    """csrc/fd_encoder.hip (the whole encoder — blocks 0-3 and multi_scale_conv over all steps — in one LDS-resident kernel per patch;
+    the [T, points, 960] spikes never reach HBM) against the per-stage kernels (a second handle created under SAPCU_FD_FUSED=0):
+    scale-fusion output, the three feature-space neighbour tables, every spike of every step, pooled features, encoding and
+    distance must agree BIT FOR BIT — full batches, one patch, small and odd patch sizes, and T = 6 (two groups of stacked steps).
+    Checked in dependency order so that a failure names the first stage that differs."""
+    over = {"time_steps_enc": T}
+    _, fd, _, _ = U.build_gpu_models_under(weights, monkeypatch, {"SAPCU_FD_FUSED": "1"}, None, over)
+    _, fd_stage, _, _ = U.build_gpu_models_under(weights, monkeypatch, {"SAPCU_FD_FUSED": "0"}, None, over)
+    assert fd.fused_blocks(48) == 1 and fd.fused_blocks(5) == 1 and fd.fused_blocks(100) == 0 and fd_stage.fused_blocks(48) == 0
+    for nq, mpts in ((64, 48), (37, 48), (1, 48), (9, 20), (70, 5), (5, 12), (3, 33)):
+        patch = U.sphere_patches(nq, mpts, skip=1700).to(U.dev())
+        kk = min(32, mpts)
+        ta, tb = _fd_taps(nq, mpts, T, kk), _fd_taps(nq, mpts, T, kk)
+        da, db = fd(patch, taps=ta), fd_stage(patch, taps=tb)
+        torch.cuda.synchronize()
+        tag = "nq=%d m=%d T=%d" % (nq, mpts, T)
+        assert torch.equal(ta["fused0"], tb["fused0"]), tag + ": scale_fusion output"
+        coff = (0, 64, 192, 448, 960)
+        for l in range(4):
+            if l:
+                assert torch.equal(ta["knn"][l - 1], tb["knn"][l - 1]), tag + ": neighbour table of block %d" % l
+            for t in range(T):
+                a, b = ta["spikes"][t, :, :, coff[l]:coff[l + 1]], tb["spikes"][t, :, :, coff[l]:coff[l + 1]]
+                assert not bool(torch.isnan(a).any()), tag + ": block %d step %d spikes not written" % (l, t)
+                assert torch.equal(a, b), tag + ": block %d step %d spikes (max diff %g)" % (l, t, float((a - b).abs().max()))
+        assert torch.equal(ta["pooled"], tb["pooled"]), tag + ": pooled (max diff %g)" % float((ta["pooled"] - tb["pooled"]).abs().max())
+        assert torch.equal(ta["enc"], tb["enc"]) and torch.equal(da, db), tag
+        # without taps (the production call) and with forced neighbour tables (the parity protocol)
+        assert torch.equal(fd(patch), da), tag + ": tap-free call"
+        assert torch.equal(fd(patch, knn_force=tb["knn"]), db), tag + ": forced tables"
+    assert fd.gate_violations() == 0 and fd_stage.gate_violations() == 0 and fd.gemm_mode() == (True, 0)
+
+
 def test_models_on_the_big_tile_kernel_equal_the_ring_kernel_bit_for_bit(weights, monkeypatch):
     """Whole fn and fd forwards with the split-row GEMMs on the big-tile kernel (default) against the ring kernel only
     (handles created under SAPCU_BT=0): identical normals and distances, bit for bit — including a batch whose last row tile is
