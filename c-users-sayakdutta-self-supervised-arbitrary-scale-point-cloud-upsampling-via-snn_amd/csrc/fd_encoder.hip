@@ -27,12 +27,26 @@
 // same score chains and tie rule in the neighbour searches, same split-f16 products in the same k order, same neuron arithmetic
 // (block 0: neuron_step<true>, blocks 1-3: NeuronStep2), same max.  Taken for patches of <= 48 points, <= 4 scales, emb % 256 == 0;
 // anything else runs the per-stage kernels.
+#include <type_traits>
+
 #include "common.h"
 #include "gemm_epi.h"
 #include "ops.h"
 
 namespace sapcu {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// diagnostic build (-DFE_STAMPS, profiles/fd_stamps.py): s_memtime at the phase boundaries, wave 0 / lane 0, 32 slots per patch
+// in the buffer passed as the spikes tap
+#ifdef FE_STAMPS
+#define FE_STAMP(IDX)                                                                                                   \
+    do {                                                                                                                \
+        if (a.tap_spikes && threadIdx.x == 0)                                                                           \
+            reinterpret_cast<unsigned long long*>(a.tap_spikes)[(int64_t)blockIdx.x * 32 + (IDX)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define FE_STAMP(IDX) do { } while (0)
+#endif
 
 constexpr int FE_M = 48;                 // points per patch (rows of every per-patch table)
 constexpr int FE_NT = 512;               // threads: 8 waves, 256 registers each
@@ -176,7 +190,34 @@ __device__ __forceinline__ void fe_knn(unsigned char* R2, float* xx, unsigned ch
         if (tid < 256) {
             const float* fi = F + (bi * 3) * FE_F_LD;
             const float* fj = F + (bj * 3) * FE_F_LD;
-            for (int cc = 0; cc < cw; ++cc) {
+            // groups of 8 channels: the 48 LDS reads of a group are issued before its FMAs (one wave per SIMD works here: a
+            // read-then-use loop per channel is pure LDS latency); every pair still sees its chain in ascending channel order
+            int cc = 0;
+            for (; cc + 8 <= cw; cc += 8) {
+                float a[8][3], bb[8][3];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        a[q][u] = fi[u * FE_F_LD + cc + q];
+                        bb[q][u] = fj[u * FE_F_LD + cc + q];
+                    }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (q == 0 && c0 == 0 && cc == 0) {
+#pragma unroll
+                        for (int u = 0; u < 3; ++u)
+#pragma unroll
+                            for (int v = 0; v < 3; ++v) acc[u][v] = __fmul_rn(a[0][u], bb[0][v]);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 3; ++u)
+#pragma unroll
+                            for (int v = 0; v < 3; ++v) acc[u][v] = __fmaf_rn(a[q][u], bb[q][v], acc[u][v]);
+                    }
+                }
+            }
+            for (; cc < cw; ++cc) {
                 float a[3], bb[3];
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
@@ -250,95 +291,137 @@ __device__ __forceinline__ void fe_knn(unsigned char* R2, float* xx, unsigned ch
     }
 }
 
-// T-step neuron loops of this thread's six (point, channel) elements of one K round of multi_scale_conv (rows row0 .. row0+5,
-// one channel): the steps [t0, t0 + nemit) go to the panel as split-f16 rows 48 (t - t0) + point, column kcol of the round
-// (steps before t0 — a second group of steps when T > 4 — are run for the state only).  fd:432-474 with the closed gate.
-template <int KIND>
-__device__ __forceinline__ void fe_emit6(const float (&x)[6], const NeuronP& p, int t0, int nemit, unsigned char* panel, int row0,
-                                         int kcol, int m, bool count, int* __restrict__ gate, float* __restrict__ tap,
-                                         int64_t tap_tstride) {
-    const int total = t0 + nemit;
+// ---- multi_scale_conv operand panel: HALF a patch (24 points) x 4 stacked steps = 96 rows (row = 4 point + step: a lane's
+// accumulator quad is then the four steps of one point, and a point's swizzle key (row >> 2) & 3 does not depend on the step) x
+// 128 columns of one K round: [k32 step (4)][plane hi | lo][96 rows][32 halves] = 48 KiB
+constexpr int FE_PR = 96;                  // panel rows
+constexpr int FE_HP = FE_M / 2;            // points per half patch
+
+// split-f16 halves of v at a precomputed panel address (hi plane; lo plane 96 rows x 64 B further)
+__device__ __forceinline__ void fe_put_at(unsigned char* p, float v) {
+    v = settle(v);                                          // (see fe_put)
+    const _Float16 hi = (_Float16)v;
+    *reinterpret_cast<_Float16*>(p) = hi;
+    *reinterpret_cast<_Float16*>(p + FE_PR * 64) = (_Float16)(v - (float)hi);
+}
+
+// T-step neuron loops of this thread's six (point, channel) elements of one K round of multi_scale_conv (six consecutive points
+// of the half patch, one channel): the steps [t0, t0 + nemit) go to the panel as split-f16 rows 4 point + (t - t0) (pe[e] = panel
+// address of point e's step-0 row in this thread's column; a step further = one row = 64 bytes); steps before t0 — a second
+// group of steps when T > 4 — are run for the state only.  fd:432-474 with the closed gate.
+// FAST: t0 = 0, nemit = 4, no tap — the production shape, fully unrolled.  pt0 = patch-level index of the first point (taps, m).
+template <int KIND, bool FAST>
+__device__ __forceinline__ void fe_emit6(const float (&x)[6], const NeuronP& p, int t0, int nemit, unsigned char* const (&pe)[6], int pt0,
+                                         int m, bool count, int* __restrict__ gate, float* __restrict__ tap, int64_t tap_tstride) {
+    const int total = FAST ? 4 : t0 + nemit;
     if (KIND == 0) {
 #pragma unroll
         for (int e = 0; e < 6; ++e) {
             NeuronS s = neuron_init(p);
-            for (int step = 0; step < total; ++step) {
-                if (count && step > 0 && s.r <= 0.f && row0 + e < m) atomicAdd(gate, 1);
-                const float sp = neuron_step<true>(step == 0 ? x[e] : 0.f, s, p);
-                if (step >= t0) {
-                    fe_put<192>(panel, FE_M * (step - t0) + row0 + e, kcol, sp);
-                    if (tap && row0 + e < m) tap[(int64_t)step * tap_tstride + (int64_t)(row0 + e) * 960] = sp;
+            bool open = false;
+            if (FAST) {
+#pragma unroll
+                for (int step = 0; step < 4; ++step) {
+                    open = open || (step > 0 && s.r <= 0.f);
+                    fe_put_at(pe[e] + step * 64, neuron_step<true>(step == 0 ? x[e] : 0.f, s, p));
+                }
+            } else {
+                for (int step = 0; step < total; ++step) {
+                    open = open || (step > 0 && s.r <= 0.f);
+                    const float sp = neuron_step<true>(step == 0 ? x[e] : 0.f, s, p);
+                    if (step >= t0) {
+                        fe_put_at(pe[e] + (step - t0) * 64, sp);
+                        if (tap && pt0 + e < m) tap[(int64_t)step * tap_tstride + (int64_t)(pt0 + e) * 960] = sp;
+                    }
                 }
             }
+            if (count && open && pt0 + e < m) atomicAdd(gate, 1);
         }
     } else {
         NeuronStep2<KIND == 1> n0(p), n1(p), n2(p);
-        for (int step = 0; step < total; ++step) {
-            const bool first = step == 0;
-            if (count && !first) {
-                int open = 0;
-                if (n0.gate_open() && row0 < m) ++open;
-                if (n1.gate_open() && row0 + 2 < m) ++open;
-                if (n2.gate_open() && row0 + 4 < m) ++open;
-                if (open) atomicAdd(gate, open);
+        const f32x2 z = f32x2{0.f, 0.f};
+        bool o0 = false, o1 = false, o2 = false;
+        if (FAST) {
+#pragma unroll
+            for (int step = 0; step < 4; ++step) {
+                if (step > 0) {
+                    o0 = o0 || n0.gate_open();
+                    o1 = o1 || n1.gate_open();
+                    o2 = o2 || n2.gate_open();
+                }
+                const f32x2 s0 = n0.step(step == 0 ? f32x2{x[0], x[1]} : z, step == 0);
+                const f32x2 s1 = n1.step(step == 0 ? f32x2{x[2], x[3]} : z, step == 0);
+                const f32x2 s2 = n2.step(step == 0 ? f32x2{x[4], x[5]} : z, step == 0);
+                fe_put_at(pe[0] + step * 64, s0.x);
+                fe_put_at(pe[1] + step * 64, s0.y);
+                fe_put_at(pe[2] + step * 64, s1.x);
+                fe_put_at(pe[3] + step * 64, s1.y);
+                fe_put_at(pe[4] + step * 64, s2.x);
+                fe_put_at(pe[5] + step * 64, s2.y);
             }
-            const f32x2 z = f32x2{0.f, 0.f};
-            const f32x2 s0 = n0.step(first ? f32x2{x[0], x[1]} : z, first);
-            const f32x2 s1 = n1.step(first ? f32x2{x[2], x[3]} : z, first);
-            const f32x2 s2 = n2.step(first ? f32x2{x[4], x[5]} : z, first);
-            if (step >= t0) {
-                const int rb = FE_M * (step - t0) + row0;
-                fe_put<192>(panel, rb, kcol, s0.x);
-                fe_put<192>(panel, rb + 1, kcol, s0.y);
-                fe_put<192>(panel, rb + 2, kcol, s1.x);
-                fe_put<192>(panel, rb + 3, kcol, s1.y);
-                fe_put<192>(panel, rb + 4, kcol, s2.x);
-                fe_put<192>(panel, rb + 5, kcol, s2.y);
-                if (tap) {
+        } else {
+            for (int step = 0; step < total; ++step) {
+                const bool first = step == 0;
+                if (!first) {
+                    o0 = o0 || n0.gate_open();
+                    o1 = o1 || n1.gate_open();
+                    o2 = o2 || n2.gate_open();
+                }
+                const f32x2 s0 = n0.step(first ? f32x2{x[0], x[1]} : z, first);
+                const f32x2 s1 = n1.step(first ? f32x2{x[2], x[3]} : z, first);
+                const f32x2 s2 = n2.step(first ? f32x2{x[4], x[5]} : z, first);
+                if (step >= t0) {
                     const float sv[6] = {s0.x, s0.y, s1.x, s1.y, s2.x, s2.y};
 #pragma unroll
-                    for (int e = 0; e < 6; ++e)
-                        if (row0 + e < m) tap[(int64_t)step * tap_tstride + (int64_t)(row0 + e) * 960] = sv[e];
+                    for (int e = 0; e < 6; ++e) {
+                        fe_put_at(pe[e] + (step - t0) * 64, sv[e]);
+                        if (tap && pt0 + e < m) tap[(int64_t)step * tap_tstride + (int64_t)(pt0 + e) * 960] = sv[e];
+                    }
                 }
             }
+        }
+        if (count) {                                        // a pair counts once
+            const int open = (o0 && pt0 < m ? 1 : 0) + (o1 && pt0 + 2 < m ? 1 : 0) + (o2 && pt0 + 4 < m ? 1 : 0);
+            if (open) atomicAdd(gate, open);
         }
     }
 }
 
-// one K round (4 k16 steps, absolute steps 4 r ..) of multi_scale_conv for this wave's column block: 6 row blocks x 1 column block
+// one K round of multi_scale_conv for this wave's column block: nk16 k16 steps (8: 128 columns; 4 in the last round) starting at
+// absolute step s_abs, 3 row blocks x 1 column block, weight fragments two steps ahead (refilled behind the MFMAs that read them)
 struct FeW {
     half8 wh[2], wl[2];
 };
-__device__ __forceinline__ void fe_msc_round(const unsigned char* X, const half8* __restrict__ wp, int cb, int r, int lane, FeW& W,
-                                             f32x16 (&acc)[6]) {
+__device__ __forceinline__ void fe_msc_round(const unsigned char* X, const half8* __restrict__ wp, int cb, int s_abs, int nk16, int lane,
+                                             FeW& W, f32x16 (&acc)[3]) {
     const int r32 = lane & 31, h = lane >> 5, sw = (r32 >> 2) & 3;
     const unsigned char* xa = X + r32 * 64;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const unsigned ko = (unsigned)((s >> 1) * (192 * 128) + ((((s & 1) * 2 + h) ^ sw) * 16));
-        // row blocks in two halves of three (24 fragment registers instead of 48); per accumulator the product order stays
-        // a_lo w_hi, a_hi w_lo, a_hi w_hi
-#pragma unroll
-        for (int i0 = 0; i0 < 6; i0 += 3) {
-            half8 ah[3], al[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                ah[i] = *reinterpret_cast<const half8*>(xa + ko + (i0 + i) * 2048);
-                al[i] = *reinterpret_cast<const half8*>(xa + ko + (i0 + i) * 2048 + 192 * 64);
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) acc[i0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], W.wh[s & 1], acc[i0 + i], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) acc[i0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], W.wl[s & 1], acc[i0 + i], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) acc[i0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], W.wh[s & 1], acc[i0 + i], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const int sa = r * 4 + s + 2;                       // refill the slot behind the MFMAs that read it (60 k16 steps in all)
-        const int sn = sa < 60 ? sa : 59;
-        W.wh[s & 1] = fe_wfrag(wp, 60, cb, sn, 0, lane);
-        W.wl[s & 1] = fe_wfrag(wp, 60, cb, sn, 1, lane);
+    // rolled, two k16 steps per iteration (static ring slots); a fully unrolled K sweep makes the compiler precompute — and
+    // spill — every fragment address of the sweep
+#define SAPCU_FE_MSTEP(S, SJ)                                                                                          \
+    {                                                                                                                  \
+        const int s_ = (S);                                                                                            \
+        const unsigned ko = (unsigned)((s_ >> 1) * (FE_PR * 128) + ((((s_ & 1) * 2 + h) ^ sw) * 16));                  \
+        half8 ah[3], al[3];                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                                \
+            ah[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048);                                               \
+            al[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048 + FE_PR * 64);                                  \
+        }                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], W.wh[SJ], acc[i], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], W.wl[SJ], acc[i], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], W.wh[SJ], acc[i], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        const int sa_ = s_abs + s_ + 2;                      /* (60 k16 steps in all) */                               \
+        const int sn_ = sa_ < 60 ? sa_ : 59;                                                                           \
+        W.wh[SJ] = fe_wfrag(wp, 60, cb, sn_, 0, lane);                                                                 \
+        W.wl[SJ] = fe_wfrag(wp, 60, cb, sn_, 1, lane);                                                                 \
     }
+#pragma unroll 1
+    for (int s0 = 0; s0 < nk16; s0 += 2) {
+        SAPCU_FE_MSTEP(s0, 0)
+        SAPCU_FE_MSTEP(s0 + 1, 1)
+    }
+#undef SAPCU_FE_MSTEP
 }
 
 __device__ __forceinline__ unsigned fe_half_max(unsigned x) {     // max of the two lane halves' values, in both halves
@@ -351,7 +434,7 @@ __device__ __forceinline__ unsigned fe_half_max(unsigned x) {     // max of the 
 // max over the neighbours, shift + LeakyReLU -> the block's pre-activation x0 (LDS for L <= 2, registers for L = 3).
 // ---------------------------------------------------------------------------------------------
 template <int L>
-__device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char* smem, int64_t patch_i, int tid, float (&x3)[8][6]) {
+__device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char* smem, int64_t patch_i, int tid, float (&x3)[2][5][6]) {
     constexpr int CIN = 64 << (L - 1), COUT = 128 << (L - 1);
     constexpr int COFF_IN = L == 1 ? 0 : (L == 2 ? 64 : 192), COFF_OUT = L == 1 ? 64 : (L == 2 ? 192 : 448);
     constexpr int KIND_IN = L == 1 ? 0 : (L == 2 ? 1 : 2);
@@ -391,6 +474,7 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
         fe_knn(R2, xx, IDXL, m, CIN, kk, fill, a.tap_knn ? a.tap_knn + tab_off : nullptr, tid);
     }
     __syncthreads();
+    FE_STAMP(4 * L);
     // (2) step-0 spikes of block L-1 as the split-f16 operand panel [64 rows][CIN] (rows >= m: whatever x0 holds there — the
     //     GEMM's rows are independent and those outputs are never used)
     {
@@ -411,6 +495,7 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
         }
     }
     __syncthreads();
+    FE_STAMP(4 * L + 1);
     // (3) GEMM: pairs pr = w + 8 q; accumulators acc[q][rows i][A' | B]
     const bool active = L != 1 || w < 4;                   // block 1 has only four pairs
     f32x16 acc[NPW][4];                                    // [pair][i * 2 + (0: A' = (W1 + W2) x, 1: B = W1 x)]
@@ -423,6 +508,7 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
         }
     }
     __syncthreads();                                       // every wave has read the panel: R2 becomes the staging area
+    FE_STAMP(4 * L + 2);
     // (4) per pair: stage A' (rows < 48) in this wave's private [48][32] tile, max over the kk neighbours per (point, channel),
     //     pre = LeakyReLU((max - B) + shift)
     float* SAw = reinterpret_cast<float*>(R2) + w * (FE_M * 32);
@@ -443,23 +529,36 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            // groups of eight rows (one accumulator quad pair), the neighbour loop outside: the eight index reads of a step, then
+            // their 32 tile reads, are independent — a row-at-a-time loop is a chain of dependent LDS latencies
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int g = 0; g < 6; g += 2) {                 // row groups 8 g .. 8 g + 15 (this lane: 4 h + 0..3 of each group of 8)
+                float mx8[8];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    if (32 * i + 8 * (e >> 2) >= FE_M) continue;
-                    const int row = 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
-                    const unsigned char* ir = IDXL + row * FE_M;
-                    float mx = -__builtin_huge_valf();
-                    int j = 0;
-                    for (; j + 4 <= kk; j += 4) {
-                        const unsigned pk = *reinterpret_cast<const unsigned*>(ir + j);
-                        mx = fmaxf(mx, SAw[(pk & 255u) * 32 + r32]);
-                        mx = fmaxf(mx, SAw[((pk >> 8) & 255u) * 32 + r32]);
-                        mx = fmaxf(mx, SAw[((pk >> 16) & 255u) * 32 + r32]);
-                        mx = fmaxf(mx, SAw[(pk >> 24) * 32 + r32]);
+                for (int z = 0; z < 8; ++z) mx8[z] = -__builtin_huge_valf();
+                const unsigned char* ir0 = IDXL + (8 * g + 4 * h) * FE_M;        // rows 8 g + 4 h + u, then 8 (g + 1) + 4 h + u
+                int j = 0;
+                for (; j + 4 <= kk; j += 4) {
+                    unsigned pk[8];
+#pragma unroll
+                    for (int z = 0; z < 8; ++z) pk[z] = *reinterpret_cast<const unsigned*>(ir0 + ((z >> 2) * 8 + (z & 3)) * FE_M + j);
+#pragma unroll
+                    for (int z = 0; z < 8; ++z) {
+                        const float v0 = SAw[(pk[z] & 255u) * 32 + r32], v1 = SAw[((pk[z] >> 8) & 255u) * 32 + r32];
+                        const float v2 = SAw[((pk[z] >> 16) & 255u) * 32 + r32], v3 = SAw[(pk[z] >> 24) * 32 + r32];
+                        mx8[z] = fmaxf(fmaxf(mx8[z], v0), fmaxf(v1, fmaxf(v2, v3)));
                     }
-                    for (; j < kk; ++j) mx = fmaxf(mx, SAw[ir[j] * 32 + r32]);
+                }
+                for (; j < kk; ++j) {
+#pragma unroll
+                    for (int z = 0; z < 8; ++z) mx8[z] = fmaxf(mx8[z], SAw[ir0[((z >> 2) * 8 + (z & 3)) * FE_M + j] * 32 + r32]);
+                }
+#pragma unroll
+                for (int z = 0; z < 8; ++z) {
+                    const int gg = g + (z >> 2);              // group of 8 rows: accumulator block gg / 4, quad gg % 4
+                    const int i = gg >> 2, e = (gg & 3) * 4 + (z & 3);
+                    const int row = 8 * gg + 4 * h + (z & 3);
+                    const float mx = mx8[z];
                     const float xb = __fadd_rn(__fmul_rn(acc[q][i * 2 + 1][e], 0.0625f), 0.0f);
                     pre[i][e] = lrelu02(__fadd_rn(__fsub_rn(mx, xb), sh));
 #ifdef FE_DEBUG_AB          // diagnostic build: block 1's GEMM outputs A' | B in columns 192.. | 320.. of the x0 tap
@@ -473,6 +572,7 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
 #endif
                     if (a.tap_x0 && row < m) a.tap_x0[((a.s0 + patch_i) * m + row) * 960 + COFF_OUT + col] = pre[i][e];
                 }
+            }
             __builtin_amdgcn_wave_barrier();               // this wave's reads of its tile are done before it is rewritten
             if (L <= 2) {
 #pragma unroll
@@ -499,15 +599,26 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
         if (L == 3) {
             __syncthreads();
             const float* SA = reinterpret_cast<const float*>(R2);
+            // multi_scale_conv's thread (wave w, lane): 64-column chunk parity cw = w & 1 (chunks 7 + c3 of the 15; cw = 1 takes the
+            // even c3), points 6 (w >> 1) + e of each half patch; chunk c3 of this pair round = tiles 2 (c3 & 3), 2 (c3 & 3) + 1
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int jj = 0; jj < 2; ++jj) {
+                const int c3l = 2 * jj + 1 - (w & 1);          // chunk inside this pair round (0..3): block chunk c3 = 4 q + c3l
+                // round of chunk 7 + c3: R = (7 + c3) >> 1 -> slot R - 3 = 2 q + jj (odd waves: c3l = 2 jj) or 2 q + jj + 1 (even: 2 jj + 1)
 #pragma unroll
-                for (int e = 0; e < 6; ++e)
-                    x3[4 * q + j][e] = SA[(2 * j + (lane >> 5)) * (FE_M * 32) + (6 * w + e) * 32 + (lane & 31)];
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) {
+                        const float v = SA[(2 * c3l + (lane >> 5)) * (FE_M * 32) + (FE_HP * hf + 6 * (w >> 1) + e) * 32 + (lane & 31)];
+                        if (w & 1) x3[hf][2 * q + jj][e] = v;
+                        else x3[hf][2 * q + jj + 1][e] = v;
+                    }
+            }
             __syncthreads();
         }
     }
     __syncthreads();
+    FE_STAMP(4 * L + 3);
 }
 
 __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a) {
@@ -529,6 +640,7 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
         XYZ[e] = e < m ? make_float4(pp[3 * e], pp[3 * e + 1], pp[3 * e + 2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int e = tid; e < 2 * FE_M * FE_M / 4; e += FE_NT) reinterpret_cast<unsigned*>(IDX0)[e] = 0u;
     __syncthreads();
+    FE_STAMP(0);
     // ---- block 0: xyz neighbours (one ranking serves all scales)                                          fd:411-417
     {
         auto fill = [&](int c0, int cw) {
@@ -543,6 +655,7 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
         fe_knn(R2, xx, IDX0, m, 3, a.kmax0, fill, nullptr, tid);
     }
     __syncthreads();
+    FE_STAMP(1);
     // ---- block 0: EdgeConv(6 -> 64) per scale, max over the ks nearest, + bias, LeakyReLU -> split panel [64][64 S]   fd:413-420
     {
         float wt[4][6], bb[4];
@@ -560,20 +673,32 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
             f32x2 mx[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) mx[s] = f32x2{-__builtin_huge_valf(), -__builtin_huge_valf()};
-            for (int j = 0; j < a.kmax0; ++j) {
-                const float4 qa = XYZ[IDX0[i * FE_M + j]], qb = XYZ[IDX0[i1 * FE_M + j]];
-                const f32x2 xj = f32x2{qa.x, qb.x}, yj = f32x2{qa.y, qb.y}, zj = f32x2{qa.z, qb.z};
-                const f32x2 dx = xj - xi, dy = yj - yi, dz = zj - zi;
+            for (int j0 = 0; j0 < a.kmax0; j0 += 4) {
+                // four edges per point: the (wave-uniform) index reads, then the coordinate reads, are issued together
+                const unsigned na4 = *reinterpret_cast<const unsigned*>(IDX0 + i * FE_M + j0);       // (row pitch 48, j0 % 4 == 0)
+                const unsigned nb4 = *reinterpret_cast<const unsigned*>(IDX0 + i1 * FE_M + j0);
+                float4 qa[4], qb[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    if (s < a.nscale && j < a.ks[s]) {
-                        f32x2 v = f32x2{wt[s][0], wt[s][0]} * dx;
-                        v = pk_fma(f32x2{wt[s][1], wt[s][1]}, dy, v);
-                        v = pk_fma(f32x2{wt[s][2], wt[s][2]}, dz, v);
-                        v = pk_fma(f32x2{wt[s][3], wt[s][3]}, xj, v);
-                        v = pk_fma(f32x2{wt[s][4], wt[s][4]}, yj, v);
-                        v = pk_fma(f32x2{wt[s][5], wt[s][5]}, zj, v);
-                        mx[s] = f32x2{fmaxf(mx[s].x, v.x), fmaxf(mx[s].y, v.y)};
+                for (int u = 0; u < 4; ++u) {
+                    qa[u] = XYZ[(na4 >> (8 * u)) & 255u];
+                    qb[u] = XYZ[(nb4 >> (8 * u)) & 255u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u;
+                    const f32x2 xj = f32x2{qa[u].x, qb[u].x}, yj = f32x2{qa[u].y, qb[u].y}, zj = f32x2{qa[u].z, qb[u].z};
+                    const f32x2 dx = xj - xi, dy = yj - yi, dz = zj - zi;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        if (s < a.nscale && j < a.ks[s]) {
+                            f32x2 v = f32x2{wt[s][0], wt[s][0]} * dx;
+                            v = pk_fma(f32x2{wt[s][1], wt[s][1]}, dy, v);
+                            v = pk_fma(f32x2{wt[s][2], wt[s][2]}, dz, v);
+                            v = pk_fma(f32x2{wt[s][3], wt[s][3]}, xj, v);
+                            v = pk_fma(f32x2{wt[s][4], wt[s][4]}, yj, v);
+                            v = pk_fma(f32x2{wt[s][5], wt[s][5]}, zj, v);
+                            mx[s] = f32x2{fmaxf(mx[s].x, v.x), fmaxf(mx[s].y, v.y)};
+                        }
                     }
                 }
             }
@@ -590,6 +715,7 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
         if (!(big < 65504.0f) && a.ovf) atomicAdd(a.ovf, 1);
     }
     __syncthreads();
+    FE_STAMP(2);
     // ---- block 0: scale_fusion (64 S -> 64) + BN + LeakyReLU = x0 of block 0                                fd:420-421
     if (w < 2) {
         f32x16 acc[2];
@@ -610,17 +736,36 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
             }
     }
     __syncthreads();
+    FE_STAMP(3);
     // ---- blocks 1..3                                                                                          fd:447-474
-    float x3[8][6];
+    // block 3's x0 of this thread's multi_scale_conv elements: [half patch][round R - 3][point].  Odd waves emit the block's chunks
+    // in rounds 3..6 (slots 0..3), even waves in rounds 4..7 (slots 1..4): one slot per thread stays unused, every index static
+    float x3[2][5][6];
     fe_edge_block<1>(a, smem, patch_i, tid, x3);
     fe_edge_block<2>(a, smem, patch_i, tid, x3);
     fe_edge_block<3>(a, smem, patch_i, tid, x3);
 
     // ---- multi_scale_conv over all steps + max over the points                                               fd:476-480
-    const int row0 = 6 * w;
+    // N in passes of 256 columns (wave w: column block 8 pass + w), the patch in two halves of 24 points (4 stacked steps = 96 rows =
+    // 3 row blocks: 48 accumulator registers), K in rounds of 128 columns: wave w emits the 64-column chunk ch = 2 R + (w & 1) for the
+    // six points 6 (w >> 1) + e of the half patch.  Chunk kinds: 0 block 0 | 1, 2 block 1 | 3..6 block 2 (x0 in LDS) | 7..14 block 3
+    // (x0 in registers); round 7 has only chunk 14.
+    const int cw = w & 1, rg = w >> 1;
     const int npass = a.emb / 256;
     const half8* __restrict__ mscw = reinterpret_cast<const half8*>(a.msc_wp);
     const int64_t tap_tstride = a.b_total * (int64_t)m * 960;
+    unsigned char* pe[6];                                   // panel addresses: point 6 rg + e of the half patch (row 4 point), column 64 cw + lane
+#pragma unroll
+    for (int e = 0; e < 6; ++e) pe[e] = R2 + fe_panel_off<FE_PR>(4 * (6 * rg + e), 64 * cw + lane);
+    FE_STAMP(16);
+#ifdef FE_STAMPS
+    unsigned long long fe_t_emit = 0, fe_t_mfma = 0, fe_tp = 0;
+#define FE_T0() fe_tp = __builtin_amdgcn_s_memtime()
+#define FE_TACC(V) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (V) += now_ - fe_tp; fe_tp = now_; } while (0)
+#else
+#define FE_T0() do { } while (0)
+#define FE_TACC(V) do { } while (0)
+#endif
     for (int pass = 0; pass < npass; ++pass) {
         const int cb = pass * 8 + w;
         const int col = 32 * cb + r32;
@@ -628,59 +773,87 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
         for (int t0 = 0; t0 < a.T; t0 += 4) {
             const int nemit = a.T - t0 < 4 ? a.T - t0 : 4;
             const bool count = pass == 0 && t0 + nemit == a.T;         // the gate check runs once, over all T steps
+#ifdef FE_STAMPS
+            float* tap = nullptr;                                      // (the spikes tap carries the stamps in this build)
+#else
             float* tap = (a.tap_spikes && pass == 0) ? a.tap_spikes + (a.s0 + patch_i) * (int64_t)m * 960 : nullptr;
-            f32x16 acc[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-            FeW W;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                W.wh[s] = fe_wfrag(mscw, 60, cb, s, 0, lane);
-                W.wl[s] = fe_wfrag(mscw, 60, cb, s, 1, lane);
-            }
-            // rounds 0..6: blocks 0-2 from LDS (column 64 r + lane); a round's neuron parameters are loaded one round ahead
-            NeuronP pnext = fe_load_np(a.nprm, lane);
-            for (int r = 0; r < 7; ++r) {
-                const int c = 64 * r + lane;
-                const NeuronP p = pnext;
-                pnext = fe_load_np(a.nprm, c + 64);
-                float x[6];
-#pragma unroll
-                for (int e = 0; e < 6; ++e) x[e] = XS[(row0 + e) * FE_XLD + c];
-                if (r == 0) fe_emit6<0>(x, p, t0, nemit, R2, row0, lane, m, count, a.gate, tap ? tap + c : nullptr, tap_tstride);
-                else if (r < 3) fe_emit6<1>(x, p, t0, nemit, R2, row0, lane, m, count, a.gate, tap ? tap + c : nullptr, tap_tstride);
-                else fe_emit6<2>(x, p, t0, nemit, R2, row0, lane, m, count, a.gate, tap ? tap + c : nullptr, tap_tstride);
-                lds_barrier();
-                fe_msc_round(R2, mscw, cb, r, lane, W, acc);
-                lds_barrier();
-            }
-            // rounds 7..14: block 3 from registers
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c = 448 + 64 * j + lane;
-                const NeuronP p = pnext;
-                pnext = fe_load_np(a.nprm, j < 7 ? c + 64 : c);
-                fe_emit6<2>(x3[j], p, t0, nemit, R2, row0, lane, m, count, a.gate, tap ? tap + c : nullptr, tap_tstride);
-                lds_barrier();
-                fe_msc_round(R2, mscw, cb, 7 + j, lane, W, acc);
-                lds_barrier();
-            }
-            // epilogue: + bias, LeakyReLU, max over the patch's points per step (row = 48 tt + point), integer keys
+#endif
+            const bool fast = t0 == 0 && nemit == 4 && tap == nullptr;         // (workgroup-uniform)
             unsigned best[4] = {0u, 0u, 0u, 0u};
+            // one half patch; HF and the round index R are compile-time (generic lambdas called with integral constants: a
+            // "#pragma unroll" loop around bodies with barriers is not reliably unrolled, and a rolled loop would index x3
+            // dynamically, i.e. put it in scratch memory)
+            auto half = [&](auto hf_c) {
+                constexpr int HF = decltype(hf_c)::value;
+                const int pt0 = FE_HP * HF + 6 * rg;                    // this thread's first point
+                f32x16 acc[3];
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int rbase = 32 * i + 8 * (e >> 2);                  // 48 = 6 x 8: a group of 8 rows never straddles two steps
-                    const int tt = rbase / FE_M;
-                    const int pt = rbase % FE_M + 4 * h + (e & 3);
-                    if (pt < m) {
-                        const unsigned key = float_max_key(lrelu02(__fadd_rn(__fmul_rn(acc[i][e], 0.0625f), bias)));
-                        best[tt] = best[tt] > key ? best[tt] : key;
-                    }
+                    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+                FeW W;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    W.wh[s] = fe_wfrag(mscw, 60, cb, s, 0, lane);
+                    W.wl[s] = fe_wfrag(mscw, 60, cb, s, 1, lane);
                 }
+                NeuronP pnext = fe_load_np(a.nprm, 64 * cw + lane);      // a chunk's neuron parameters are loaded one round ahead
+#pragma unroll 1
+                for (int R = 0; R < 8; ++R) {
+                    const int ch = 2 * R + cw;                          // this wave's chunk (15 = none: round 7, odd waves)
+                    const int c = 64 * ch + lane;
+                    const NeuronP p = pnext;
+                    pnext = fe_load_np(a.nprm, c + 128 < 960 ? c + 128 : (c < 960 ? c : 959));
+                    FE_T0();
+                    float* tp = tap ? tap + c : nullptr;
+                    if (ch < 15) {
+                        float x[6];
+                        if (ch < 7) {                                   // blocks 0-2: x0 from LDS
+#pragma unroll
+                            for (int e = 0; e < 6; ++e) x[e] = XS[(pt0 + e) * FE_XLD + c];
+                        } else {                                        // block 3: x0 from registers, slot R - 3 (wave-uniform selects:
+#pragma unroll                                                          // the loop stays rolled and x3 stays in registers)
+                            for (int e = 0; e < 6; ++e) {
+                                float v = x3[HF][0][e];
+                                v = R == 4 ? x3[HF][1][e] : v;
+                                v = R == 5 ? x3[HF][2][e] : v;
+                                v = R == 6 ? x3[HF][3][e] : v;
+                                v = R == 7 ? x3[HF][4][e] : v;
+                                x[e] = v;
+                            }
+                        }
+                        if (ch == 0) {                                  // block 0 (wave-uniform branches)
+                            if (fast) fe_emit6<0, true>(x, p, 0, 4, pe, pt0, m, count, a.gate, nullptr, 0);
+                            else fe_emit6<0, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
+                        } else if (ch < 3) {                            // block 1
+                            if (fast) fe_emit6<1, true>(x, p, 0, 4, pe, pt0, m, count, a.gate, nullptr, 0);
+                            else fe_emit6<1, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
+                        } else {                                        // blocks 2, 3
+                            if (fast) fe_emit6<2, true>(x, p, 0, 4, pe, pt0, m, count, a.gate, nullptr, 0);
+                            else fe_emit6<2, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
+                        }
+                    }
+                    lds_barrier();
+                    FE_TACC(fe_t_emit);
+                    fe_msc_round(R2, mscw, cb, 8 * R, R < 7 ? 8 : 4, lane, W, acc);
+                    lds_barrier();
+                    FE_TACC(fe_t_mfma);
+                }
+                // epilogue of this half: + bias, LeakyReLU, running max per step over the half's points (row = 4 point + step:
+                // register u of a quad is step u), integer keys
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int pl = 8 * i + 2 * (e >> 2) + h;          // point inside the half patch
+                        if (FE_HP * HF + pl < m) {
+                            const unsigned key = float_max_key(lrelu02(__fadd_rn(__fmul_rn(acc[i][e], 0.0625f), bias)));
+                            best[e & 3] = best[e & 3] > key ? best[e & 3] : key;
+                        }
+                    }
+            };
+            half(std::integral_constant<int, 0>{});
+            half(std::integral_constant<int, 1>{});
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const unsigned k2 = fe_half_max(best[tt]);
@@ -688,6 +861,14 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
             }
         }
     }
+#ifdef FE_STAMPS
+    if (a.tap_spikes && threadIdx.x == 0) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(a.tap_spikes) + (int64_t)blockIdx.x * 32;
+        st[17] = fe_t_emit;
+        st[18] = fe_t_mfma;
+        st[19] = __builtin_amdgcn_s_memtime();
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
