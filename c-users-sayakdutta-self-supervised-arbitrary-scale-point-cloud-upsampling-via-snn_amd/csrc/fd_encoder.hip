@@ -291,32 +291,33 @@ __device__ __forceinline__ void fe_knn(unsigned char* R2, float* xx, unsigned ch
     }
 }
 
-// ---- multi_scale_conv operand panel: HALF a patch (24 points) x 4 stacked steps = 96 rows (row = 4 point + step: a lane's
+// ---- multi_scale_conv operand panel: a THIRD of a patch (16 points) x 4 stacked steps = 64 rows (row = 4 point + step: a lane's
 // accumulator quad is then the four steps of one point, and a point's swizzle key (row >> 2) & 3 does not depend on the step) x
-// 128 columns of one K round: [k32 step (4)][plane hi | lo][96 rows][32 halves] = 48 KiB
-constexpr int FE_PR = 96;                  // panel rows
-constexpr int FE_HP = FE_M / 2;            // points per half patch
+// 128 columns of one K round: [k32 step (4)][plane hi | lo][64 rows][32 halves] = 32 KiB
+constexpr int FE_PR = 64;                  // panel rows
+constexpr int FE_TP = FE_M / 3;            // points per third of a patch
 
-// split-f16 halves of v at a precomputed panel address (hi plane; lo plane 96 rows x 64 B further)
+// split-f16 halves of v at a precomputed panel address (hi plane; lo plane 64 rows x 64 B further).  lo = f16(v - hi) written as
+// the FMA it is (v - hi is exact in f32, so one rounding to f16 either way): the compiler then has v_fma_mixlo_f16 for it.
 __device__ __forceinline__ void fe_put_at(unsigned char* p, float v) {
     v = settle(v);                                          // (see fe_put)
     const _Float16 hi = (_Float16)v;
     *reinterpret_cast<_Float16*>(p) = hi;
-    *reinterpret_cast<_Float16*>(p + FE_PR * 64) = (_Float16)(v - (float)hi);
+    *reinterpret_cast<_Float16*>(p + FE_PR * 64) = (_Float16)__builtin_fmaf((float)hi, -1.0f, v);
 }
 
-// T-step neuron loops of this thread's six (point, channel) elements of one K round of multi_scale_conv (six consecutive points
-// of the half patch, one channel): the steps [t0, t0 + nemit) go to the panel as split-f16 rows 4 point + (t - t0) (pe[e] = panel
+// T-step neuron loops of this thread's four (point, channel) elements of one K round of multi_scale_conv (four consecutive points
+// of the third, one channel): the steps [t0, t0 + nemit) go to the panel as split-f16 rows 4 point + (t - t0) (pe[e] = panel
 // address of point e's step-0 row in this thread's column; a step further = one row = 64 bytes); steps before t0 — a second
 // group of steps when T > 4 — are run for the state only.  fd:432-474 with the closed gate.
 // FAST: t0 = 0, nemit = 4, no tap — the production shape, fully unrolled.  pt0 = patch-level index of the first point (taps, m).
 template <int KIND, bool FAST>
-__device__ __forceinline__ void fe_emit6(const float (&x)[6], const NeuronP& p, int t0, int nemit, unsigned char* const (&pe)[6], int pt0,
+__device__ __forceinline__ void fe_emit4(const float (&x)[4], const NeuronP& p, int t0, int nemit, unsigned char* const (&pe)[4], int pt0,
                                          int m, bool count, int* __restrict__ gate, float* __restrict__ tap, int64_t tap_tstride) {
     const int total = FAST ? 4 : t0 + nemit;
     if (KIND == 0) {
 #pragma unroll
-        for (int e = 0; e < 6; ++e) {
+        for (int e = 0; e < 4; ++e) {
             NeuronS s = neuron_init(p);
             bool open = false;
             if (FAST) {
@@ -338,26 +339,22 @@ __device__ __forceinline__ void fe_emit6(const float (&x)[6], const NeuronP& p, 
             if (count && open && pt0 + e < m) atomicAdd(gate, 1);
         }
     } else {
-        NeuronStep2<KIND == 1> n0(p), n1(p), n2(p);
+        NeuronStep2<KIND == 1> n0(p), n1(p);
         const f32x2 z = f32x2{0.f, 0.f};
-        bool o0 = false, o1 = false, o2 = false;
+        bool o0 = false, o1 = false;
         if (FAST) {
 #pragma unroll
             for (int step = 0; step < 4; ++step) {
                 if (step > 0) {
                     o0 = o0 || n0.gate_open();
                     o1 = o1 || n1.gate_open();
-                    o2 = o2 || n2.gate_open();
                 }
                 const f32x2 s0 = n0.step(step == 0 ? f32x2{x[0], x[1]} : z, step == 0);
                 const f32x2 s1 = n1.step(step == 0 ? f32x2{x[2], x[3]} : z, step == 0);
-                const f32x2 s2 = n2.step(step == 0 ? f32x2{x[4], x[5]} : z, step == 0);
                 fe_put_at(pe[0] + step * 64, s0.x);
                 fe_put_at(pe[1] + step * 64, s0.y);
                 fe_put_at(pe[2] + step * 64, s1.x);
                 fe_put_at(pe[3] + step * 64, s1.y);
-                fe_put_at(pe[4] + step * 64, s2.x);
-                fe_put_at(pe[5] + step * 64, s2.y);
             }
         } else {
             for (int step = 0; step < total; ++step) {
@@ -365,15 +362,13 @@ __device__ __forceinline__ void fe_emit6(const float (&x)[6], const NeuronP& p, 
                 if (!first) {
                     o0 = o0 || n0.gate_open();
                     o1 = o1 || n1.gate_open();
-                    o2 = o2 || n2.gate_open();
                 }
                 const f32x2 s0 = n0.step(first ? f32x2{x[0], x[1]} : z, first);
                 const f32x2 s1 = n1.step(first ? f32x2{x[2], x[3]} : z, first);
-                const f32x2 s2 = n2.step(first ? f32x2{x[4], x[5]} : z, first);
                 if (step >= t0) {
-                    const float sv[6] = {s0.x, s0.y, s1.x, s1.y, s2.x, s2.y};
+                    const float sv[4] = {s0.x, s0.y, s1.x, s1.y};
 #pragma unroll
-                    for (int e = 0; e < 6; ++e) {
+                    for (int e = 0; e < 4; ++e) {
                         fe_put_at(pe[e] + (step - t0) * 64, sv[e]);
                         if (tap && pt0 + e < m) tap[(int64_t)step * tap_tstride + (int64_t)(pt0 + e) * 960] = sv[e];
                     }
@@ -381,47 +376,48 @@ __device__ __forceinline__ void fe_emit6(const float (&x)[6], const NeuronP& p, 
             }
         }
         if (count) {                                        // a pair counts once
-            const int open = (o0 && pt0 < m ? 1 : 0) + (o1 && pt0 + 2 < m ? 1 : 0) + (o2 && pt0 + 4 < m ? 1 : 0);
+            const int open = (o0 && pt0 < m ? 1 : 0) + (o1 && pt0 + 2 < m ? 1 : 0);
             if (open) atomicAdd(gate, open);
         }
     }
 }
 
-// one K round of multi_scale_conv for this wave's column block: nk16 k16 steps (8: 128 columns; 4 in the last round) starting at
-// absolute step s_abs, 3 row blocks x 1 column block, weight fragments two steps ahead (refilled behind the MFMAs that read them)
+// one K round of multi_scale_conv: nk16 k16 steps (8: 128 columns; 4 in the last round) starting at absolute step s_abs, this
+// wave's 2 row blocks x 3 column blocks cb0 .. cb0 + 2 (ALL emb columns are covered by the eight waves in one sweep over K, so
+// every spike is generated once).  Weight fragments L2 -> registers one k16 step ahead, refilled in place behind the MFMAs
+// that read them; the loop is rolled (a fully unrolled K sweep makes the compiler precompute — and spill — every fragment address).
 struct FeW {
-    half8 wh[2], wl[2];
+    half8 wh[3], wl[3];
 };
-__device__ __forceinline__ void fe_msc_round(const unsigned char* X, const half8* __restrict__ wp, int cb, int s_abs, int nk16, int lane,
-                                             FeW& W, f32x16 (&acc)[3]) {
+__device__ __forceinline__ void fe_msc_round(const unsigned char* X, const half8* __restrict__ wp, int cb0, int s_abs, int nk16, int lane,
+                                             FeW& W, f32x16 (&acc)[6]) {
     const int r32 = lane & 31, h = lane >> 5, sw = (r32 >> 2) & 3;
     const unsigned char* xa = X + r32 * 64;
-    // rolled, two k16 steps per iteration (static ring slots); a fully unrolled K sweep makes the compiler precompute — and
-    // spill — every fragment address of the sweep
-#define SAPCU_FE_MSTEP(S, SJ)                                                                                          \
-    {                                                                                                                  \
-        const int s_ = (S);                                                                                            \
-        const unsigned ko = (unsigned)((s_ >> 1) * (FE_PR * 128) + ((((s_ & 1) * 2 + h) ^ sw) * 16));                  \
-        half8 ah[3], al[3];                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                                \
-            ah[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048);                                               \
-            al[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048 + FE_PR * 64);                                  \
-        }                                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], W.wh[SJ], acc[i], 0, 0, 0); \
-        _Pragma("unroll") for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], W.wl[SJ], acc[i], 0, 0, 0); \
-        _Pragma("unroll") for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], W.wh[SJ], acc[i], 0, 0, 0); \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        const int sa_ = s_abs + s_ + 2;                      /* (60 k16 steps in all) */                               \
-        const int sn_ = sa_ < 60 ? sa_ : 59;                                                                           \
-        W.wh[SJ] = fe_wfrag(wp, 60, cb, sn_, 0, lane);                                                                 \
-        W.wl[SJ] = fe_wfrag(wp, 60, cb, sn_, 1, lane);                                                                 \
-    }
 #pragma unroll 1
-    for (int s0 = 0; s0 < nk16; s0 += 2) {
-        SAPCU_FE_MSTEP(s0, 0)
-        SAPCU_FE_MSTEP(s0 + 1, 1)
+    for (int s = 0; s < nk16; ++s) {
+        const unsigned ko = (unsigned)((s >> 1) * (FE_PR * 128) + ((((s & 1) * 2 + h) ^ sw) * 16));
+        half8 ah[2], al[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048);
+            al[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048 + FE_PR * 64);
+        }
+        // acc[i * 3 + j]: row block i, column block cb0 + j; per accumulator a_lo w_hi, a_hi w_lo, a_hi w_hi
+#pragma unroll
+        for (int b = 0; b < 6; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b / 3], W.wh[b % 3], acc[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / 3], W.wl[b % 3], acc[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / 3], W.wh[b % 3], acc[b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int sa = s_abs + s + 1;                       // (60 k16 steps in all; the last refill re-loads the last fragment)
+        const int sn = sa < 60 ? sa : 59;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            W.wh[j] = fe_wfrag(wp, 60, cb0 + j, sn, 0, lane);
+            W.wl[j] = fe_wfrag(wp, 60, cb0 + j, sn, 1, lane);
+        }
     }
-#undef SAPCU_FE_MSTEP
 }
 
 __device__ __forceinline__ unsigned fe_half_max(unsigned x) {     // max of the two lane halves' values, in both halves
@@ -434,7 +430,7 @@ __device__ __forceinline__ unsigned fe_half_max(unsigned x) {     // max of the 
 // max over the neighbours, shift + LeakyReLU -> the block's pre-activation x0 (LDS for L <= 2, registers for L = 3).
 // ---------------------------------------------------------------------------------------------
 template <int L>
-__device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char* smem, int64_t patch_i, int tid, float (&x3)[2][5][6]) {
+__device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char* smem, int64_t patch_i, int tid, float (&x3)[3][5][4]) {
     constexpr int CIN = 64 << (L - 1), COUT = 128 << (L - 1);
     constexpr int COFF_IN = L == 1 ? 0 : (L == 2 ? 64 : 192), COFF_OUT = L == 1 ? 64 : (L == 2 ? 192 : 448);
     constexpr int KIND_IN = L == 1 ? 0 : (L == 2 ? 1 : 2);
@@ -600,18 +596,18 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
             __syncthreads();
             const float* SA = reinterpret_cast<const float*>(R2);
             // multi_scale_conv's thread (wave w, lane): 64-column chunk parity cw = w & 1 (chunks 7 + c3 of the 15; cw = 1 takes the
-            // even c3), points 6 (w >> 1) + e of each half patch; chunk c3 of this pair round = tiles 2 (c3 & 3), 2 (c3 & 3) + 1
+            // even c3), points 4 (w >> 1) + e of each third of the patch; chunk c3 of this pair round = tiles 2 (c3 & 3), 2 (c3 & 3) + 1
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int c3l = 2 * jj + 1 - (w & 1);          // chunk inside this pair round (0..3): block chunk c3 = 4 q + c3l
                 // round of chunk 7 + c3: R = (7 + c3) >> 1 -> slot R - 3 = 2 q + jj (odd waves: c3l = 2 jj) or 2 q + jj + 1 (even: 2 jj + 1)
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
+                for (int th = 0; th < 3; ++th)
 #pragma unroll
-                    for (int e = 0; e < 6; ++e) {
-                        const float v = SA[(2 * c3l + (lane >> 5)) * (FE_M * 32) + (FE_HP * hf + 6 * (w >> 1) + e) * 32 + (lane & 31)];
-                        if (w & 1) x3[hf][2 * q + jj][e] = v;
-                        else x3[hf][2 * q + jj + 1][e] = v;
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = SA[(2 * c3l + (lane >> 5)) * (FE_M * 32) + (FE_TP * th + 4 * (w >> 1) + e) * 32 + (lane & 31)];
+                        if (w & 1) x3[th][2 * q + jj][e] = v;
+                        else x3[th][2 * q + jj + 1][e] = v;
                     }
             }
             __syncthreads();
@@ -738,25 +734,26 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
     __syncthreads();
     FE_STAMP(3);
     // ---- blocks 1..3                                                                                          fd:447-474
-    // block 3's x0 of this thread's multi_scale_conv elements: [half patch][round R - 3][point].  Odd waves emit the block's chunks
+    // block 3's x0 of this thread's multi_scale_conv elements: [third of the patch][round R - 3][point].  Odd waves emit the block's chunks
     // in rounds 3..6 (slots 0..3), even waves in rounds 4..7 (slots 1..4): one slot per thread stays unused, every index static
-    float x3[2][5][6];
+    float x3[3][5][4];
     fe_edge_block<1>(a, smem, patch_i, tid, x3);
     fe_edge_block<2>(a, smem, patch_i, tid, x3);
     fe_edge_block<3>(a, smem, patch_i, tid, x3);
 
     // ---- multi_scale_conv over all steps + max over the points                                               fd:476-480
-    // N in passes of 256 columns (wave w: column block 8 pass + w), the patch in two halves of 24 points (4 stacked steps = 96 rows =
-    // 3 row blocks: 48 accumulator registers), K in rounds of 128 columns: wave w emits the 64-column chunk ch = 2 R + (w & 1) for the
-    // six points 6 (w >> 1) + e of the half patch.  Chunk kinds: 0 block 0 | 1, 2 block 1 | 3..6 block 2 (x0 in LDS) | 7..14 block 3
-    // (x0 in registers); round 7 has only chunk 14.
+    // The patch in thirds of 16 points (4 stacked steps = 64 rows = 2 row blocks); wave w owns column blocks 3 w .. 3 w + 2 of ALL
+    // emb = 768 columns (2 x 3 accumulator blocks = 96 registers), so ONE sweep over K per third and every spike is generated
+    // exactly once; K in rounds of 128 columns: wave w emits the 64-column chunk ch = 2 R + (w & 1) for the four points 4 (w >> 1) + e
+    // of the third.  Chunk kinds: 0 block 0 | 1, 2 block 1 | 3..6 block 2 (x0 in LDS) | 7..14 block 3 (x0 in registers); round 7
+    // has only chunk 14.  emb > 768: further sweeps of 24 column blocks.
     const int cw = w & 1, rg = w >> 1;
-    const int npass = a.emb / 256;
+    const int nsweep = a.emb / 768 + (a.emb % 768 ? 1 : 0);
     const half8* __restrict__ mscw = reinterpret_cast<const half8*>(a.msc_wp);
     const int64_t tap_tstride = a.b_total * (int64_t)m * 960;
-    unsigned char* pe[6];                                   // panel addresses: point 6 rg + e of the half patch (row 4 point), column 64 cw + lane
+    unsigned char* pe[4];                                   // panel addresses: point 4 rg + e of the third (row 4 point), column 64 cw + lane
 #pragma unroll
-    for (int e = 0; e < 6; ++e) pe[e] = R2 + fe_panel_off<FE_PR>(4 * (6 * rg + e), 64 * cw + lane);
+    for (int e = 0; e < 4; ++e) pe[e] = R2 + fe_panel_off<FE_PR>(4 * (4 * rg + e), 64 * cw + lane);
     FE_STAMP(16);
 #ifdef FE_STAMPS
     unsigned long long fe_t_emit = 0, fe_t_mfma = 0, fe_tp = 0;
@@ -766,36 +763,43 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
 #define FE_T0() do { } while (0)
 #define FE_TACC(V) do { } while (0)
 #endif
-    for (int pass = 0; pass < npass; ++pass) {
-        const int cb = pass * 8 + w;
-        const int col = 32 * cb + r32;
-        const float bias = a.msc_b[col];
+    for (int sweep = 0; sweep < nsweep; ++sweep) {
+        // column blocks of this wave in this sweep; blocks beyond emb are clamped to the last one (computed, never stored)
+        const int ncb = a.emb / 32;
+        const int cbw = sweep * 24 + 3 * w;
+        const int cb0 = cbw + 2 < ncb ? cbw : (ncb >= 3 ? ncb - 3 : 0);
+        float bias[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) bias[j] = a.msc_b[32 * (cb0 + j) + r32];
         for (int t0 = 0; t0 < a.T; t0 += 4) {
             const int nemit = a.T - t0 < 4 ? a.T - t0 : 4;
-            const bool count = pass == 0 && t0 + nemit == a.T;         // the gate check runs once, over all T steps
+            const bool count = sweep == 0 && t0 + nemit == a.T;        // the gate check runs once, over all T steps
 #ifdef FE_STAMPS
             float* tap = nullptr;                                      // (the spikes tap carries the stamps in this build)
 #else
-            float* tap = (a.tap_spikes && pass == 0) ? a.tap_spikes + (a.s0 + patch_i) * (int64_t)m * 960 : nullptr;
+            float* tap = (a.tap_spikes && sweep == 0) ? a.tap_spikes + (a.s0 + patch_i) * (int64_t)m * 960 : nullptr;
 #endif
             const bool fast = t0 == 0 && nemit == 4 && tap == nullptr;         // (workgroup-uniform)
-            unsigned best[4] = {0u, 0u, 0u, 0u};
-            // one half patch; HF and the round index R are compile-time (generic lambdas called with integral constants: a
-            // "#pragma unroll" loop around bodies with barriers is not reliably unrolled, and a rolled loop would index x3
-            // dynamically, i.e. put it in scratch memory)
-            auto half = [&](auto hf_c) {
-                constexpr int HF = decltype(hf_c)::value;
-                const int pt0 = FE_HP * HF + 6 * rg;                    // this thread's first point
-                f32x16 acc[3];
+            unsigned best[3][4];
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+                for (int tt = 0; tt < 4; ++tt) best[j][tt] = 0u;
+            // one third of the patch; TH is compile-time (a generic lambda called with integral constants: x3 must be indexed
+            // statically to stay in registers), the rounds are a rolled loop
+            auto third = [&](auto th_c) {
+                constexpr int TH = decltype(th_c)::value;
+                const int pt0 = FE_TP * TH + 4 * rg;                    // this thread's first point
+                f32x16 acc[6];
+#pragma unroll
+                for (int b = 0; b < 6; ++b)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
                 FeW W;
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    W.wh[s] = fe_wfrag(mscw, 60, cb, s, 0, lane);
-                    W.wl[s] = fe_wfrag(mscw, 60, cb, s, 1, lane);
+                for (int j = 0; j < 3; ++j) {
+                    W.wh[j] = fe_wfrag(mscw, 60, cb0 + j, 0, 0, lane);
+                    W.wl[j] = fe_wfrag(mscw, 60, cb0 + j, 0, 1, lane);
                 }
                 NeuronP pnext = fe_load_np(a.nprm, 64 * cw + lane);      // a chunk's neuron parameters are loaded one round ahead
 #pragma unroll 1
@@ -807,57 +811,63 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
                     FE_T0();
                     float* tp = tap ? tap + c : nullptr;
                     if (ch < 15) {
-                        float x[6];
+                        float x[4];
                         if (ch < 7) {                                   // blocks 0-2: x0 from LDS
 #pragma unroll
-                            for (int e = 0; e < 6; ++e) x[e] = XS[(pt0 + e) * FE_XLD + c];
+                            for (int e = 0; e < 4; ++e) x[e] = XS[(pt0 + e) * FE_XLD + c];
                         } else {                                        // block 3: x0 from registers, slot R - 3 (wave-uniform selects:
 #pragma unroll                                                          // the loop stays rolled and x3 stays in registers)
-                            for (int e = 0; e < 6; ++e) {
-                                float v = x3[HF][0][e];
-                                v = R == 4 ? x3[HF][1][e] : v;
-                                v = R == 5 ? x3[HF][2][e] : v;
-                                v = R == 6 ? x3[HF][3][e] : v;
-                                v = R == 7 ? x3[HF][4][e] : v;
+                            for (int e = 0; e < 4; ++e) {
+                                float v = x3[TH][0][e];
+                                v = R == 4 ? x3[TH][1][e] : v;
+                                v = R == 5 ? x3[TH][2][e] : v;
+                                v = R == 6 ? x3[TH][3][e] : v;
+                                v = R == 7 ? x3[TH][4][e] : v;
                                 x[e] = v;
                             }
                         }
                         if (ch == 0) {                                  // block 0 (wave-uniform branches)
-                            if (fast) fe_emit6<0, true>(x, p, 0, 4, pe, pt0, m, count, a.gate, nullptr, 0);
-                            else fe_emit6<0, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
+                            if (fast) fe_emit4<0, true>(x, p, 0, 4, pe, pt0, m, count, a.gate, nullptr, 0);
+                            else fe_emit4<0, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
                         } else if (ch < 3) {                            // block 1
-                            if (fast) fe_emit6<1, true>(x, p, 0, 4, pe, pt0, m, count, a.gate, nullptr, 0);
-                            else fe_emit6<1, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
+                            if (fast) fe_emit4<1, true>(x, p, 0, 4, pe, pt0, m, count, a.gate, nullptr, 0);
+                            else fe_emit4<1, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
                         } else {                                        // blocks 2, 3
-                            if (fast) fe_emit6<2, true>(x, p, 0, 4, pe, pt0, m, count, a.gate, nullptr, 0);
-                            else fe_emit6<2, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
+                            if (fast) fe_emit4<2, true>(x, p, 0, 4, pe, pt0, m, count, a.gate, nullptr, 0);
+                            else fe_emit4<2, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
                         }
                     }
                     lds_barrier();
                     FE_TACC(fe_t_emit);
-                    fe_msc_round(R2, mscw, cb, 8 * R, R < 7 ? 8 : 4, lane, W, acc);
+                    fe_msc_round(R2, mscw, cb0, 8 * R, R < 7 ? 8 : 4, lane, W, acc);
                     lds_barrier();
                     FE_TACC(fe_t_mfma);
                 }
-                // epilogue of this half: + bias, LeakyReLU, running max per step over the half's points (row = 4 point + step:
+                // epilogue of this third: + bias, LeakyReLU, running max per step over the third's points (row = 4 point + step:
                 // register u of a quad is step u), integer keys
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+                for (int b = 0; b < 6; ++b)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const int pl = 8 * i + 2 * (e >> 2) + h;          // point inside the half patch
-                        if (FE_HP * HF + pl < m) {
-                            const unsigned key = float_max_key(lrelu02(__fadd_rn(__fmul_rn(acc[i][e], 0.0625f), bias)));
-                            best[e & 3] = best[e & 3] > key ? best[e & 3] : key;
+                        const int pl = 8 * (b / 3) + 2 * (e >> 2) + h;    // point inside the third
+                        if (FE_TP * TH + pl < m) {
+                            const unsigned key = float_max_key(lrelu02(__fadd_rn(__fmul_rn(acc[b][e], 0.0625f), bias[b % 3])));
+                            best[b % 3][e & 3] = best[b % 3][e & 3] > key ? best[b % 3][e & 3] : key;
                         }
                     }
             };
-            half(std::integral_constant<int, 0>{});
-            half(std::integral_constant<int, 1>{});
+            third(std::integral_constant<int, 0>{});
+            third(std::integral_constant<int, 1>{});
+            third(std::integral_constant<int, 2>{});
+            if (cbw + 2 < ncb || sweep == 0) {                          // (a clamped tail wave of a later sweep stores nothing new)
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const unsigned k2 = fe_half_max(best[tt]);
-                if (h == 0 && tt < nemit) a.pooled[((int64_t)(t0 + tt) * a.b + patch_i) * a.emb + col] = float_from_max_key(k2);
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const unsigned k2 = fe_half_max(best[j][tt]);
+                        if (h == 0 && tt < nemit)
+                            a.pooled[((int64_t)(t0 + tt) * a.b + patch_i) * a.emb + 32 * (cb0 + j) + r32] = float_from_max_key(k2);
+                    }
             }
         }
     }
@@ -913,7 +923,7 @@ int launch_pack_fd_neuron(const float* raw, int C, int eif, int coff, float* out
     return SAPCU_OK;
 }
 
-bool fd_encoder_ok(int m, int nscale, int emb, int T) { return m >= 1 && m <= FE_M && nscale >= 1 && nscale <= 4 && emb % 256 == 0 && emb >= 256 && T >= 1; }
+bool fd_encoder_ok(int m, int nscale, int emb, int T) { return m >= 1 && m <= FE_M && nscale >= 1 && nscale <= 4 && emb % 32 == 0 && emb >= 96 && T >= 1; }
 
 int launch_fd_encoder(const FdEncArgs& a, hipStream_t st) {
     if (a.b == 0) return SAPCU_OK;

@@ -951,7 +951,7 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
             if (rc == SAPCU_OK) hip_ok(hipMemset(m->gate_dev, 0, sizeof(int)), "memset gate");
             // the fused encoder's operands: five matrices in fragment order (hi | lo planes interleaved per fragment), neuron
             // parameters clamped once
-            if (rc == SAPCU_OK && m->sf16 && m->nscale <= 4 && m->emb % 256 == 0) {
+            if (rc == SAPCU_OK && m->sf16 && m->nscale <= 4 && m->emb >= 96) {
                 const int mats[5][3] = {{FD_FUSE_W, 64, 64 * m->nscale}, {FD_EDGE1_W, 256, 64}, {FD_EDGE2_W, 512, 128},
                                         {FD_EDGE3_W, 1024, 256}, {FD_MSC_W, m->emb, 960}};
                 int64_t halves = 0;
