@@ -384,40 +384,45 @@ __device__ __forceinline__ void fe_emit4(const float (&x)[4], const NeuronP& p, 
 
 // one K round of multi_scale_conv: nk16 k16 steps (8: 128 columns; 4 in the last round) starting at absolute step s_abs, this
 // wave's 2 row blocks x 3 column blocks cb0 .. cb0 + 2 (ALL emb columns are covered by the eight waves in one sweep over K, so
-// every spike is generated once).  Weight fragments L2 -> registers one k16 step ahead, refilled in place behind the MFMAs
+// every spike is generated once).  Weight fragments L2 -> registers two k16 steps ahead, refilled in place behind the MFMAs
 // that read them; the loop is rolled (a fully unrolled K sweep makes the compiler precompute — and spill — every fragment address).
 struct FeW {
-    half8 wh[3], wl[3];
+    half8 wh[2][3], wl[2][3];      // two k16 steps ahead (slot = step & 1)
 };
 __device__ __forceinline__ void fe_msc_round(const unsigned char* X, const half8* __restrict__ wp, int cb0, int s_abs, int nk16, int lane,
                                              FeW& W, f32x16 (&acc)[6]) {
     const int r32 = lane & 31, h = lane >> 5, sw = (r32 >> 2) & 3;
     const unsigned char* xa = X + r32 * 64;
-#pragma unroll 1
-    for (int s = 0; s < nk16; ++s) {
-        const unsigned ko = (unsigned)((s >> 1) * (FE_PR * 128) + ((((s & 1) * 2 + h) ^ sw) * 16));
-        half8 ah[2], al[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            ah[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048);
-            al[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048 + FE_PR * 64);
-        }
-        // acc[i * 3 + j]: row block i, column block cb0 + j; per accumulator a_lo w_hi, a_hi w_lo, a_hi w_hi
-#pragma unroll
-        for (int b = 0; b < 6; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b / 3], W.wh[b % 3], acc[b], 0, 0, 0);
-#pragma unroll
-        for (int b = 0; b < 6; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / 3], W.wl[b % 3], acc[b], 0, 0, 0);
-#pragma unroll
-        for (int b = 0; b < 6; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / 3], W.wh[b % 3], acc[b], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        const int sa = s_abs + s + 1;                       // (60 k16 steps in all; the last refill re-loads the last fragment)
-        const int sn = sa < 60 ? sa : 59;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            W.wh[j] = fe_wfrag(wp, 60, cb0 + j, sn, 0, lane);
-            W.wl[j] = fe_wfrag(wp, 60, cb0 + j, sn, 1, lane);
-        }
+#define SAPCU_FE_MSTEP(S, SJ)                                                                                           \
+    {                                                                                                                   \
+        const int s_ = (S);                                                                                             \
+        const unsigned ko = (unsigned)((s_ >> 1) * (FE_PR * 128) + ((((s_ & 1) * 2 + h) ^ sw) * 16));                   \
+        half8 ah[2], al[2];                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                 \
+            ah[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048);                                                \
+            al[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048 + FE_PR * 64);                                   \
+        }                                                                                                               \
+        /* acc[i * 3 + j]: row block i, column block cb0 + j; per accumulator a_lo w_hi, a_hi w_lo, a_hi w_hi */        \
+        _Pragma("unroll") for (int b = 0; b < 6; ++b)                                                                   \
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b / 3], W.wh[SJ][b % 3], acc[b], 0, 0, 0);                \
+        _Pragma("unroll") for (int b = 0; b < 6; ++b)                                                                   \
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / 3], W.wl[SJ][b % 3], acc[b], 0, 0, 0);                \
+        _Pragma("unroll") for (int b = 0; b < 6; ++b)                                                                   \
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / 3], W.wh[SJ][b % 3], acc[b], 0, 0, 0);                \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        const int sa_ = s_abs + s_ + 2;                     /* (60 k16 steps in all; the tail re-loads the last fragment) */ \
+        const int sn_ = sa_ < 60 ? sa_ : 59;                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                 \
+            W.wh[SJ][j] = fe_wfrag(wp, 60, cb0 + j, sn_, 0, lane);                                                      \
+            W.wl[SJ][j] = fe_wfrag(wp, 60, cb0 + j, sn_, 1, lane);                                                      \
+        }                                                                                                               \
     }
+#pragma unroll 1
+    for (int s0 = 0; s0 < nk16; s0 += 2) {
+        SAPCU_FE_MSTEP(s0, 0)
+        SAPCU_FE_MSTEP(s0 + 1, 1)
+    }
+#undef SAPCU_FE_MSTEP
 }
 
 __device__ __forceinline__ unsigned fe_half_max(unsigned x) {     // max of the two lane halves' values, in both halves
@@ -430,7 +435,7 @@ __device__ __forceinline__ unsigned fe_half_max(unsigned x) {     // max of the 
 // max over the neighbours, shift + LeakyReLU -> the block's pre-activation x0 (LDS for L <= 2, registers for L = 3).
 // ---------------------------------------------------------------------------------------------
 template <int L>
-__device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char* smem, int64_t patch_i, int tid, float (&x3)[3][5][4]) {
+__device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char* smem, int64_t patch_i, int tid, float (&x3)[3][4][4]) {
     constexpr int CIN = 64 << (L - 1), COUT = 128 << (L - 1);
     constexpr int COFF_IN = L == 1 ? 0 : (L == 2 ? 64 : 192), COFF_OUT = L == 1 ? 64 : (L == 2 ? 192 : 448);
     constexpr int KIND_IN = L == 1 ? 0 : (L == 2 ? 1 : 2);
@@ -600,15 +605,12 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int c3l = 2 * jj + 1 - (w & 1);          // chunk inside this pair round (0..3): block chunk c3 = 4 q + c3l
-                // round of chunk 7 + c3: R = (7 + c3) >> 1 -> slot R - 3 = 2 q + jj (odd waves: c3l = 2 jj) or 2 q + jj + 1 (even: 2 jj + 1)
+                // round of chunk 7 + c3: odd waves R = 3 + 2 q + jj, even waves R = 4 + 2 q + jj: slot 2 q + jj = R - 4 + (w & 1) for both
 #pragma unroll
                 for (int th = 0; th < 3; ++th)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = SA[(2 * c3l + (lane >> 5)) * (FE_M * 32) + (FE_TP * th + 4 * (w >> 1) + e) * 32 + (lane & 31)];
-                        if (w & 1) x3[th][2 * q + jj][e] = v;
-                        else x3[th][2 * q + jj + 1][e] = v;
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        x3[th][2 * q + jj][e] = SA[(2 * c3l + (lane >> 5)) * (FE_M * 32) + (FE_TP * th + 4 * (w >> 1) + e) * 32 + (lane & 31)];
             }
             __syncthreads();
         }
@@ -734,9 +736,9 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
     __syncthreads();
     FE_STAMP(3);
     // ---- blocks 1..3                                                                                          fd:447-474
-    // block 3's x0 of this thread's multi_scale_conv elements: [third of the patch][round R - 3][point].  Odd waves emit the block's chunks
-    // in rounds 3..6 (slots 0..3), even waves in rounds 4..7 (slots 1..4): one slot per thread stays unused, every index static
-    float x3[3][5][4];
+    // block 3's x0 of this thread's multi_scale_conv elements: [third of the patch][slot][point].  Odd waves emit the block's chunks
+    // in rounds 3..6, even waves in rounds 4..7: slot = R - 4 + (w & 1), selected by wave-uniform compares (every array index static)
+    float x3[3][4][4];
     fe_edge_block<1>(a, smem, patch_i, tid, x3);
     fe_edge_block<2>(a, smem, patch_i, tid, x3);
     fe_edge_block<3>(a, smem, patch_i, tid, x3);
@@ -797,10 +799,12 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
                     for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
                 FeW W;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    W.wh[j] = fe_wfrag(mscw, 60, cb0 + j, 0, 0, lane);
-                    W.wl[j] = fe_wfrag(mscw, 60, cb0 + j, 0, 1, lane);
-                }
+                for (int sj = 0; sj < 2; ++sj)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        W.wh[sj][j] = fe_wfrag(mscw, 60, cb0 + j, sj, 0, lane);
+                        W.wl[sj][j] = fe_wfrag(mscw, 60, cb0 + j, sj, 1, lane);
+                    }
                 NeuronP pnext = fe_load_np(a.nprm, 64 * cw + lane);      // a chunk's neuron parameters are loaded one round ahead
 #pragma unroll 1
                 for (int R = 0; R < 8; ++R) {
@@ -818,11 +822,11 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
                         } else {                                        // block 3: x0 from registers, slot R - 3 (wave-uniform selects:
 #pragma unroll                                                          // the loop stays rolled and x3 stays in registers)
                             for (int e = 0; e < 4; ++e) {
+                                const int slot = R - 4 + cw;
                                 float v = x3[TH][0][e];
-                                v = R == 4 ? x3[TH][1][e] : v;
-                                v = R == 5 ? x3[TH][2][e] : v;
-                                v = R == 6 ? x3[TH][3][e] : v;
-                                v = R == 7 ? x3[TH][4][e] : v;
+                                v = slot == 1 ? x3[TH][1][e] : v;
+                                v = slot == 2 ? x3[TH][2][e] : v;
+                                v = slot == 3 ? x3[TH][3][e] : v;
                                 x[e] = v;
                             }
                         }

@@ -851,10 +851,7 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
     m->opt_fn_maxfuse = !env_off("SAPCU_FN_MAXFUSE");
     m->opt_fd_maxfuse = !env_off("SAPCU_FD_MAXFUSE");
     m->opt_fd_split = !env_off("SAPCU_FD_SPLIT");
-    {   // (opt-in until it beats the per-stage kernels: SAPCU_FD_FUSED=1)
-        const char* fe = getenv("SAPCU_FD_FUSED");
-        m->opt_fd_fused = fe && strcmp(fe, "1") == 0;
-    }
+    m->opt_fd_fused = !env_off("SAPCU_FD_FUSED");
     const char* ce = getenv("SAPCU_CHUNK");
     m->chunk = ce ? atoll(ce) : 0;
     if (m->chunk < 0) m->chunk = 0;
