@@ -58,8 +58,11 @@ constexpr int FE_OFF_IDX0 = FE_OFF_XYZ + FE_M * 16;        // u8[48][48]: xyz ne
 constexpr int FE_OFF_IDXL = FE_OFF_IDX0 + FE_M * FE_M;     // u8[48][48]: feature-space neighbours of the current block
 constexpr int FE_OFF_XX = FE_OFF_IDXL + FE_M * FE_M;       // float[64]
 constexpr int FE_LDS = FE_OFF_XX + 256;                    // 157 184 B
-constexpr int FE_F_LD = 33;                                // score staging [64][33] f32 at R2 + 0, keys [m][m+1] behind it
-constexpr int FE_KEYS_OFF = 64 * FE_F_LD * 4;
+constexpr int FE_F_LD = 33;                                // score staging 2 x [64][33] f32 at R2 + 0, keys [m][m+1] behind them
+constexpr int FE_KEYS_OFF = 2 * 64 * FE_F_LD * 4;         // (two staging buffers)
+constexpr int FE_TLD = 36;                                 // EdgeConv staging tile of a wave: [48][36] f32 (32 channels + 4 pad)
+constexpr int FE_TILE = FE_M * FE_TLD;
+static_assert(8 * FE_TILE * 4 <= FE_R2_BYTES, "fd encoder: staging tiles");
 static_assert(FE_LDS <= 163840, "fd encoder: LDS budget");
 static_assert(FE_KEYS_OFF + FE_M * (FE_M + 1) * 4 <= FE_R2_BYTES, "fd encoder: score keys");
 
@@ -115,13 +118,13 @@ __device__ __forceinline__ half8 fe_wfrag(const half8* __restrict__ wp, int nk16
 // C[64 rows, NCB column blocks] = panel[64, 16 nk16] . W^T for this wave's column blocks cb[]: both 32-row blocks, weights
 // L2 -> registers two k16 steps ahead, products (a_lo w_hi, a_hi w_lo, a_hi w_hi) per k16 step in ascending k — the order of
 // every split-f16 GEMM of the library.  acc[i * NCB + j] = row block i, column block cb[j].
-template <int NCB>
+template <int NCB, int NRB = 2>
 __device__ __forceinline__ void fe_gemm64(const unsigned char* X, const half8* __restrict__ wp, int nk16, const int (&cb)[NCB],
-                                          int lane, f32x16 (&acc)[2 * NCB]) {
+                                          int lane, f32x16 (&acc)[NRB * NCB], int rb0 = 0) {
     const int r32 = lane & 31, h = lane >> 5, sw = (r32 >> 2) & 3;
-    const unsigned char* xa = X + r32 * 64;
+    const unsigned char* xa = X + r32 * 64 + rb0 * 2048;         // NRB row blocks starting at row block rb0
 #pragma unroll
-    for (int b = 0; b < 2 * NCB; ++b)
+    for (int b = 0; b < NRB * NCB; ++b)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
     half8 wh[2][NCB], wl[2][NCB];
@@ -136,16 +139,16 @@ __device__ __forceinline__ void fe_gemm64(const unsigned char* X, const half8* _
     {                                                                                                                 \
         const int s_ = (S);                                                                                           \
         const unsigned ko = (unsigned)((s_ >> 1) * 8192 + ((((s_ & 1) * 2 + h) ^ sw) * 16));                          \
-        half8 ah[2], al[2];                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                               \
+        half8 ah[NRB], al[NRB];                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < NRB; ++i) {                                                             \
             ah[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048);                                              \
             al[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048 + 4096);                                       \
         }                                                                                                             \
-        _Pragma("unroll") for (int b = 0; b < 2 * NCB; ++b)                                                           \
+        _Pragma("unroll") for (int b = 0; b < NRB * NCB; ++b)                                                         \
             acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b / NCB], wh[SJ][b % NCB], acc[b], 0, 0, 0);           \
-        _Pragma("unroll") for (int b = 0; b < 2 * NCB; ++b)                                                           \
+        _Pragma("unroll") for (int b = 0; b < NRB * NCB; ++b)                                                         \
             acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / NCB], wl[SJ][b % NCB], acc[b], 0, 0, 0);           \
-        _Pragma("unroll") for (int b = 0; b < 2 * NCB; ++b)                                                           \
+        _Pragma("unroll") for (int b = 0; b < NRB * NCB; ++b)                                                         \
             acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / NCB], wh[SJ][b % NCB], acc[b], 0, 0, 0);           \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
         const int sn_ = s_ + 2 < nk16 ? s_ + 2 : nk16 - 1;                                                            \
@@ -163,31 +166,48 @@ __device__ __forceinline__ void fe_gemm64(const unsigned char* X, const half8* _
 }
 
 
+// sum of v over the 64 lanes (wave-uniform result): DPP butterflies inside rows of 16, then four scalar reads — the
+// ds_bpermute shuffles of __shfl_xor cost an LDS round trip each
+__device__ __forceinline__ int fe_wave_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);     // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);     // row_mirror: every lane holds its row's sum
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+
 // ---------------------------------------------------------------------------------------------
 // In-patch kNN (fd/snn_coder.py:25-32), the arithmetic of patch_knn_kernel<3> (patch_ops.hip): score[i][j] = (-xx[j] - (-2 <xi,xj>))
 // - xx[i] with <.,.> a channel-ascending f32 FMA chain and xx a sequential sum of rounded squares; top-k by descending score,
-// equal scores by ascending index.  `fill(c0, cw)` stages channels c0 .. c0+cw-1 of all 64 rows (rows >= m: 0) into F[row][33].
-// Scores: threads 0..255 as a 16 x 16 grid of 3 x 3 pair blocks; ranks: one wave per row, the row's keys broadcast through
-// scalar registers.  Output: idx_out[i][rank] (bytes, row pitch 48) and the optional int32 tap [m][k].
+// equal scores by ascending index.  `fill(F, c0, cw, ftid)` (threads 256..511, ftid = tid - 256) stages channels c0 .. c0+cw-1
+// of all 64 rows (rows >= m: 0) into F[row][33]; the staging area is double-buffered: waves 4-7 fill chunk n + 1 while waves
+// 0-3 — a 16 x 16 grid of 3 x 3 pair blocks — accumulate chunk n (one barrier per chunk).  Ranks: one wave per row, the row's
+// keys broadcast through scalar registers.  Output: idx_out[i][rank] (bytes, row pitch 48) and the optional int32 tap [m][k].
 // ---------------------------------------------------------------------------------------------
 template <typename Fill>
 __device__ __forceinline__ void fe_knn(unsigned char* R2, float* xx, unsigned char* idx_out, int m, int c, int k, Fill fill,
                                        int32_t* __restrict__ tap, int tid) {
-    float* F = reinterpret_cast<float*>(R2);
+    float* Fb = reinterpret_cast<float*>(R2);                          // two buffers of [64][33]
     unsigned* K = reinterpret_cast<unsigned*>(R2 + FE_KEYS_OFF);
     const int bi = (tid >> 4) & 15, bj = tid & 15;
+    const bool scorer = tid < 256;
     float acc[3][3];
 #pragma unroll
     for (int u = 0; u < 3; ++u)
 #pragma unroll
         for (int v = 0; v < 3; ++v) acc[u][v] = 0.f;
     float myxx = 0.f;
-    for (int c0 = 0; c0 < c; c0 += 32) {
+    __syncthreads();                                                   // the area is free (previous phase done)
+    if (!scorer) fill(Fb, 0, min(32, c), tid - 256);
+    __syncthreads();
+    int buf = 0;
+    for (int c0 = 0; c0 < c; c0 += 32, buf ^= 1) {
         const int cw = min(32, c - c0);
-        __syncthreads();
-        fill(c0, cw);
-        __syncthreads();
-        if (tid < 256) {
+        float* F = Fb + buf * (64 * FE_F_LD);
+        if (!scorer) {
+            if (c0 + 32 < c) fill(Fb + (buf ^ 1) * (64 * FE_F_LD), c0 + 32, min(32, c - c0 - 32), tid - 256);
+        } else {
             const float* fi = F + (bi * 3) * FE_F_LD;
             const float* fj = F + (bj * 3) * FE_F_LD;
             // groups of 8 channels: the 48 LDS reads of a group are issued before its FMAs (one wave per SIMD works here: a
@@ -238,16 +258,17 @@ __device__ __forceinline__ void fe_knn(unsigned char* R2, float* xx, unsigned ch
             }
             if (tid < m) {
                 const float* fr = F + tid * FE_F_LD;
-                for (int cc = 0; cc < cw; ++cc) {
-                    const float sq = __fmul_rn(fr[cc], fr[cc]);
-                    myxx = (c0 == 0 && cc == 0) ? sq : __fadd_rn(myxx, sq);
+                for (int cc2 = 0; cc2 < cw; ++cc2) {
+                    const float sq = __fmul_rn(fr[cc2], fr[cc2]);
+                    myxx = (c0 == 0 && cc2 == 0) ? sq : __fadd_rn(myxx, sq);
                 }
             }
         }
+        __syncthreads();                                               // chunk n consumed, chunk n + 1 staged
     }
     if (tid < m) xx[tid] = myxx;
     __syncthreads();
-    if (tid < 256) {
+    if (scorer) {
 #pragma unroll
         for (int u = 0; u < 3; ++u)
 #pragma unroll
@@ -269,9 +290,7 @@ __device__ __forceinline__ void fe_knn(unsigned char* R2, float* xx, unsigned ch
 #pragma unroll
             for (int u = 0; u < 8; ++u) r0 += (unsigned)__builtin_amdgcn_readlane(key0, (jb + u) & 63) > key0;
         }
-        int tot = lane < m ? r0 : 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+        const int tot = fe_wave_sum(lane < m ? r0 : 0);
         if (tot != full) {                      // (wave-uniform) equal scores in this row: exact (score, index) order
             const unsigned long long k0 = ((unsigned long long)key0 << 32) | (unsigned)~lane;
             r0 = 0;
@@ -457,18 +476,24 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
             if (a.tap_knn) a.tap_knn[tab_off + e] = v;
         }
     } else {
-        auto fill = [&](int c0, int cw) {
-            // thread -> channel c0 + (tid & 31), rows (tid >> 5) + 16 n: one parameter load per chunk
-            float* F = reinterpret_cast<float*>(R2);
-            const int cc = tid & 31;
-            const NeuronP p = fe_load_np(a.nprm, COFF_IN + c0 + cc);
+        // thread (256 of them) -> channel c0 + (ftid & 31), rows (ftid >> 5) + 8 n; a chunk's parameters are loaded one chunk ahead
+        NeuronP pn = fe_load_np(a.nprm, COFF_IN + (tid & 31));
+        auto fill = [&](float* F, int c0, int cw, int ftid) {
+            const int cc = ftid & 31;
+            const NeuronP p = pn;
+            pn = fe_load_np(a.nprm, COFF_IN + (c0 + 32 < CIN ? c0 + 32 : c0) + cc);
 #pragma unroll
-            for (int n = 0; n < 4; n += 2) {
-                const int ia = (tid >> 5) + 16 * n, ib = ia + 16;           // rows < 48 hold x0 (whatever it is beyond m)
-                const f32x2 sp = fe_spike0<KIND_IN>(f32x2{XS[(ia < FE_M ? ia : 0) * FE_XLD + COFF_IN + c0 + cc],
-                                                          XS[(ib < FE_M ? ib : 0) * FE_XLD + COFF_IN + c0 + cc]}, p);
-                F[ia * FE_F_LD + cc] = ia < m ? sp.x : 0.f;
-                F[ib * FE_F_LD + cc] = ib < m ? sp.y : 0.f;
+            for (int n = 0; n < 8; n += 2) {
+                const int ia = (ftid >> 5) + 8 * n, ib = ia + 8;            // rows < 48 hold x0 (whatever it is beyond m)
+                if (ia < FE_M) {                                            // (rows 48..63: zeros, ib < 48 whenever ia < 40)
+                    const f32x2 sp = fe_spike0<KIND_IN>(f32x2{XS[ia * FE_XLD + COFF_IN + c0 + cc],
+                                                              XS[(ib < FE_M ? ib : ia) * FE_XLD + COFF_IN + c0 + cc]}, p);
+                    F[ia * FE_F_LD + cc] = ia < m ? sp.x : 0.f;
+                    F[ib * FE_F_LD + cc] = (ib < m && ib < FE_M) ? sp.y : 0.f;
+                } else {
+                    F[ia * FE_F_LD + cc] = 0.f;
+                    F[ib * FE_F_LD + cc] = 0.f;
+                }
             }
             (void)cw;
         };
@@ -480,8 +505,10 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
     //     GEMM's rows are independent and those outputs are never used)
     {
         const int cc = tid & 63;
+        NeuronP pn2 = fe_load_np(a.nprm, COFF_IN + cc);
         for (int c0 = 0; c0 < CIN; c0 += 64) {
-            const NeuronP p = fe_load_np(a.nprm, COFF_IN + c0 + cc);
+            const NeuronP p = pn2;
+            pn2 = fe_load_np(a.nprm, COFF_IN + (c0 + 64 < CIN ? c0 + 64 : c0) + cc);
 #pragma unroll
             for (int n = 0; n < 6; n += 2) {
                 const int ia = (tid >> 6) + 8 * n, ib = ia + 8;            // rows 0..47
@@ -510,10 +537,13 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
     }
     __syncthreads();                                       // every wave has read the panel: R2 becomes the staging area
     FE_STAMP(4 * L + 2);
-    // (4) per pair: stage A' (rows < 48) in this wave's private [48][32] tile, max over the kk neighbours per (point, channel),
-    //     pre = LeakyReLU((max - B) + shift)
-    float* SAw = reinterpret_cast<float*>(R2) + w * (FE_M * 32);
+    // (4) per pair: stage A' (rows < 48) in this wave's private [48][36] tile (pitch 36 floats: 16-byte aligned rows that do not all
+    //     start in the same bank); the max over the kk neighbours is taken with the lanes re-mapped to (channel quad, six rows) —
+    //     one 16-byte tile read per neighbour serves four channels (a lane-per-channel walk spends 4 instructions per element and
+    //     neighbour) —, written back over the tile, and picked up in the accumulator layout: pre = LeakyReLU((max - B) + shift)
+    float* SAw = reinterpret_cast<float*>(R2) + w * FE_TILE;
     const int r32 = lane & 31, h = lane >> 5;
+    const int qd = lane & 7, g6 = 6 * (lane >> 3);              // the max phase's mapping: channels 4 qd .. 4 qd + 3, rows g6 .. g6 + 5
 #pragma unroll
     for (int q = 0; q < NPW; ++q) {
         float pre[2][16];
@@ -526,54 +556,62 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
                 for (int e = 0; e < 16; ++e) {
                     if (32 * i + 8 * (e >> 2) >= FE_M) continue;              // 48 = 6 x 8: whole groups of 8 rows are in or out
                     const int row = 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
-                    SAw[row * 32 + r32] = __fadd_rn(__fmul_rn(acc[q][i * 2][e], 0.0625f), 0.0f);    // the GEMM epilogue's value (no bias)
+                    SAw[row * FE_TLD + r32] = __fadd_rn(__fmul_rn(acc[q][i * 2][e], 0.0625f), 0.0f);    // the GEMM epilogue's value (no bias)
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            // groups of eight rows (one accumulator quad pair), the neighbour loop outside: the eight index reads of a step, then
-            // their 32 tile reads, are independent — a row-at-a-time loop is a chain of dependent LDS latencies
+            {
+                float4 mx[6];
 #pragma unroll
-            for (int g = 0; g < 6; g += 2) {                 // row groups 8 g .. 8 g + 15 (this lane: 4 h + 0..3 of each group of 8)
-                float mx8[8];
-#pragma unroll
-                for (int z = 0; z < 8; ++z) mx8[z] = -__builtin_huge_valf();
-                const unsigned char* ir0 = IDXL + (8 * g + 4 * h) * FE_M;        // rows 8 g + 4 h + u, then 8 (g + 1) + 4 h + u
+                for (int r = 0; r < 6; ++r) mx[r] = make_float4(-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf());
+                const unsigned char* ir0 = IDXL + g6 * FE_M;
+                const float* tq = SAw + 4 * qd;
                 int j = 0;
                 for (; j + 4 <= kk; j += 4) {
-                    unsigned pk[8];
+                    unsigned pk[6];
 #pragma unroll
-                    for (int z = 0; z < 8; ++z) pk[z] = *reinterpret_cast<const unsigned*>(ir0 + ((z >> 2) * 8 + (z & 3)) * FE_M + j);
+                    for (int r = 0; r < 6; ++r) pk[r] = *reinterpret_cast<const unsigned*>(ir0 + r * FE_M + j);
 #pragma unroll
-                    for (int z = 0; z < 8; ++z) {
-                        const float v0 = SAw[(pk[z] & 255u) * 32 + r32], v1 = SAw[((pk[z] >> 8) & 255u) * 32 + r32];
-                        const float v2 = SAw[((pk[z] >> 16) & 255u) * 32 + r32], v3 = SAw[(pk[z] >> 24) * 32 + r32];
-                        mx8[z] = fmaxf(fmaxf(mx8[z], v0), fmaxf(v1, fmaxf(v2, v3)));
+                    for (int r = 0; r < 6; ++r) {
+                        const float4 v0 = *reinterpret_cast<const float4*>(tq + (pk[r] & 255u) * FE_TLD);
+                        const float4 v1 = *reinterpret_cast<const float4*>(tq + ((pk[r] >> 8) & 255u) * FE_TLD);
+                        const float4 v2 = *reinterpret_cast<const float4*>(tq + ((pk[r] >> 16) & 255u) * FE_TLD);
+                        const float4 v3 = *reinterpret_cast<const float4*>(tq + (pk[r] >> 24) * FE_TLD);
+                        mx[r].x = fmaxf(fmaxf(mx[r].x, v0.x), fmaxf(v1.x, fmaxf(v2.x, v3.x)));
+                        mx[r].y = fmaxf(fmaxf(mx[r].y, v0.y), fmaxf(v1.y, fmaxf(v2.y, v3.y)));
+                        mx[r].z = fmaxf(fmaxf(mx[r].z, v0.z), fmaxf(v1.z, fmaxf(v2.z, v3.z)));
+                        mx[r].w = fmaxf(fmaxf(mx[r].w, v0.w), fmaxf(v1.w, fmaxf(v2.w, v3.w)));
                     }
                 }
                 for (; j < kk; ++j) {
 #pragma unroll
-                    for (int z = 0; z < 8; ++z) mx8[z] = fmaxf(mx8[z], SAw[ir0[((z >> 2) * 8 + (z & 3)) * FE_M + j] * 32 + r32]);
-                }
-#pragma unroll
-                for (int z = 0; z < 8; ++z) {
-                    const int gg = g + (z >> 2);              // group of 8 rows: accumulator block gg / 4, quad gg % 4
-                    const int i = gg >> 2, e = (gg & 3) * 4 + (z & 3);
-                    const int row = 8 * gg + 4 * h + (z & 3);
-                    const float mx = mx8[z];
-                    const float xb = __fadd_rn(__fmul_rn(acc[q][i * 2 + 1][e], 0.0625f), 0.0f);
-                    pre[i][e] = lrelu02(__fadd_rn(__fsub_rn(mx, xb), sh));
-#ifdef FE_DEBUG_AB          // diagnostic build: block 1's GEMM outputs A' | B in columns 192.. | 320.. of the x0 tap
-                    if (L == 1 && a.tap_x0 && row < m) {
-                        a.tap_x0[((a.s0 + patch_i) * m + row) * 960 + 192 + col] = SAw[row * 32 + r32];
-                        a.tap_x0[((a.s0 + patch_i) * m + row) * 960 + 320 + col] = xb;
+                    for (int r = 0; r < 6; ++r) {
+                        const float4 v0 = *reinterpret_cast<const float4*>(tq + ir0[r * FE_M + j] * FE_TLD);
+                        mx[r].x = fmaxf(mx[r].x, v0.x);
+                        mx[r].y = fmaxf(mx[r].y, v0.y);
+                        mx[r].z = fmaxf(mx[r].z, v0.z);
+                        mx[r].w = fmaxf(mx[r].w, v0.w);
                     }
-#endif
-#ifdef FE_DEBUG_AB
-                    if (L == 1)
-#endif
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();           // every lane has read the tile: the maxima go over it
+#pragma unroll
+                for (int r = 0; r < 6; ++r) *reinterpret_cast<float4*>(SAw + (g6 + r) * FE_TLD + 4 * qd) = mx[r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (32 * i + 8 * (e >> 2) >= FE_M) continue;
+                    const int row = 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
+                    const float mxv = SAw[row * FE_TLD + r32];
+                    const float xb = __fadd_rn(__fmul_rn(acc[q][i * 2 + 1][e], 0.0625f), 0.0f);
+                    pre[i][e] = lrelu02(__fadd_rn(__fsub_rn(mxv, xb), sh));
                     if (a.tap_x0 && row < m) a.tap_x0[((a.s0 + patch_i) * m + row) * 960 + COFF_OUT + col] = pre[i][e];
                 }
-            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();               // this wave's reads of its tile are done before it is rewritten
             if (L <= 2) {
 #pragma unroll
@@ -593,7 +631,7 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
                     for (int e = 0; e < 16; ++e) {
                         if (32 * i + 8 * (e >> 2) >= FE_M) continue;
                         const int row = 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
-                        SAw[row * 32 + r32] = pre[i][e];
+                        SAw[row * FE_TLD + r32] = pre[i][e];
                     }
             }
         }
@@ -610,7 +648,7 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
                 for (int th = 0; th < 3; ++th)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        x3[th][2 * q + jj][e] = SA[(2 * c3l + (lane >> 5)) * (FE_M * 32) + (FE_TP * th + 4 * (w >> 1) + e) * 32 + (lane & 31)];
+                        x3[th][2 * q + jj][e] = SA[(2 * c3l + (lane >> 5)) * FE_TILE + (FE_TP * th + 4 * (w >> 1) + e) * FE_TLD + (lane & 31)];
             }
             __syncthreads();
         }
@@ -641,10 +679,9 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
     FE_STAMP(0);
     // ---- block 0: xyz neighbours (one ranking serves all scales)                                          fd:411-417
     {
-        auto fill = [&](int c0, int cw) {
-            float* F = reinterpret_cast<float*>(R2);
-            for (int e = tid; e < 64 * 3; e += FE_NT) {
-                const int i = e / 3, cc = e % 3;
+        auto fill = [&](float* F, int c0, int cw, int ftid) {
+            if (ftid < 64 * 3) {
+                const int i = ftid / 3, cc = ftid % 3;
                 const float4 v = XYZ[i < FE_M ? i : 0];
                 F[i * FE_F_LD + cc] = i < m ? (cc == 0 ? v.x : (cc == 1 ? v.y : v.z)) : 0.f;
             }
@@ -663,6 +700,9 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
             for (int t = 0; t < 6; ++t) wt[s][t] = s < a.nscale ? a.e0_w[((int64_t)s * 64 + lane) * 6 + t] : 0.f;
             bb[s] = s < a.nscale ? a.e0_b[s * 64 + lane] : 0.f;
         }
+        int ksv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ksv[s] = s < a.nscale ? a.ks[s] : 0;
         float big = 0.f;
         for (int i = 2 * w; i < m; i += 16) {
             const int i1 = (i + 1 < m) ? i + 1 : i;
@@ -671,24 +711,31 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
             f32x2 mx[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) mx[s] = f32x2{-__builtin_huge_valf(), -__builtin_huge_valf()};
-            for (int j0 = 0; j0 < a.kmax0; j0 += 4) {
-                // four edges per point: the (wave-uniform) index reads, then the coordinate reads, are issued together
-                const unsigned na4 = *reinterpret_cast<const unsigned*>(IDX0 + i * FE_M + j0);       // (row pitch 48, j0 % 4 == 0)
-                const unsigned nb4 = *reinterpret_cast<const unsigned*>(IDX0 + i1 * FE_M + j0);
-                float4 qa[4], qb[4];
+            // the coordinates of four edges per point are read one batch AHEAD of the arithmetic that uses them (index -> coordinate
+            // is a chain of two LDS latencies); the batch loop is rolled, two batches per iteration (static double-buffer slots) —
+            // fully unrolled, the compiler hoists the 192 (edge, scale) activity conditions out of the point loop and spills them
+            const unsigned char* ia_ = IDX0 + i * FE_M;
+            const unsigned char* ib_ = IDX0 + i1 * FE_M;
+            float4 qa[2][4], qb[2][4];
+            auto issue = [&](int d, float4 (&da)[4], float4 (&db)[4]) {
+                const int dd = d < 12 ? d : 11;                          // (row pitch 48 bytes = 12 batches; entries beyond kmax0: "point 0")
+                const unsigned na = *reinterpret_cast<const unsigned*>(ia_ + 4 * dd);
+                const unsigned nb = *reinterpret_cast<const unsigned*>(ib_ + 4 * dd);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    qa[u] = XYZ[(na4 >> (8 * u)) & 255u];
-                    qb[u] = XYZ[(nb4 >> (8 * u)) & 255u];
+                    da[u] = XYZ[(na >> (8 * u)) & 255u];
+                    db[u] = XYZ[(nb >> (8 * u)) & 255u];
                 }
+            };
+            auto edges = [&](int j0, const float4 (&da)[4], const float4 (&db)[4]) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int j = j0 + u;
-                    const f32x2 xj = f32x2{qa[u].x, qb[u].x}, yj = f32x2{qa[u].y, qb[u].y}, zj = f32x2{qa[u].z, qb[u].z};
+                    const f32x2 xj = f32x2{da[u].x, db[u].x}, yj = f32x2{da[u].y, db[u].y}, zj = f32x2{da[u].z, db[u].z};
                     const f32x2 dx = xj - xi, dy = yj - yi, dz = zj - zi;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        if (s < a.nscale && j < a.ks[s]) {
+                        if (j < ksv[s]) {                                   // (ksv[s] = 0 for s >= nscale)
                             f32x2 v = f32x2{wt[s][0], wt[s][0]} * dx;
                             v = pk_fma(f32x2{wt[s][1], wt[s][1]}, dy, v);
                             v = pk_fma(f32x2{wt[s][2], wt[s][2]}, dz, v);
@@ -699,6 +746,14 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
                         }
                     }
                 }
+            };
+            issue(0, qa[0], qb[0]);
+#pragma unroll 1
+            for (int d0 = 0; 4 * d0 < a.kmax0; d0 += 2) {
+                issue(d0 + 1, qa[1], qb[1]);
+                edges(4 * d0, qa[0], qb[0]);
+                issue(d0 + 2, qa[0], qb[0]);
+                if (4 * (d0 + 1) < a.kmax0) edges(4 * (d0 + 1), qa[1], qb[1]);
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -715,23 +770,24 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
     __syncthreads();
     FE_STAMP(2);
     // ---- block 0: scale_fusion (64 S -> 64) + BN + LeakyReLU = x0 of block 0                                fd:420-421
-    if (w < 2) {
-        f32x16 acc[2];
-        const int cbs[1] = {w};
-        fe_gemm64<1>(R2, reinterpret_cast<const half8*>(a.fuse_wp), 4 * a.nscale, cbs, lane, acc);
-        const int col = 32 * w + r32;
+    if (w < 4) {                                           // four 32 x 32 output blocks, one per wave (one wave per SIMD)
+        f32x16 acc[1];
+        const int cbs[1] = {w & 1};
+        const int i = w >> 1;
+        fe_gemm64<1, 1>(R2, reinterpret_cast<const half8*>(a.fuse_wp), 4 * a.nscale, cbs, lane, acc, i);
+        const int col = 32 * (w & 1) + r32;
         const float bias = a.fuse_b[col];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
+        {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 if (32 * i + 8 * (e >> 2) >= FE_M) continue;
                 const int row = 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
-                const float v = lrelu02(__fadd_rn(__fmul_rn(acc[i][e], 0.0625f), bias));
+                const float v = lrelu02(__fadd_rn(__fmul_rn(acc[0][e], 0.0625f), bias));
                 XS[row * FE_XLD + col] = v;
                 if (a.tap_fused0 && row < m) a.tap_fused0[((a.s0 + patch_i) * m + row) * 64 + col] = v;
                 if (a.tap_x0 && row < m) a.tap_x0[((a.s0 + patch_i) * m + row) * 960 + col] = v;
             }
+        }
     }
     __syncthreads();
     FE_STAMP(3);
