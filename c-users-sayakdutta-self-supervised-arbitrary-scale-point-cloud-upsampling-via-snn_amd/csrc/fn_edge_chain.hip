@@ -24,7 +24,7 @@
 // e of block i = row 32i + 8(e>>2) + 4h + (e&3)), pe stays in registers until the aggregation, the per-point softmax gets
 // its rows from the two lane halves with v_permlane32_swap and sums them in neighbour order — every value equals the
 // unfused chain's bit for bit (same split-f16 products in the same order, same neuron arithmetic, same softmax order).
-// d = 128: 256-thread workgroups, 51 KiB of LDS -> three per CU.  d = 256: 512 threads, 131 KiB, one per CU.  d = 512: 512
+// d = 128: 256-thread workgroups, 51 KiB of LDS, two per CU (192 registers, see the kernel).  d = 256: 512 threads, 131 KiB, one per CU.  d = 512: 512
 // threads (wave tile 64 x 64), 131 KiB.  The k loops are rolled (two k16 steps per iteration).  What bounds them (each pipe at its practical rate, the
 // kernel time their sum) and the overlap designs that were measured without gain: DESIGN.md section 4.1c.
 #include "common.h"
@@ -35,7 +35,7 @@ namespace sapcu {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // Shape of a workgroup's work.  ROWS = MFMA rows per group = whole points: d = 128: 96 rows = 4 points of 24 neighbours (no idle
-// row; 51 KiB of LDS -> THREE 4-wave workgroups per CU, 168 registers per wave), d = 256: 128 rows = 7 points of 18 (one 8-wave
+// row; 51 KiB of LDS; two 4-wave workgroups per CU at 192 registers per wave), d = 256: 128 rows = 7 points of 18 (one 8-wave
 // workgroup, 256 registers), d = 512: 64 rows = 5 points of 12 (a 128-row panel of 512 columns would be 256 KiB; one 8-wave
 // workgroup, 256 registers).  One plane of one k32 step is [ROWS][32 halves]; a k32 step = hi plane | lo plane.  A wave owns CB
 // column blocks of 32 and all ROWS rows: RB x CB accumulator blocks.  CB = 2 at d = 512 (wave tile 64 x 64): half the LDS
@@ -44,7 +44,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // the weight ring refilled in place and unconditionally (exact wait counts in the rolled k loop) 17.2; 8 waves, same loop 16.6;
 // 8 waves, epilogue units of 8 elements 16.3 (before the wait counts were exact the 8-wave form lost: 18.4 against 17.6).
 // d = 256: fully unrolled k loop 8.27, rolled 8.10.  d = 128: 128-row groups (5 points + 8 idle rows), two workgroups per CU,
-// unrolled loop 4.64; 96-row groups, three per CU, rolled loop 4.42.
+// unrolled loop 4.64; 96-row groups, three per CU (168 registers, 23 of them spilled), rolled loop 4.42; two per CU, no spill: 4.55 (r3).
 template <int D> struct ChainShape {
     static constexpr int ROWS = D == 128 ? 96 : (D == 256 ? 128 : 64);
     static constexpr int RB = ROWS / 32;              // 32-row MFMA blocks per wave tile
@@ -206,9 +206,12 @@ __device__ __forceinline__ NeuronP chain_lif(const float* __restrict__ lif, int 
     return np;
 }
 
-// threads = 64 x (d / 32 / CB).  d = 128: three 256-thread workgroups per CU
+// threads = 64 x (d / 32 / CB).  d = 128: two 256-thread workgroups per CU.  (LDS would hold three — 51 KiB each — and three ran
+// 2.9 % faster, 4.55 against 4.68 ms per launch, but only at 168 registers per wave: the compiler then spills 23 of them, whatever
+// is trimmed from the epilogues, and their scratch traffic was 1.2 of the launch's 1.68 GB of HBM bytes.  At two per CU the kernel
+// takes 192 registers and touches no scratch.)
 template <int D, int KK>
-__global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? 3 : 1)) void fn_edge_chain_kernel(const ChainArgs a) {
+__global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? 2 : 1)) void fn_edge_chain_kernel(const ChainArgs a) {
     using S = ChainShape<D>;
     constexpr int CH_ROWS = S::ROWS, RB = S::RB, CB = S::CB, NB = S::NB, CH_PLANE = S::PLANE, CH_KSTEP = S::KSTEP;
     constexpr int PPG = CH_ROWS / KK;                      // points per group

@@ -27,16 +27,20 @@ struct KnnOut {
 // per channel it reads BT + BT values from LDS for BT*BT FMAs (one-pair-per-thread needed 2 reads per FMA and was bound
 // by LDS bandwidth in feature space, c = 64..256).  Every pair still sees ITS chain in ascending channel order, so the
 // scores are bit-identical.  BT = ceil(m / 16): 3 for the model's 48-point patches, 7 for the reference's default m = 100, up to 8.
-template <int BT>
-__global__ __launch_bounds__(256) void patch_knn_kernel(const float* __restrict__ feat, int64_t pstride, int m,
-                                                        int c, int ld, const KnnOut out) {
+// NT = 256, or 512 for m > 64 (BT >= 5): the rank phase — m^3 compares per patch, one wave per row — then has eight waves per
+// workgroup (the score keys of a 100-point patch take 40 KiB of LDS: two workgroups per CU either way); the score phase keeps
+// its 16 x 16 thread grid (threads 256.. only help staging).
+template <int BT, int NT>
+__global__ __launch_bounds__(NT) void patch_knn_kernel(const float* __restrict__ feat, int64_t pstride, int m,
+                                                       int c, int ld, const KnnOut out) {
     extern __shared__ float sm[];
     unsigned* K = reinterpret_cast<unsigned*>(sm);   // [m][m+1] score keys
     float* xx = sm + m * (m + 1);       // [m]
     float* F = xx + m;                  // [16*BT][PK_CH+1]  (rows >= m zero)
     const int tid = threadIdx.x;
     const float* base = feat + (int64_t)blockIdx.x * pstride;
-    const int bi = tid >> 4, bj = tid & 15;
+    const int bi = (tid >> 4) & 15, bj = tid & 15;
+    const bool scorer = NT == 256 || tid < 256;
     const int mpad = 16 * BT;
     float acc[BT][BT];
 #pragma unroll
@@ -47,11 +51,12 @@ __global__ __launch_bounds__(256) void patch_knn_kernel(const float* __restrict_
     for (int c0 = 0; c0 < c; c0 += PK_CH) {
         const int cw = min(PK_CH, c - c0);
         __syncthreads();
-        for (int e = tid; e < mpad * cw; e += 256) {
+        for (int e = tid; e < mpad * cw; e += NT) {
             const int i = e / cw, cc = e % cw;
             F[i * (PK_CH + 1) + cc] = i < m ? base[(int64_t)i * ld + c0 + cc] : 0.f;
         }
         __syncthreads();
+        if (!scorer) continue;                          // (the barriers above are reached by every thread each iteration)
         const float* fi = F + (bi * BT) * (PK_CH + 1);
         const float* fj = F + (bj * BT) * (PK_CH + 1);
         for (int cc = 0; cc < cw; ++cc) {
@@ -83,6 +88,7 @@ __global__ __launch_bounds__(256) void patch_knn_kernel(const float* __restrict_
     }
     if (tid < m) xx[tid] = myxx;
     __syncthreads();
+    if (scorer)
 #pragma unroll
     for (int u = 0; u < BT; ++u)
 #pragma unroll
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256) void patch_knn_kernel(const float* __restrict_
     // ~index: greater = higher score, or equal score and lower index.
     const int lane = tid & 63, wave = tid >> 6;
     const int full = m * (m - 1) / 2;
-    for (int i = wave; i < m; i += 4) {
+    for (int i = wave; i < m; i += NT / 64) {
         const unsigned* row = K + i * (m + 1);
         const int j0 = lane, j1 = lane + 64;
         const unsigned key0 = j0 < m ? row[j0] : 0u, key1 = j1 < m ? row[j1] : 0u;
@@ -177,19 +183,19 @@ int launch_patch_knn_multi(const float* feat, int64_t b, int64_t pstride, int m,
     const int btk = bt <= 3 ? 3 : bt;                               // pair block per thread: 16 * btk >= m rows / columns
     const size_t lds = (size_t)(m * (m + 1) + m + 16 * btk * (PK_CH + 1)) * sizeof(float);
     // m > ~110 needs more than the default 64 KiB of dynamic LDS (m = 128: 83 KiB): raised once per device
-#define SAPCU_PK(BT)                                                                                                  \
-    do {                                                                                                              \
-        static DeviceOnce once;                                                                                       \
-        if (lds > 65536) SAPCU_SET_MAX_LDS(once, (&patch_knn_kernel<BT>), 98304);                                      \
-        hipLaunchKernelGGL(patch_knn_kernel<BT>, dim3((unsigned)b), dim3(256), lds, st, feat, pstride, m, c, ld, out); \
+#define SAPCU_PK(BT, NT)                                                                                                  \
+    do {                                                                                                                  \
+        static DeviceOnce once;                                                                                           \
+        if (lds > 65536) SAPCU_SET_MAX_LDS(once, (&patch_knn_kernel<BT, NT>), 98304);                                      \
+        hipLaunchKernelGGL((patch_knn_kernel<BT, NT>), dim3((unsigned)b), dim3(NT), lds, st, feat, pstride, m, c, ld, out); \
     } while (0)
     switch (btk) {
-        case 3: SAPCU_PK(3); break;
-        case 4: SAPCU_PK(4); break;
-        case 5: SAPCU_PK(5); break;
-        case 6: SAPCU_PK(6); break;
-        case 7: SAPCU_PK(7); break;
-        default: SAPCU_PK(8); break;
+        case 3: SAPCU_PK(3, 256); break;
+        case 4: SAPCU_PK(4, 256); break;
+        case 5: SAPCU_PK(5, 512); break;
+        case 6: SAPCU_PK(6, 512); break;
+        case 7: SAPCU_PK(7, 512); break;
+        default: SAPCU_PK(8, 512); break;
     }
 #undef SAPCU_PK
     SAPCU_CHECK_LAUNCH();
