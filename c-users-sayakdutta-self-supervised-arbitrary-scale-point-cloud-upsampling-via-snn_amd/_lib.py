@@ -9,7 +9,10 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsapcu_hip.so")
+# SAPCU_LIB_PATH: another build of the same library (e.g. csrc/libsapcu_hip_exact.so, `make -C csrc exact`: every neuron update in
+# the reference's operation order); read once, at import
+LIB_PATH = os.environ.get("SAPCU_LIB_PATH") or os.path.join(_HERE, "csrc", "libsapcu_hip.so")
+EXACT_LIB_PATH = os.path.join(_HERE, "csrc", "libsapcu_hip_exact.so")
 
 FN_TAPS = ("stem", "block1", "block2", "block3", "pooled", "enc", "logits")
 FD_TAPS = ("fused0", "spikes", "knn", "pooled", "enc", "x0")

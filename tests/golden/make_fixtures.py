@@ -529,8 +529,65 @@ def scale16_fixture():
          fps_idx=idx.astype(np.int64), output=up[idx])
 
 
+def ref_vs_ref_fixture():
+    """The reference against ITSELF: the same inputs with torch.set_num_threads(1) and with 8 threads (oneDNN / OpenBLAS sum in a
+    thread-count-dependent order, so fd's feature-space neighbour searches break near-ties differently).  These figures are the
+    floor under any parity statement about free-running fd: (a) fd on the 256 patches of test_fd_forward_256_patches...: patches
+    whose neighbour sets differ, distances within 2e-4; (b) the end-to-end sphere-2048 run of e2e_upsample.npz (made with the
+    container's default 8 threads) repeated with ONE thread: fraction of refined points within 2e-4."""
+    fn, fd = _calibrated_models()
+    cloud = T.sphere_cloud(5000, 0)
+    q = T.grid_queries(256 + 200, 0)[200:]
+    idx = G.knn_bruteforce(cloud, q, 48)
+    patch = torch.from_numpy(G.gather_centre(cloud, q, idx)).float()
+    real_knn = ref_fd.knn
+    runs = {}
+    for nt in (1, 8):
+        torch.set_num_threads(nt)
+        tables = []
+
+        def rec(x, k):
+            out = real_knn(x, k)
+            tables.append(out.detach().clone())
+            return out
+
+        ref_fd.knn = rec
+        try:
+            with torch.no_grad():
+                fd.reset_states()
+                d = fd(patch)
+        finally:
+            ref_fd.knn = real_knn
+        # per forward: T x (4 xyz scales + 3 feature-space) searches; the feature-space ones of t = 0 are calls 4, 5, 6
+        runs[nt] = (npy(d), [npy(t.sort(-1)[0]) for t in tables[4:7]])
+    torch.set_num_threads(8)
+    (d1, k1), (d8, k8) = runs[1], runs[8]
+    flip_rows = [(a != b).any(-1) for a, b in zip(k1, k8)]               # [256, 48] per block
+    flip_patch = np.zeros(256, bool)
+    for f in flip_rows:
+        flip_patch |= f.any(-1)
+    fd_stats = dict(fd256_flip_patches=int(flip_patch.sum()), fd256_flip_rows=int(sum(f.sum() for f in flip_rows)),
+                    fd256_max_abs_diff=float(np.abs(d1 - d8).max()), fd256_within_2e4=float((np.abs(d1 - d8) <= 2e-4).mean()),
+                    fd256_max_abs_diff_flipfree=float(np.abs(d1 - d8)[~flip_patch].max()))
+    print("reference 1 thread vs 8 threads, fd on 256 patches:", fd_stats)
+    # (b) end to end with one thread against the committed 8-thread run
+    g = np.load(os.path.join(HERE, "e2e_upsample.npz"))
+    torch.set_num_threads(1)
+    try:
+        seeds, unfiltered, _ = _reference_upsample(fn, fd, T.sphere_cloud(2048, 0), 0.03)
+    finally:
+        torch.set_num_threads(8)
+    assert np.array_equal(seeds, g["seeds"])
+    err = np.abs(unfiltered - g["unfiltered"]).max(axis=1)
+    e2e = dict(e2e_within_2e4=float((err <= 2e-4).mean()), e2e_median=float(np.median(err)), e2e_p90=float(np.quantile(err, 0.9)),
+               e2e_points=int(err.size))
+    print("reference 1 thread vs 8 threads, sphere-2048 end to end:", e2e)
+    save("ref_vs_ref.npz", threads=np.array([1, 8]), **{k: np.array(v) for k, v in dict(fd_stats, **e2e).items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--only-ref-vs-ref", action="store_true", help="only (re)generate ref_vs_ref.npz (reference 1 thread vs 8 threads)")
     ap.add_argument("--skip-e2e", action="store_true")
     ap.add_argument("--only-fps", action="store_true", help="only (re)generate fps.npz")
     ap.add_argument("--only-train", action="store_true", help="only (re)generate neuron_train.npz")
@@ -541,6 +598,9 @@ def main():
     ap.add_argument("--only-suite", action="store_true", help="only (re)generate shape_suite.npz (BASELINE config 3 stand-in)")
     ap.add_argument("--only-scale16", action="store_true", help="only (re)generate scale16.npz (BASELINE config 4 stand-in)")
     args = ap.parse_args()
+    if args.only_ref_vs_ref:
+        ref_vs_ref_fixture()
+        return
     if args.only_suite or args.suite_shape:
         shape_suite_fixture(args.suite_shape)
         return

@@ -1187,14 +1187,15 @@ def test_training_epoch_bf16_tracks_the_f32_and_oracle_loss_curves():
     """One epoch of the trainfn.py:253-330 loop (fn_trainer.run_epoch) over a synthetic PU1K-shaped loader, AdamW + global-norm
     clipping + learning-rate warm-up as config/fn.yaml, dropout off: Trainer(use_amp=True) (bf16 GEMM operands) against the
     f32 HIP run from the same initial state, and the f32 HIP run against the oracle's f32 restatement (CPU torch autograd)
-    for the first steps.  The loss is ~1.6 on 32 patches per step.  Hard spikes make a run piecewise constant in its inputs: two
-    arithmetics agree until a spike flips, and one flipped spike moves a 32-patch loss by ~0.03.  Bars stated before measuring:
-    per-step |delta loss| <= 0.15 (bf16 vs f32), <= 0.05 (f32 HIP vs oracle).  Measured (3 runs): bf16 vs f32 0.07-0.11 — inside
-    its bar; f32 HIP vs oracle 0.08-0.09 at the very FIRST step (identical parameters, so this is spike flips between two f32
-    summation orders, not drift; the single-step fixtures avoid it by choosing data away from every threshold) — the up-front
-    0.05 was too tight for unselected data.  The HIP runs themselves vary from run to run (float atomics in the scatter-adds
-    reorder sums), so the bars in force are: per step <= 0.2, mean over the compared steps <= 0.1, and
-    the epoch-mean loss of the bf16 run within 0.06 of the f32 run's (measured 0.01-0.03).
+    for the first steps.  The loss is 1.3-1.8 on 32 patches per step.  Hard spikes make a run piecewise constant in its inputs: two
+    arithmetics agree until a spike flips, and one flipped spike moves a 32-patch loss by ~0.03
+    (test_training_first_step_difference_is_spike_flips shows the mechanism).  The loader's data (seed 7) keeps the first step
+    away from every threshold, so the comparison with the oracle is exact where it can be:
+      * f32 HIP vs oracle: steps 1 and 2 within 1e-3 (measured: equal to 4 decimals, 3 runs); step 3 — after two optimiser steps
+        the first spike flips — within 0.07 (measured 0.047, x 1.5);
+      * bf16 vs f32 HIP (different GEMM arithmetic from the first step on): per step <= 0.13 (measured max 0.057-0.085 over 3 runs,
+        x 1.5), mean <= 0.08 (measured 0.03-0.05); epoch means within 0.06 (measured 0.01-0.03).
+    (The HIP runs vary from run to run from the fourth step on: float atomics in the scatter-adds reorder sums)
     Every loss finite; parameters of the two HIP runs within 20 x lr x steps."""
     import copy
     import sapcu_amd
@@ -1202,7 +1203,7 @@ def test_training_epoch_bf16_tracks_the_f32_and_oracle_loss_curves():
     from oracle import train_path as TP
     kw = dict(k_values=[24, 18, 12], emb_dims=640, time_steps_enc=4, time_steps_dec=12, num_heads=8, use_snn_decoder=False, decoder_dropout=0.1)
     sd = T.training_state_dict(sapcu_amd.ImprovedSNNNormalEstimation(**kw).state_dict(), 3)
-    loader = lambda: fn_trainer.SyntheticPU1K(batches=6, batch_size=2, patches=16, points=12, seed=5)
+    loader = lambda: fn_trainer.SyntheticPU1K(batches=6, batch_size=2, patches=16, points=12, seed=7)
     lr, clip, warm = 1.8e-4, 0.15, 4
     curves, params, stats = {}, {}, {}
     for mode in ("f32", "bf16"):
@@ -1245,10 +1246,150 @@ def test_training_epoch_bf16_tracks_the_f32_and_oracle_loss_curves():
     print("epoch losses  f32: %s\n              bf16: %s\n            oracle: %s\n  |bf16 - f32| max %.4f, |f32 - oracle| max %.4f, parameter drift %.3g; "
           "%.1f / %.1f clouds/s (f32 / bf16)" % (np.round(curves["f32"], 4), np.round(curves["bf16"], 4), np.round(oracle_losses, 4),
                                                 max(d_bf), max(d_or), worst, stats["f32"]["clouds_per_s"], stats["bf16"]["clouds_per_s"]))
-    assert max(d_bf) <= 0.2 and float(np.mean(d_bf)) <= 0.1
-    assert max(d_or) <= 0.2 and float(np.mean(d_or)) <= 0.1
+    assert max(d_bf) <= 0.13 and float(np.mean(d_bf)) <= 0.08, d_bf
+    assert d_or[0] <= 1e-3 and d_or[1] <= 1e-3 and d_or[2] <= 0.07, d_or
     assert abs(float(np.mean(curves["bf16"])) - float(np.mean(curves["f32"]))) <= 0.06
     assert worst <= 20 * lr * 6
+
+
+def test_training_hard_spike_flips_sit_on_their_thresholds():
+    """Why the f32 HIP training forward and the oracle's f32 restatement differ at the FIRST step of the epoch test although the
+    parameters are identical: hard spikes.  Five neuron layers of that step — conv1 / snn_init and block 1's fc1 / snn1, w_qs / snn_q,
+    w_ks / snn_k, w_vs / snn_v (conv + BatchNorm(batch statistics) + LIF x 4), each fed the ORACLE's input so that a difference cannot
+    come from upstream — on the device and in the oracle: every spike that differs belongs to an element whose membrane passes
+    within 1e-5 of its threshold at some step of the SAME computation in float64 (two f32 summation orders land on either side of
+    it), and no element away from its threshold (margin > 1e-4) differs.  BatchNorm couples the patches of a batch, so downstream one
+    flipped spike moves every patch a little: the whole-model comparison is the loss bar of the epoch test; this test pins the
+    mechanism behind it."""
+    import sapcu_amd
+    from sapcu_amd import fn_trainer, testing as T, train as TR
+    from oracle import train_path as TP
+    kw = dict(k_values=[24, 18, 12], emb_dims=640, time_steps_enc=4, time_steps_dec=12, num_heads=8, use_snn_decoder=False, decoder_dropout=0.1)
+    sd = T.training_state_dict(sapcu_amd.ImprovedSNNNormalEstimation(**kw).state_dict(), 3)
+    batch = next(iter(fn_trainer.SyntheticPU1K(batches=6, batch_size=2, patches=16, points=12, seed=5)))
+    pts = batch["input"]
+    x0 = pts.reshape(-1, 3)
+    e = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+
+    def layer(x, conv, bn, snn):
+        """(device spikes, oracle spikes, float64 margin min_t |m_t - theta_t|) of one conv + BN(train) + LIF x 4 layer on input x"""
+        W = e[conv + ".weight"].reshape(e[conv + ".weight"].shape[0], -1)
+        args = [e[conv + ".bias"], e[bn + ".weight"], e[bn + ".bias"], e[snn + ".membrane_decay"], e[snn + ".threshold_adapt"],
+                e[snn + ".refractory_decay"], e[snn + ".threshold_base"]]
+        with torch.no_grad():
+            dev_spk = TR.conv_bn_lif_train(TR._pad_channels(x.to(U.dev())), TR._pad_channels(W.to(U.dev())), *[t.to(U.dev()) for t in args],
+                                           steps=4, eps=1e-5).cpu()
+            or_spk = TP.conv_bn_lif_train(x, W, *args, steps=4, eps=1e-5)
+            y = x.double() @ W.double().t() + args[0].double()                  # the same layer in float64 (fn/snn_coder.py:125-151)
+            z = (y - y.mean(0)) / torch.sqrt(y.var(0, unbiased=False) + 1e-5) * args[1].double() + args[2].double()
+            decay, adapt, rdecay = args[3].double().clamp(0.1, 0.99), args[4].double().clamp(0.001, 0.1), args[5].double().clamp(0.1, 0.95)
+            th0 = args[6].double()
+            m, th, r, inp = torch.zeros_like(z), th0.expand_as(z).clone(), torch.zeros_like(z), z
+            margin = torch.full_like(z, float("inf"))
+            for _ in range(4):
+                inp = inp * (r <= 0).double()
+                m = m * decay * (1 - r) + inp
+                margin = torch.minimum(margin, (m - th).abs())
+                sp = (m - th > 0).double()
+                m = m * (1 - sp)
+                r = r * rdecay + sp
+                th = th0 + ((th + adapt * sp) - th0) * 0.95
+                inp = sp
+        return dev_spk, or_spk, margin
+
+    total_flips = 0
+    feat = None
+    for name, conv, bn, snn, src in (("conv1", "conv1.0", "conv1.1", "snn_init", "x0"), ("trans1.fc1", "trans1.fc1.0", "trans1.fc1.1", "trans1.snn1", "feat"),
+                                      ("trans1.w_qs", "trans1.w_qs.0", "trans1.w_qs.1", "trans1.snn_q", "x1"),
+                                      ("trans1.w_ks", "trans1.w_ks.0", "trans1.w_ks.1", "trans1.snn_k", "x1"),
+                                      ("trans1.w_vs", "trans1.w_vs.0", "trans1.w_vs.1", "trans1.snn_v", "x1")):
+        x = {"x0": x0, "feat": feat, "x1": locals().get("x1")}[src]
+        dev_spk, or_spk, margin = layer(x, conv, bn, snn)
+        if name == "conv1":
+            feat = or_spk                                                       # teacher forcing: the oracle's activations feed the next layer
+        if name == "trans1.fc1":
+            x1 = or_spk
+        assert set(np.unique(dev_spk.numpy())) <= {0.0, 1.0} and dev_spk.shape == or_spk.shape
+        flip = dev_spk != or_spk
+        total_flips += int(flip.sum())
+        print("%-12s %5d of %7d spikes differ (device vs oracle, same input); float64 threshold margin of the differing ones: max %.3g; "
+              "elements within 1e-5 of a threshold: %d" % (name, int(flip.sum()), flip.numel(), float(margin[flip].max()) if flip.any() else 0.0,
+                                                          int((margin < 1e-5).sum())))
+        assert float(flip.float().mean()) <= 0.01, name
+        assert not bool(flip[margin > 1e-4].any()), name + ": a spike away from its threshold differs — an arithmetic defect, not a rounding flip"
+    print("differing spikes over the five teacher-forced layers: %d" % total_flips)
+
+
+def test_training_first_step_difference_is_spike_flips():
+    """The whole fn training forward (identical parameters, first batch of three loaders) on the device, in the oracle (f32) and in
+    the oracle run in float64:
+      * seed 7 (the epoch test's data): all three agree on every patch to 1e-4 (measured 6e-6) — the device forward has no
+        arithmetic difference from the reference's forward where no spike sits on a threshold;
+      * seed 5: the oracle disagrees WITH ITSELF between f32 and f64 on most patches (measured 31 of 32 beyond 1e-3, normals up to
+        0.55 apart): that batch has spikes on their thresholds, and BatchNorm's batch statistics spread one flip over every patch —
+        the device differs from the f32 oracle the same way (the 0.08 first-step loss gap round 2's epoch test saw on this data);
+      * seed 6: the oracle's two precisions agree, the device lands a few spikes on the other side (its f32 sums run in another
+        order than torch's): normals within 0.05, loss within 0.005 (measured 0.023 / 0.0007)."""
+    import sapcu_amd
+    from sapcu_amd import fn_trainer, testing as T, train as TR
+    from oracle import train_path as TP
+    kw = dict(k_values=[24, 18, 12], emb_dims=640, time_steps_enc=4, time_steps_dec=12, num_heads=8, use_snn_decoder=False, decoder_dropout=0.1)
+    sd = T.training_state_dict(sapcu_amd.ImprovedSNNNormalEstimation(**kw).state_dict(), 3)
+    names = [n for n, _ in sapcu_amd.ImprovedSNNNormalEstimation(**kw).named_parameters()]
+    res = {}
+    for seed in (7, 5, 6):
+        batch = next(iter(fn_trainer.SyntheticPU1K(batches=6, batch_size=2, patches=16, points=12, seed=seed)))
+        pts = batch["input"]
+        B, NP, M, _ = pts.shape
+        flat = pts.reshape(B * NP, M, 3)
+        dist = ((flat[:, :, None, :] - flat[:, None, :, :]) ** 2).sum(-1)
+        knn = [dist.topk(min(k, M), dim=-1, largest=False)[1] for k in (24, 18, 12)]
+        with torch.no_grad():
+            n32 = TP.fn_train_forward({n: sd[n] for n in names}, flat, knn)
+            n64 = TP.fn_train_forward({n: sd[n].double() for n in names}, flat.double(), knn).float()
+            nd = TR.fn_train_forward({n: v.to(U.dev()) for n, v in sd.items()}, flat.to(U.dev()),
+                                     knn=[k.to(torch.int32).to(U.dev()) for k in knn]).cpu()
+        gt = torch.nn.functional.normalize(batch["normal"], dim=-1)
+        loss = {nm: float(TP.angular_loss_with_consistency(torch.nn.functional.normalize(v.view(B, NP, 3), dim=-1), gt, pts.mean(dim=2))[0])
+                for nm, v in (("dev", nd), ("o32", n32), ("o64", n64))}
+        per = lambda a, b: (a - b).abs().max(1)[0]
+        res[seed] = dict(dev_o32=per(nd, n32), o32_o64=per(n32, n64), loss=loss)
+        print("seed %d: |dev - oracle32| max %.3g (%d of %d patches > 1e-3); |oracle32 - oracle64| max %.3g (%d patches > 1e-3); losses %s" % (
+            seed, float(res[seed]["dev_o32"].max()), int((res[seed]["dev_o32"] > 1e-3).sum()), B * NP, float(res[seed]["o32_o64"].max()),
+            int((res[seed]["o32_o64"] > 1e-3).sum()), {k: round(v, 5) for k, v in loss.items()}))
+    assert float(res[7]["dev_o32"].max()) <= 1e-4 and float(res[7]["o32_o64"].max()) <= 1e-4
+    assert abs(res[7]["loss"]["dev"] - res[7]["loss"]["o32"]) <= 1e-4
+    assert int((res[5]["o32_o64"] > 1e-3).sum()) >= 16, "seed 5 was chosen because the oracle's own precisions disagree on it"
+    assert float(res[6]["o32_o64"].max()) <= 1e-4 and float(res[6]["dev_o32"].max()) <= 0.05
+    assert abs(res[6]["loss"]["dev"] - res[6]["loss"]["o32"]) <= 0.005
+
+
+def test_training_epoch_of_50_batches_at_the_reference_batch_shape():
+    """BASELINE config 5 at the reference's own batch shape (config/fn.yaml: 4 clouds x 64 patches x 12 points), 50 batches of the
+    trainfn.py:253-330 loop on bf16 GEMM operands and on f32: no skipped batch, every loss finite and in the band the reference
+    reports for this loss (Observations.md: 1.58-1.61), epoch means of the two arithmetics within 0.06, parameters moved."""
+    import copy
+    import sapcu_amd
+    from sapcu_amd import fn_trainer, testing as T
+    kw = dict(k_values=[24, 18, 12], emb_dims=640, time_steps_enc=6, time_steps_dec=12, num_heads=8, use_snn_decoder=False, decoder_dropout=0.1)
+    sd = T.training_state_dict(sapcu_amd.ImprovedSNNNormalEstimation(**kw).state_dict(), 3)
+    lr, means = 1.8e-4, {}
+    for mode in ("f32", "bf16"):
+        model = sapcu_amd.ImprovedSNNNormalEstimation(**kw)
+        model.load_state_dict(copy.deepcopy(sd), strict=True)
+        model.cuda()
+        opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=1e-4, betas=(0.9, 0.999))
+        tr = fn_trainer.Trainer(model, opt, device=torch.device("cuda"), use_amp=(mode == "bf16"), grad_clip=0.15, grad_clip_type="norm")
+        loader = fn_trainer.SyntheticPU1K(batches=50, batch_size=4, patches=64, points=12, seed=11)
+        it, losses, st = fn_trainer.run_epoch(tr, loader, lr=lr, warmup_steps=20, warmup_factor=0.01, state_reset_freq=25)
+        assert it == 50 and len(losses) == 50 and st["skipped"] == 0 and all(np.isfinite(losses)), (mode, losses)
+        assert 1.2 <= min(losses) and max(losses) <= 2.0, (mode, min(losses), max(losses))
+        moved = max(float((q.detach().cpu() - sd[n]).abs().max()) for n, q in model.named_parameters())
+        assert 0 < moved <= 50 * lr * 4, moved
+        means[mode] = float(np.mean(losses))
+        print("%s: 50 batches of 4 x 64 x 12 in %.2f s = %.0f clouds/s, loss first %.4f mean %.4f last %.4f" % (
+            mode, st["seconds"], st["clouds_per_s"], losses[0], means[mode], losses[-1]))
+    assert abs(means["f32"] - means["bf16"]) <= 0.06, means
 
 
 @pytest.mark.parametrize("r,k,n,lif,csplit", [(1024, 128, 128, 0, 0), (2048 + 77, 256, 256, 1, 1), (4096 + 3, 512, 512, 0, 0), (3000, 512, 512, 1, 0),
@@ -1472,6 +1613,22 @@ def test_fused_fd_encoder_equals_the_per_stage_path_bit_for_bit(weights, monkeyp
         assert torch.equal(fd(patch), da), tag + ": tap-free call"
         assert torch.equal(fd(patch, knn_force=tb["knn"]), db), tag + ": forced tables"
     assert fd.gate_violations() == 0 and fd_stage.gate_violations() == 0 and fd.gemm_mode() == (True, 0)
+
+
+def test_exact_operation_order_build():
+    """csrc/libsapcu_hip_exact.so (make exact: -DSAPCU_LIF_EXACT_ORDER, every neuron update in the reference's operation order —
+    the variant INTEGRATION.md advertises) in a child process (the library is chosen at import: SAPCU_LIB_PATH): neuron unit
+    against the reference vectors (1e-6), fn / fd against the oracle (1e-4), fused fd encoder == per-stage kernels bit for bit."""
+    import subprocess
+    import sys
+    from sapcu_amd import _lib
+    if not os.path.exists(_lib.EXACT_LIB_PATH):
+        pytest.fail("%s is not built (make -C csrc exact; __graft_entry__.build() does)" % _lib.EXACT_LIB_PATH)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SAPCU_LIB_PATH=_lib.EXACT_LIB_PATH)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "exact_order_check.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "EXACT_ORDER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    print(r.stdout.strip().splitlines()[-1])
 
 
 def test_models_on_the_big_tile_kernel_equal_the_ring_kernel_bit_for_bit(weights, monkeypatch):

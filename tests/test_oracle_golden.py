@@ -367,3 +367,14 @@ def test_fn_trainer_step_matches_reference():
     coef = min(1.0, float(g["grad_clip"]) / (float(total) + 1e-6))
     new = {n: (p[n].detach() - float(g["lr"]) * coef * gr) for n, gr in zip(names, grads)}
     check_fn_trainer_updates(g, new, {n: p[n] for n in names}, names, 2e-2, 5e-5)
+
+
+def test_reference_against_itself_fixture():
+    """tests/golden/ref_vs_ref.npz (make_fixtures.py --only-ref-vs-ref): the REAL reference run with 1 thread and with 8 threads —
+    the floor under every free-running fd parity figure quoted in DESIGN.md section 2 and profiles/r03_flip_sources.md.  fd alone is
+    bit-stable across thread counts on the build host (0 flipped neighbour sets on 256 patches); end to end, fn's thread-dependent
+    sums (~6e-6 on the normals) rotate the patches by enough to flip fd neighbours: 96.8 % of the refined points within 2e-4."""
+    g = golden("ref_vs_ref.npz")
+    assert list(g["threads"]) == [1, 8]
+    assert int(g["fd256_flip_patches"]) == 0 and float(g["fd256_max_abs_diff"]) == 0.0
+    assert int(g["e2e_points"]) == 901 and 0.9 <= float(g["e2e_within_2e4"]) < 1.0 and float(g["e2e_median"]) < 1e-5
