@@ -170,8 +170,18 @@ __device__ __forceinline__ f32x2 pk_clamp10(f32x2 d) { return f32x2{clampf(d.x, 
 
 // two spikes at once; clamp, exp2 and rcp are per lane.  Element-wise the arithmetic is exactly soft_spike()'s
 // (exact-order build) or its fused form (default).
+//
+// The reference clamps x to +-10 before the two exponentials.  The default (fused) build leaves the clamp out — two of a
+// pair-step's 20 instructions in kernels that are bound by VALU issue: beyond |x| = 10 the sigmoid term is 0 or 1 in f32
+// either way (exp2(+-144) is inf / below 2^-126 next to 1), and the Gaussian term is 0.1995 exp(-50) = 3.9e-23 clamped
+// against something smaller un-clamped: the spike moves by < 4e-23 absolute, the split-f16 operand made from it not at all
+// (below half the smallest f16 subnormal).  x = +-inf gives 0 / 1 + 0 without the clamp as well (x*x = inf -> exp2(-inf) = 0).
 __device__ __forceinline__ f32x2 soft_spike2(f32x2 d) {
+#ifdef SAPCU_LIF_EXACT_ORDER
     const f32x2 x = pk_clamp10(d);
+#else
+    const f32x2 x = d;
+#endif
     const f32x2 b = x * -14.426950408889634074f;
     f32x2 g, e, s;
 #ifdef SAPCU_LIF_EXACT_ORDER
@@ -343,6 +353,66 @@ struct NeuronStep2 {
             a = f32x2{clampf(a.x, -5.0f, 5.0f), clampf(a.y, -5.0f, 5.0f)} * 1.4426950408889634074f;
             const f32x2 e = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
             mm = pk_fma(e, f32x2{p.dT, p.dT}, mm);
+        }
+        const f32x2 sp = soft_spike2(mm - s.th);
+        s.m = pk_fma(-mm, sp, mm);
+        s.r = first ? sp : pk_fma(s.r, rdecay, sp);
+        s.th = pk_fma(s.th, f32x2{0.95f, 0.95f}, pk_fma(sp, a95, thc));
+        return sp;
+#endif
+    }
+};
+
+// NeuronStep2 for a pair of DIFFERENT channels (lane .x = channel a, .y = channel b of one point): the same arithmetic per lane, the
+// parameters as 2-vectors.  (fd's per-stage EdgeConv + neuron kernel walks four consecutive channels per thread.)
+template <bool EIF>
+struct NeuronStep2V {
+    NeuronP pa, pb;
+    f32x2 decay, rdecay, a95, thc, theta0, dT, rh, inv_dT;
+    NeuronS2 s;
+#ifdef SAPCU_LIF_EXACT_ORDER
+    NeuronS sx, sy;
+#endif
+    __device__ __forceinline__ NeuronStep2V(const NeuronP& a, const NeuronP& b) : pa(a), pb(b) {
+        decay = f32x2{a.decay, b.decay};
+        rdecay = f32x2{a.rdecay, b.rdecay};
+        a95 = f32x2{a.adapt * 0.95f, b.adapt * 0.95f};
+        thc = f32x2{a.theta0 * 0.05f, b.theta0 * 0.05f};
+        theta0 = f32x2{a.theta0, b.theta0};
+        dT = f32x2{a.dT, b.dT};
+        rh = f32x2{a.rh, b.rh};
+        inv_dT = EIF ? f32x2{__fdiv_rn(1.0f, __fadd_rn(a.dT, 1e-6f)), __fdiv_rn(1.0f, __fadd_rn(b.dT, 1e-6f))} : f32x2{0.f, 0.f};
+        s.m = f32x2{0.f, 0.f};
+        s.r = f32x2{0.f, 0.f};
+        s.th = theta0;
+#ifdef SAPCU_LIF_EXACT_ORDER
+        sx = neuron_init(a);
+        sy = neuron_init(b);
+#endif
+    }
+    __device__ __forceinline__ bool gate_open() const {
+#ifdef SAPCU_LIF_EXACT_ORDER
+        return sx.r <= 0.f || sy.r <= 0.f;
+#else
+        return s.r.x <= 0.f || s.r.y <= 0.f;
+#endif
+    }
+    __device__ __forceinline__ f32x2 step(f32x2 x, bool first) {
+#ifdef SAPCU_LIF_EXACT_ORDER
+        return f32x2{neuron_step<EIF>(x.x, sx, pa), neuron_step<EIF>(x.y, sy, pb)};
+#else
+        f32x2 mm;
+        if (first) {
+            mm = x;
+        } else {
+            const f32x2 md = s.m * decay;
+            mm = pk_fma(-md, s.r, md);
+        }
+        if (EIF) {
+            f32x2 a = (s.m - rh) * inv_dT;
+            a = f32x2{clampf(a.x, -5.0f, 5.0f), clampf(a.y, -5.0f, 5.0f)} * 1.4426950408889634074f;
+            const f32x2 e = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+            mm = pk_fma(e, dT, mm);
         }
         const f32x2 sp = soft_spike2(mm - s.th);
         s.m = pk_fma(-mm, sp, mm);

@@ -909,86 +909,80 @@ __global__ __launch_bounds__(256) void fd_neuron_kernel(const float* __restrict_
     }
 }
 
-// MODE 1 restructured: one workgroup per (patch, 128-channel chunk).  The patch's A' rows for the chunk are
-// staged in LDS once (m x 128 floats), so the k-neighbour max reads LDS instead of k gathers from L2 per
-// element (k = 32: 32x less L2 traffic — the old form was bound by it: 6.4 GB per launch for C = 512).
+// MODE 1 restructured: one workgroup per (patch, 128-channel chunk).  The patch's A' rows for the chunk are staged in LDS once
+// (m x 128 floats, + the neighbour table as bytes), so the k-neighbour max reads LDS instead of k gathers from L2 per element.
+// Round 3: a thread owns FOUR consecutive channels of a point — one 16-byte LDS read per neighbour serves four channels (a
+// thread per channel spends three instructions per element and neighbour; at 100-point patches the kernel was 3.5 x its
+// 48-point time for 2.1 x the rows) —, 32 channel quads x 8 point slots per workgroup, the two (channel, channel) pairs of a
+// point as packed neuron chains (NeuronStep2V), 8 / 16-byte stores.  Same operations per element as before.
 constexpr int FDE_CH = 128;
-constexpr int FDE_NH = 2;    // threads per channel: the patch's 8-point groups alternate between them (twice the waves over the same LDS tile)
+constexpr int FDE_SLOTS = 8;    // point slots: 32 quads x 8 = 256 threads
 
 template <bool EIF>
-__global__ __launch_bounds__(FDE_CH * FDE_NH) void fd_edge_neuron_kernel(const float* __restrict__ in, int ldi,
+__global__ __launch_bounds__(256) void fd_edge_neuron_kernel(const float* __restrict__ in, int ldi,
                                                                 const int32_t* __restrict__ idx, int kk, int m,
                                                                 const float* __restrict__ shift, int64_t pts, int C,
                                                                 const float* __restrict__ prm, int T,
                                                                 float* __restrict__ spk, int ldo, int coff,
                                                                 int* __restrict__ gate_violations, float* __restrict__ spk_split) {
-    extern __shared__ float sA[];                       // [m][FDE_CH]
-    const int tx = threadIdx.x % FDE_CH;
-    const int hf = __builtin_amdgcn_readfirstlane(threadIdx.x / FDE_CH);     // wave-uniform: the neighbour lists stay scalar loads
-    const int c = blockIdx.y * FDE_CH + tx;
+    extern __shared__ float sA[];                       // [m][FDE_CH] f32, then the neighbour table [m][kk] as bytes
+    unsigned char* sI = reinterpret_cast<unsigned char*>(sA + (size_t)m * FDE_CH);
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.y * FDE_CH;
     const int64_t row0 = (int64_t)blockIdx.x * m;
-    const bool live = c < C;
-    // Every global load of this kernel misses the caches (the [pts, 2C] operand is 0.8 GB at C = 512): they are issued in
-    // batches of 8 with nothing waiting in between — the one-load-one-wait form spent 3/4 of the kernel in HBM latency.
-    // Dead lanes (c >= C) replay the last channel so that the loads stay unconditional.
-    const float* col = in + row0 * ldi + (live ? c : C - 1);
-    for (int i0 = 8 * hf; i0 < m; i0 += 8 * FDE_NH) {
-        float t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = col[(int64_t)min(i0 + u, m - 1) * ldi];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (i0 + u < m) sA[(i0 + u) * FDE_CH + tx] = t[u];
+    // staging: 16-byte loads of the [pts, 2C] operand's first half (C % 4 == 0; channels >= C of the last chunk: zeros)
+    for (int e = tid; e < m * (FDE_CH / 4); e += 256) {
+        const int i = e / (FDE_CH / 4), q = e % (FDE_CH / 4);
+        const int c = c0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C) v = *reinterpret_cast<const float4*>(in + (row0 + i) * ldi + c);
+        *reinterpret_cast<float4*>(sA + i * FDE_CH + 4 * q) = v;
     }
+    for (int e = tid; e < m * kk; e += 256) sI[e] = (unsigned char)idx[row0 * kk + e];
     __syncthreads();
-    if (!live) return;
-    const NeuronP p = EIF ? load_eif(prm, C, c) : load_lif(prm, C, c);
-    const float sh = shift[c];
-    const float* xcol = col + C;                        // the x_i term of the factored EdgeConv
-    float xn[8];
+    const int q4 = tid & 31, slot = tid >> 5;
+    const int c = c0 + 4 * q4;
+    if (c >= C) return;
+    NeuronP p[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) xn[u] = xcol[(int64_t)min(8 * hf + u, m - 1) * ldi];
-    for (int g = 8 * hf; g < m; g += 8 * FDE_NH) {
-        float xc[8];
+    for (int u = 0; u < 4; ++u) p[u] = EIF ? load_eif(prm, C, c + u) : load_lif(prm, C, c + u);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+    const float* tq = sA + 4 * q4;
+    for (int i = slot; i < m; i += FDE_SLOTS) {
+        const int64_t r = row0 + i;
+        const float4 xb = *reinterpret_cast<const float4*>(in + r * ldi + C + c);          // the x_i term of the factored EdgeConv
+        const unsigned char* ir = sI + i * kk;
+        float4 mx = make_float4(-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf());
+        int j = 0;
+        for (; j + 4 <= kk; j += 4) {
+            float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) xc[u] = xn[u];
-        if (g + 8 * FDE_NH < m) {                       // next group's x_i terms: in flight during this group's four passes
-#pragma unroll
-            for (int u = 0; u < 8; ++u) xn[u] = xcol[(int64_t)min(g + 8 * FDE_NH + u, m - 1) * ldi];
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(tq + ir[j + u] * FDE_CH);
+            mx.x = fmaxf(fmaxf(mx.x, v[0].x), fmaxf(v[1].x, fmaxf(v[2].x, v[3].x)));
+            mx.y = fmaxf(fmaxf(mx.y, v[0].y), fmaxf(v[1].y, fmaxf(v[2].y, v[3].y)));
+            mx.z = fmaxf(fmaxf(mx.z, v[0].z), fmaxf(v[1].z, fmaxf(v[2].z, v[3].z)));
+            mx.w = fmaxf(fmaxf(mx.w, v[0].w), fmaxf(v[1].w, fmaxf(v[2].w, v[3].w)));
         }
-        // two points per pass: their neuron chains share every packed instruction (an odd m repeats the last point)
-#pragma unroll
-        for (int u = 0; u < 8; u += 2) {
-            const int i = g + u;
-            if (i < m) {
-                const bool two = i + 1 < m;
-                const int i1 = two ? i + 1 : i;
-                const int64_t ra = row0 + i, rb = row0 + i1;
-                const int32_t* ia = idx + ra * kk;
-                const int32_t* ib = idx + rb * kk;
-                float ma = -__builtin_huge_valf(), mb = ma;
-                for (int j = 0; j < kk; ++j) {
-                    ma = fmaxf(ma, sA[ia[j] * FDE_CH + tx]);
-                    mb = fmaxf(mb, sA[ib[j] * FDE_CH + tx]);
-                }
-                const f32x2 pre = f32x2{lrelu02(__fadd_rn(__fsub_rn(ma, xc[u]), sh)),
-                                        lrelu02(__fadd_rn(__fsub_rn(mb, two ? xc[u + 1] : xc[u]), sh))};
-                NeuronStep2<EIF> ns(p);
-                for (int step = 0; step < T; ++step) {
-                    if (step > 0 && ns.gate_open()) atomicAdd(gate_violations, 1);
-                    const f32x2 sp = ns.step(step == 0 ? pre : f32x2{0.f, 0.f}, step == 0);
-                    if (spk_split) {                             // (see fd_neuron_kernel)
-                        store_split(spk_split, (int64_t)step * pts + ra, ldo, coff + c, sp.x);
-                        if (two) store_split(spk_split, (int64_t)step * pts + rb, ldo, coff + c, sp.y);
-                        if (step == 0) {
-                            spk[ra * ldo + coff + c] = sp.x;
-                            if (two) spk[rb * ldo + coff + c] = sp.y;
-                        }
-                    } else {
-                        spk[((int64_t)step * pts + ra) * ldo + coff + c] = sp.x;
-                        if (two) spk[((int64_t)step * pts + rb) * ldo + coff + c] = sp.y;
-                    }
-                }
+        for (; j < kk; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(tq + ir[j] * FDE_CH);
+            mx.x = fmaxf(mx.x, v.x);
+            mx.y = fmaxf(mx.y, v.y);
+            mx.z = fmaxf(mx.z, v.z);
+            mx.w = fmaxf(mx.w, v.w);
+        }
+        const f32x2 pre0 = f32x2{lrelu02(__fadd_rn(__fsub_rn(mx.x, xb.x), sh.x)), lrelu02(__fadd_rn(__fsub_rn(mx.y, xb.y), sh.y))};
+        const f32x2 pre1 = f32x2{lrelu02(__fadd_rn(__fsub_rn(mx.z, xb.z), sh.z)), lrelu02(__fadd_rn(__fsub_rn(mx.w, xb.w), sh.w))};
+        NeuronStep2V<EIF> n0(p[0], p[1]), n1(p[2], p[3]);
+        for (int step = 0; step < T; ++step) {
+            if (step > 0 && (n0.gate_open() || n1.gate_open())) atomicAdd(gate_violations, 1);
+            const f32x2 z = f32x2{0.f, 0.f};
+            const f32x2 s0 = n0.step(step == 0 ? pre0 : z, step == 0), s1 = n1.step(step == 0 ? pre1 : z, step == 0);
+            const float sv[4] = {s0.x, s0.y, s1.x, s1.y};
+            if (spk_split) {                             // (see fd_neuron_kernel)
+                store_split4<true>(spk_split, (int64_t)step * pts + r, ldo, coff + c, ldo, sv);
+                if (step == 0) *reinterpret_cast<float4*>(spk + r * ldo + coff + c) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+            } else {
+                *reinterpret_cast<float4*>(spk + ((int64_t)step * pts + r) * ldo + coff + c) = make_float4(sv[0], sv[1], sv[2], sv[3]);
             }
         }
     }
@@ -1022,14 +1016,16 @@ int launch_fd_neuron(bool eif, int mode, const float* in, int ldi, const int32_t
                      const float* shift, int64_t pts, int C, const float* prm, int T, float* spk, int ldo, int coff,
                      float* pre_out, int* gate_violations, hipStream_t st, float* spk_split) {
     if (pts == 0) return SAPCU_OK;
-    if (mode == 1 && pre_out == nullptr && pts % m == 0) {
+    // the 16-byte form needs 4-aligned channel geometry (every tensor of the models has it) and byte-sized neighbour indices
+    if (mode == 1 && pre_out == nullptr && pts % m == 0 && C % 4 == 0 && ldi % 4 == 0 && ldo % 32 == 0 && coff % 4 == 0 && m <= 256 &&
+        (((uintptr_t)in | (uintptr_t)spk | (uintptr_t)shift) & 15) == 0) {
         const dim3 g2((unsigned)(pts / m), (unsigned)((C + FDE_CH - 1) / FDE_CH));
-        const size_t lds = (size_t)m * FDE_CH * sizeof(float);
+        const size_t lds = (size_t)m * FDE_CH * sizeof(float) + (((size_t)m * kk + 15) & ~(size_t)15);
         if (eif)
-            hipLaunchKernelGGL(fd_edge_neuron_kernel<true>, g2, dim3(FDE_CH * FDE_NH), lds, st, in, ldi, idx, kk, m, shift, pts, C, prm,
+            hipLaunchKernelGGL(fd_edge_neuron_kernel<true>, g2, dim3(256), lds, st, in, ldi, idx, kk, m, shift, pts, C, prm,
                                T, spk, ldo, coff, gate_violations, spk_split);
         else
-            hipLaunchKernelGGL(fd_edge_neuron_kernel<false>, g2, dim3(FDE_CH * FDE_NH), lds, st, in, ldi, idx, kk, m, shift, pts, C,
+            hipLaunchKernelGGL(fd_edge_neuron_kernel<false>, g2, dim3(256), lds, st, in, ldi, idx, kk, m, shift, pts, C,
                                prm, T, spk, ldo, coff, gate_violations, spk_split);
         SAPCU_CHECK_LAUNCH();
         return SAPCU_OK;
