@@ -98,7 +98,7 @@ def recorded_pmc():
 
 # algorithmic HBM bytes per query = 2 x 576 B patches in + 16 B out + ~410 B outer-kNN share
 ALGO_BYTES_PER_QUERY = 2 * 576 + 16 + 410
-NEURON_FLOOR_NS_PER_1000 = 1.58       # profiles/micro/lif_rate.hip on MI355X: the 4-step LIF loop alone, 2 waves per SIMD
+NEURON_FLOOR_NS_PER_1000 = 1.51       # profiles/micro/lif_rate.hip on MI355X: the 4-step LIF loop alone, 2 waves per SIMD
 
 
 def roofline_leg(dev, reps=5):
@@ -180,7 +180,7 @@ def roofline_leg(dev, reps=5):
             "algorithmic_bytes_per_launch": algo_bytes,
             "valu": {"neuron_elements_per_launch": elems, "ns_per_1000_elements": round(ns_per_1000, 3),
                      "floor_ns_per_1000_elements": NEURON_FLOOR_NS_PER_1000, "frac_of_neuron_floor": round(NEURON_FLOOR_NS_PER_1000 / ns_per_1000, 4),
-                     "note": "the kernel's physical bound is VALU issue of the 4-step neuron loops (13 packed + 2 clamp + 6 transcendental "
+                     "note": "the kernel's physical bound is VALU issue of the 4-step neuron loops (12 packed + 6 transcendental "
                              "instructions per pair and step); floor = the bare loop, profiles/micro/lif_rate.hip"},
             "step_traffic": step_traffic}
 

@@ -177,7 +177,7 @@ __device__ __forceinline__ f32x2 pk_clamp10(f32x2 d) { return f32x2{clampf(d.x, 
 // against something smaller un-clamped: the spike moves by < 4e-23 absolute, the split-f16 operand made from it not at all
 // (below half the smallest f16 subnormal).  x = +-inf gives 0 / 1 + 0 without the clamp as well (x*x = inf -> exp2(-inf) = 0).
 __device__ __forceinline__ f32x2 soft_spike2(f32x2 d) {
-#ifdef SAPCU_LIF_EXACT_ORDER
+#if defined(SAPCU_LIF_EXACT_ORDER) || defined(SAPCU_SPIKE_CLAMP)     // (the second macro: same-box A/B builds, profiles/step_ab.py)
     const f32x2 x = pk_clamp10(d);
 #else
     const f32x2 x = d;

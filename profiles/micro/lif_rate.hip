@@ -7,7 +7,11 @@
 using namespace sapcu;
 
 __device__ __forceinline__ float spike1(float d) {
+#ifdef SAPCU_LIF_EXACT_ORDER
     const float x = clampf(d, -10.0f, 10.0f);
+#else
+    const float x = d;                                  // (as common.h soft_spike2 in the default build)
+#endif
     const float b = x * -14.426950408889634074f;
     const float a = __fmaf_rn(x * x, -0.72134752044448170368f, -2.3257480647361593f);
     const float g = __builtin_amdgcn_exp2f(a);
