@@ -98,6 +98,19 @@ __device__ __forceinline__ float half_bcast(float x, int hr) {
     return __uint_as_float(hr ? r[1] : r[0]);
 }
 
+// lanes 0-31 get the lane half `ha` of a, lanes 32-63 the lane half `hb` of b (ha, hb compile-time; h = this lane's half)
+__device__ __forceinline__ float half_pick(float a, int ha, float b, int hb, int h) {
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    if (ha == 0 && hb == 1) return h ? b : a;
+    if (ha == hb) {
+        const auto r = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);       // r[0] = [a.lo, b.lo], r[1] = [a.hi, b.hi]
+        return __uint_as_float(ha ? r[1] : r[0]);
+    }
+    const unsigned s = h ? ua : ub;                                                  // [b.lo, a.hi]
+    const auto r = __builtin_amdgcn_permlane32_swap(s, s, false, false);             // [b.lo, b.lo], [a.hi, a.hi]
+    return __uint_as_float(h ? r[0] : r[1]);
+}
+
 template <int CB>
 struct ChainLane {       // per-lane constants of the epilogues
     int r32, h;
@@ -396,17 +409,27 @@ __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? 2 : 1)) void fn
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     acc[i * CB + j][e] = __fmul_rn(__fmaf_rn(acc[i * CB + j][e], 0.0625f, b3), a.inv_sqrt_hd);
-            // per point: its kk rows alternate between the lane halves in quads; both halves fetch the other's values and
-            // run the same neighbour-ordered sums (fn_softmax_agg_kernel's operation order)
+            // per point: its kk rows alternate between the lane halves in quads.  Points are taken in PAIRS: lane half 0 runs the
+            // neighbour-ordered sums (fn_softmax_agg_kernel's operation order) of point pp, half 1 those of point pp + 1, each
+            // half fetching its point's values from whichever half holds them (an odd last point: both halves, as before r3 —
+            // every point used to be summed by both halves).
 #pragma unroll
-            for (int p = 0; p < PPG; ++p) {
+            for (int pp = 0; pp < PPG; pp += 2) {
+                const bool pair = pp + 1 < PPG;            // compile-time after unrolling
                 float xs[KK], ts[KK];
 #pragma unroll
                 for (int jj = 0; jj < KK; ++jj) {
-                    const int r = p * KK + jj, i = r >> 5, rr = r & 31;
+                    const int r = pp * KK + jj, i = r >> 5, rr = r & 31;
                     const int e = ((rr >> 3) << 2) | (rr & 3), hr = (rr >> 2) & 1;
-                    xs[jj] = half_bcast(acc[i * CB + j][e], hr);
-                    ts[jj] = half_bcast(pe[i * CB + j][e], hr);
+                    if (pair) {
+                        const int r1 = r + KK, i1 = r1 >> 5, rr1 = r1 & 31;
+                        const int e1 = ((rr1 >> 3) << 2) | (rr1 & 3), hr1 = (rr1 >> 2) & 1;
+                        xs[jj] = half_pick(acc[i * CB + j][e], hr, acc[i1 * CB + j][e1], hr1, L.h);
+                        ts[jj] = half_pick(pe[i * CB + j][e], hr, pe[i1 * CB + j][e1], hr1, L.h);
+                    } else {
+                        xs[jj] = half_bcast(acc[i * CB + j][e], hr);
+                        ts[jj] = half_bcast(pe[i * CB + j][e], hr);
+                    }
                 }
                 float mx = -__builtin_huge_valf();
 #pragma unroll
@@ -421,7 +444,8 @@ __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? 2 : 1)) void fn
                 float out = 0.f;
 #pragma unroll
                 for (int jj = 0; jj < KK; ++jj) out = __fmaf_rn(__fmul_rn(xs[jj], inv_den), ts[jj], out);
-                if (p < npts && (p & 1) == L.h) {          // both halves hold the result: each stores every other point
+                const int p = pair ? pp + L.h : pp;        // this half's point
+                if (p < npts && (pair || L.h == 0)) {
                     const int64_t pt = pt0 + p;
                     if (a.res_split) chain_store_split_nt(a.res, pt, D, L.col[j], out);
                     else __builtin_nontemporal_store(out, &a.res[pt * D + L.col[j]]);
