@@ -44,7 +44,15 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // the weight ring refilled in place and unconditionally (exact wait counts in the rolled k loop) 17.2; 8 waves, same loop 16.6;
 // 8 waves, epilogue units of 8 elements 16.3 (before the wait counts were exact the 8-wave form lost: 18.4 against 17.6).
 // d = 256: fully unrolled k loop 8.27, rolled 8.10.  d = 128: 128-row groups (5 points + 8 idle rows), two workgroups per CU,
-// unrolled loop 4.64; 96-row groups, three per CU (168 registers, 23 of them spilled), rolled loop 4.42; two per CU, no spill: 4.55 (r3).
+// unrolled loop 4.64; 96-row groups, three per CU (168 registers, 23 of them spilled), rolled loop 4.42; two per CU, no spill: 4.55;
+// round 3, once the t = v_j + pe adds stopped being sunk to the end of the kernel (see the first epilogue): 144 / 182 / 198
+// registers (d = 128 / 256 / 512), no scratch anywhere, three per CU again at d = 128.
+#ifndef SAPCU_CHAIN_WD
+#define SAPCU_CHAIN_WD 2
+#endif
+#ifndef SAPCU_CHAIN_LB128
+#define SAPCU_CHAIN_LB128 3
+#endif
 template <int D> struct ChainShape {
     static constexpr int ROWS = D == 128 ? 96 : (D == 256 ? 128 : 64);
     static constexpr int RB = ROWS / 32;              // 32-row MFMA blocks per wave tile
@@ -55,7 +63,7 @@ template <int D> struct ChainShape {
     static constexpr int KSTEP = 2 * PLANE;
     static constexpr int LDS = ROWS * D * 4 + ROWS * 16 + ROWS * 8;
     static constexpr int US = D == 128 ? 4 : 8;       // elements per lane of one epilogue unit (d = 128: 168 registers per wave)
-    static constexpr int WD = 2;                      // weight fragments this many k16 steps ahead (x CB column blocks x hi, lo) = the
+    static constexpr int WD = SAPCU_CHAIN_WD;                     // weight fragments this many k16 steps ahead (x CB column blocks x hi, lo) = the
                                                       // body of the rolled k loop
 };
 
@@ -219,12 +227,10 @@ __device__ __forceinline__ NeuronP chain_lif(const float* __restrict__ lif, int 
     return np;
 }
 
-// threads = 64 x (d / 32 / CB).  d = 128: two 256-thread workgroups per CU.  (LDS would hold three — 51 KiB each — and three ran
-// 2.9 % faster, 4.55 against 4.68 ms per launch, but only at 168 registers per wave: the compiler then spills 23 of them, whatever
-// is trimmed from the epilogues, and their scratch traffic was 1.2 of the launch's 1.68 GB of HBM bytes.  At two per CU the kernel
-// takes 192 registers and touches no scratch.)
+// threads = 64 x (d / 32 / CB).  d = 128: three 256-thread workgroups per CU (51 KiB of LDS each, <= 170 registers per wave: the
+// kernel takes 144 and no scratch; three ran 1 % faster than two in the same-box A/B of round 3, 2.9 % in round 2's).
 template <int D, int KK>
-__global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? 2 : 1)) void fn_edge_chain_kernel(const ChainArgs a) {
+__global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? SAPCU_CHAIN_LB128 : 1)) void fn_edge_chain_kernel(const ChainArgs a) {
     using S = ChainShape<D>;
     constexpr int CH_ROWS = S::ROWS, RB = S::RB, CB = S::CB, NB = S::NB, CH_PLANE = S::PLANE, CH_KSTEP = S::KSTEP;
     constexpr int PPG = CH_ROWS / KK;                      // points per group
@@ -365,7 +371,9 @@ __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? 2 : 1)) void fn
                 const int p0 = r0 / KK < PPG ? r0 / KK : PPG - 1, p1 = r1 / KK < PPG ? r1 / KK : PPG - 1;
                 const float qv = p0 == p1 ? qp[j][p0] : (L.h ? qp[j][p1] : qp[j][p0]);
                 chain_put<CH_PLANE, CB>(X, L, j, i, e >> 2, e & 3, __fadd_rn(__fsub_rn(qv, kq[u & 1][z]), v[z]));
-                pe[b][e] = __fadd_rn(vq[u & 1][z], v[z]);                                  // t = v_j + pe (fn:386-389)
+                // t = v_j + pe (fn:386-389).  settle: formed HERE — left alone the compiler sank some of these adds to the softmax
+                // and kept both operands alive until then, the gathered one in scratch behind a vmcnt(0) right after its load
+                pe[b][e] = settle(__fadd_rn(vq[u & 1][z], v[z]));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
