@@ -1696,10 +1696,13 @@ def test_concurrent_forwards_of_one_handle_on_two_streams(weights):
     assert fd.gate_violations() == 0 and fn.gemm_mode() == (True, 0) and fd.gemm_mode() == (True, 0)
 
 
-def test_graph_captured_training_step_equals_the_eager_step():
+@pytest.mark.parametrize("use_amp", [False, True])
+def test_graph_captured_training_step_equals_the_eager_step(use_amp):
     """fn_trainer.GraphedTrainStep (one optimisation step replayed as a HIP graph) against Trainer.train_step from the same
     initial state, dropout off: same first loss, finite losses and gradient norms on every replay (the scatter-add targets
-    must be re-zeroed inside the graph), and parameters that stay close to the eager run's after four AdamW steps."""
+    must be re-zeroed inside the graph), and parameters that stay close to the eager run's after four AdamW steps.
+    use_amp=True (no scaler — a case the constructor accepts): both run the bf16 GEMMs, i.e. the captured step's first loss
+    equals the eager bf16 step's and differs from the f32 step's (the graph used to capture the f32 GEMMs)."""
     import copy
     import sapcu_amd
     from sapcu_amd import fn_trainer, testing as T
@@ -1714,7 +1717,7 @@ def test_graph_captured_training_step_equals_the_eager_step():
         model.attn_dropout = model.decoder_dropout = 0.0
         model.cuda()
         opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=True)
-        tr = fn_trainer.Trainer(model, opt, device=torch.device("cuda"), grad_clip=0.15, grad_clip_type="norm")
+        tr = fn_trainer.Trainer(model, opt, device=torch.device("cuda"), grad_clip=0.15, grad_clip_type="norm", use_amp=use_amp)
         step = fn_trainer.GraphedTrainStep(tr, data, warmup=0) if graphed else tr.train_step     # (capturing runs no kernels)
         probe = torch.from_numpy(g["points"]).reshape(-1, g["points"].shape[-2], 3)[:8].cuda()
         model.eval()
@@ -1737,6 +1740,14 @@ def test_graph_captured_training_step_equals_the_eager_step():
     # the first steps agree; later ones drift apart the way two eager runs do (float atomics in the scatter-adds reorder sums,
     # a hard spike flips, and the loss of a 16-patch batch moves by 0.1)
     assert abs(le[0] - lg[0]) <= 1e-5 and max(abs(a - b) for a, b in zip(le, lg)) <= 0.3, (le, lg)
+    if use_amp:                                          # ... and it is the bf16 arithmetic that was captured
+        model = sapcu_amd.ImprovedSNNNormalEstimation(**kw)
+        model.load_state_dict(copy.deepcopy(sd), strict=True)
+        model.attn_dropout = model.decoder_dropout = 0.0
+        model.cuda().train()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=True)
+        l32 = fn_trainer.Trainer(model, opt, device=torch.device("cuda"), grad_clip=0.15, grad_clip_type="norm").train_step(data)[0]
+        assert abs(l32 - lg[0]) > 10 * abs(le[0] - lg[0]) and abs(l32 - lg[0]) > 1e-6, (l32, le[0], lg[0])
     worst = max(float((pe[n] - pg[n]).abs().max()) for n in pe)
     assert worst <= 1.2e-3, worst           # four AdamW steps of lr 1e-4: each moves a weight by at most ~lr, in either direction
 
