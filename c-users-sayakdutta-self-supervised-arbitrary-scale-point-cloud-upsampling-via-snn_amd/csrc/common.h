@@ -160,6 +160,7 @@ __device__ __forceinline__ float neuron_step(float x, NeuronS& s, const NeuronP&
 // -DSAPCU_LIF_EXACT_ORDER restores the reference's operation order op for op.
 // ---------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct NeuronP2 {
     f32x2 decay, adapt, rdecay, theta0;

@@ -58,7 +58,7 @@ constexpr int FE_OFF_IDX0 = FE_OFF_XYZ + FE_M * 16;        // u8[48][48]: xyz ne
 constexpr int FE_OFF_IDXL = FE_OFF_IDX0 + FE_M * FE_M;     // u8[48][48]: feature-space neighbours of the current block
 constexpr int FE_OFF_XX = FE_OFF_IDXL + FE_M * FE_M;       // float[64]
 constexpr int FE_LDS = FE_OFF_XX + 256;                    // 157 184 B
-constexpr int FE_F_LD = 33;                                // score staging 2 x [64][33] f32 at R2 + 0, keys [m][m+1] behind them
+constexpr int FE_F_LD = 36;                                // score staging 2 x [64][36] f32 at R2 + 0, keys [m][m+1] behind them
 constexpr int FE_KEYS_OFF = 2 * 64 * FE_F_LD * 4;         // (two staging buffers)
 constexpr int FE_TLD = 36;                                 // EdgeConv staging tile of a wave: [48][36] f32 (32 channels + 4 pad)
 constexpr int FE_TILE = FE_M * FE_TLD;
@@ -178,110 +178,96 @@ __device__ __forceinline__ int fe_wave_sum(int v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// In-patch kNN (fd/snn_coder.py:25-32), the arithmetic of patch_knn_kernel<3> (patch_ops.hip): score[i][j] = (-xx[j] - (-2 <xi,xj>))
+// In-patch kNN (fd/snn_coder.py:25-32), the arithmetic of patch_knn_kernel (patch_ops.hip): score[i][j] = (-xx[j] - (-2 <xi,xj>))
 // - xx[i] with <.,.> a channel-ascending f32 FMA chain and xx a sequential sum of rounded squares; top-k by descending score,
 // equal scores by ascending index.  `fill(F, c0, cw, ftid)` (threads 256..511, ftid = tid - 256) stages channels c0 .. c0+cw-1
-// of all 64 rows (rows >= m: 0) into F[row][33]; the staging area is double-buffered: waves 4-7 fill chunk n + 1 while waves
-// 0-3 — a 16 x 16 grid of 3 x 3 pair blocks — accumulate chunk n (one barrier per chunk).  Ranks: one wave per row, the row's
-// keys broadcast through scalar registers.  Output: idx_out[i][rank] (bytes, row pitch 48) and the optional int32 tap [m][k].
+// of all 64 rows (rows >= m: 0; channels up to the next multiple of 4: 0) into F[row][36]; the staging area is double-buffered:
+// waves 4-7 fill chunk n + 1 while waves 0-3 accumulate chunk n (one barrier per chunk).
+//
+// Round 3: the inner products run on the matrix pipe.  v_mfma_f32_16x16x4_f32 IS a k-ascending chain of IEEE f32 FMAs
+// (profiles/micro/mfma_f32_exact.hip: 0 of 256 outputs differ from fmaf chains over 256 channels, likewise the 32x32x2 shape),
+// so a 16 x 16 block of pairs takes one MFMA per 4 channels, operands one LDS dword per lane (row stride 36: conflict-free), and
+// the scores stay bit-identical to the VALU form (9 FMAs per 6 LDS reads per lane: bound by the LDS port).  <xi,xj> = <xj,xi>
+// bit for bit, so only the six blocks bi <= bj of the 3 x 3 block grid are computed: waves 0-2 two blocks each, wave 3 the squared
+// norms.  Ranks: one wave per row, the row's keys broadcast through scalar registers.  Output: idx_out[i][rank] (bytes, row
+// pitch 48) and the optional int32 tap [m][k].
 // ---------------------------------------------------------------------------------------------
 template <typename Fill>
 __device__ __forceinline__ void fe_knn(unsigned char* R2, float* xx, unsigned char* idx_out, int m, int c, int k, Fill fill,
                                        int32_t* __restrict__ tap, int tid) {
-    float* Fb = reinterpret_cast<float*>(R2);                          // two buffers of [64][33]
+    float* Fb = reinterpret_cast<float*>(R2);                          // two buffers of [64][36]
     unsigned* K = reinterpret_cast<unsigned*>(R2 + FE_KEYS_OFF);
-    const int bi = (tid >> 4) & 15, bj = tid & 15;
-    const bool scorer = tid < 256;
-    float acc[3][3];
-#pragma unroll
-    for (int u = 0; u < 3; ++u)
-#pragma unroll
-        for (int v = 0; v < 3; ++v) acc[u][v] = 0.f;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g4 = lane >> 4;
+    // blocks of this wave (wave-uniform): wave 0: (0,0) (1,2), wave 1: (0,1) (2,2), wave 2: (0,2) (1,1)
+    const int bi0 = 0, bj0 = wave < 3 ? wave : 0;
+    const int bi1 = wave == 1 ? 2 : 1, bj1 = wave == 2 ? 1 : 2;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float myxx = 0.f;
     __syncthreads();                                                   // the area is free (previous phase done)
-    if (!scorer) fill(Fb, 0, min(32, c), tid - 256);
+    if (wave >= 4) fill(Fb, 0, min(32, c), tid - 256);
     __syncthreads();
     int buf = 0;
     for (int c0 = 0; c0 < c; c0 += 32, buf ^= 1) {
         const int cw = min(32, c - c0);
-        float* F = Fb + buf * (64 * FE_F_LD);
-        if (!scorer) {
+        const float* F = Fb + buf * (64 * FE_F_LD);
+        if (wave >= 4) {
             if (c0 + 32 < c) fill(Fb + (buf ^ 1) * (64 * FE_F_LD), c0 + 32, min(32, c - c0 - 32), tid - 256);
-        } else {
-            const float* fi = F + (bi * 3) * FE_F_LD;
-            const float* fj = F + (bj * 3) * FE_F_LD;
-            // groups of 8 channels: the 48 LDS reads of a group are issued before its FMAs (one wave per SIMD works here: a
-            // read-then-use loop per channel is pure LDS latency); every pair still sees its chain in ascending channel order
-            int cc = 0;
-            for (; cc + 8 <= cw; cc += 8) {
-                float a[8][3], bb[8][3];
+        } else if (wave < 3) {
+            const float* fa0 = F + (16 * bi0 + r16) * FE_F_LD + g4;
+            const float* fb0 = F + (16 * bj0 + r16) * FE_F_LD + g4;
+            const float* fa1 = F + (16 * bi1 + r16) * FE_F_LD + g4;
+            const float* fb1 = F + (16 * bj1 + r16) * FE_F_LD + g4;
+            if (cw == 32) {                                            // the 32 operand reads first, then the 16 MFMAs
+                float a0[8], b0[8], a1[8], b1[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
+                for (int s4 = 0; s4 < 8; ++s4) {
+                    a0[s4] = fa0[4 * s4];
+                    b0[s4] = fb0[4 * s4];
+                    a1[s4] = fa1[4 * s4];
+                    b1[s4] = fb1[4 * s4];
+                }
 #pragma unroll
-                    for (int u = 0; u < 3; ++u) {
-                        a[q][u] = fi[u * FE_F_LD + cc + q];
-                        bb[q][u] = fj[u * FE_F_LD + cc + q];
-                    }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    if (q == 0 && c0 == 0 && cc == 0) {
-#pragma unroll
-                        for (int u = 0; u < 3; ++u)
-#pragma unroll
-                            for (int v = 0; v < 3; ++v) acc[u][v] = __fmul_rn(a[0][u], bb[0][v]);
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < 3; ++u)
-#pragma unroll
-                            for (int v = 0; v < 3; ++v) acc[u][v] = __fmaf_rn(a[q][u], bb[q][v], acc[u][v]);
-                    }
+                for (int s4 = 0; s4 < 8; ++s4) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s4], b0[s4], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s4], b1[s4], acc1, 0, 0, 0);
+                }
+            } else {
+                for (int cc = 0; cc < cw; cc += 4) {                   // (the fill zero-pads to a multiple of 4: + 0 is exact)
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[cc], fb0[cc], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[cc], fb1[cc], acc1, 0, 0, 0);
                 }
             }
-            for (; cc < cw; ++cc) {
-                float a[3], bb[3];
-#pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    a[u] = fi[u * FE_F_LD + cc];
-                    bb[u] = fj[u * FE_F_LD + cc];
-                }
-                if (c0 == 0 && cc == 0) {
-#pragma unroll
-                    for (int u = 0; u < 3; ++u)
-#pragma unroll
-                        for (int v = 0; v < 3; ++v) acc[u][v] = __fmul_rn(a[u], bb[v]);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 3; ++u)
-#pragma unroll
-                        for (int v = 0; v < 3; ++v) acc[u][v] = __fmaf_rn(a[u], bb[v], acc[u][v]);
-                }
-            }
-            if (tid < m) {
-                const float* fr = F + tid * FE_F_LD;
-                for (int cc2 = 0; cc2 < cw; ++cc2) {
-                    const float sq = __fmul_rn(fr[cc2], fr[cc2]);
-                    myxx = (c0 == 0 && cc2 == 0) ? sq : __fadd_rn(myxx, sq);
-                }
+        } else if (lane < m) {                                         // wave 3: squared norms
+            const float* fr = F + lane * FE_F_LD;
+            for (int cc2 = 0; cc2 < cw; ++cc2) {
+                const float sq = __fmul_rn(fr[cc2], fr[cc2]);
+                myxx = (c0 == 0 && cc2 == 0) ? sq : __fadd_rn(myxx, sq);
             }
         }
         __syncthreads();                                               // chunk n consumed, chunk n + 1 staged
     }
-    if (tid < m) xx[tid] = myxx;
+    if (wave == 3 && lane < m) xx[lane] = myxx;
     __syncthreads();
-    if (scorer) {
+    if (wave < 3) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u)
+        for (int q = 0; q < 2; ++q) {
+            const int bi = q ? bi1 : bi0, bj = q ? bj1 : bj0;
+            const f32x4 acc = q ? acc1 : acc0;
+            const int j = 16 * bj + r16;
 #pragma unroll
-            for (int v = 0; v < 3; ++v) {
-                const int i = bi * 3 + u, j = bj * 3 + v;
+            for (int e = 0; e < 4; ++e) {
+                const int i = 16 * bi + 4 * g4 + e;
                 if (i < m && j < m) {
-                    const float inner = __fmul_rn(-2.0f, acc[u][v]);
+                    const float inner = __fmul_rn(-2.0f, acc[e]);
+                    // stored as the order-preserving integer key of the score (+ 0.0f: -0 and +0 compare equal as floats)
                     K[i * (m + 1) + j] = float_max_key(__fadd_rn(__fsub_rn(__fsub_rn(-xx[j], inner), xx[i]), 0.0f));
+                    if (bi != bj) K[j * (m + 1) + i] = float_max_key(__fadd_rn(__fsub_rn(__fsub_rn(-xx[i], inner), xx[j]), 0.0f));
                 }
             }
+        }
     }
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
     const int full = m * (m - 1) / 2;
     for (int i = wave; i < m; i += FE_NT / 64) {
         const unsigned key0 = lane < m ? K[i * (m + 1) + lane] : 0u;
@@ -680,10 +666,10 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
     // ---- block 0: xyz neighbours (one ranking serves all scales)                                          fd:411-417
     {
         auto fill = [&](float* F, int c0, int cw, int ftid) {
-            if (ftid < 64 * 3) {
-                const int i = ftid / 3, cc = ftid % 3;
+            {                                                          // 64 rows x (x, y, z, 0)
+                const int i = ftid >> 2, cc = ftid & 3;
                 const float4 v = XYZ[i < FE_M ? i : 0];
-                F[i * FE_F_LD + cc] = i < m ? (cc == 0 ? v.x : (cc == 1 ? v.y : v.z)) : 0.f;
+                F[i * FE_F_LD + cc] = (i < m && cc < 3) ? (cc == 0 ? v.x : (cc == 1 ? v.y : v.z)) : 0.f;
             }
             (void)c0; (void)cw;
         };
