@@ -207,6 +207,21 @@ __device__ __forceinline__ void chain_put(unsigned char* X, const ChainLane<CB>&
     *reinterpret_cast<_Float16*>(p + PLANE) = (_Float16)(v - (float)hi);
 }
 
+// two elements of one column, rows u and u + 1 of a register quad: the split with the packed conversions of gfx950 (v_cvt_pk_f16_f32:
+// one instruction per PAIR and plane instead of one per element; round-to-nearest-even like the scalar form — the same bits)
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+template <int PLANE, int CB>
+__device__ __forceinline__ void chain_put2(unsigned char* X, const ChainLane<CB>& L, int j, int i, int q, int u, float v0, float v1) {
+    unsigned char* p = X + L.xw[j][q & 1] + (unsigned)(i * 2048 + q * 512 + u * 64);
+    const f32x2 v = f32x2{v0, v1};
+    const half2v hi = __builtin_convertvector(v, half2v);
+    const half2v lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), half2v);
+    *reinterpret_cast<_Float16*>(p) = hi.x;
+    *reinterpret_cast<_Float16*>(p + 64) = hi.y;
+    *reinterpret_cast<_Float16*>(p + PLANE) = lo.x;
+    *reinterpret_cast<_Float16*>(p + PLANE + 64) = lo.y;
+}
+
 // store_split (gemm_epi.h) with non-temporal stores: the result rows are streamed out once and must not push the weights and the
 // k / v rows out of L2 (measured at d = 512 together with the non-temporal q loads: 29 % fewer L2 misses per launch)
 __device__ __forceinline__ void chain_store_split_nt(float* base, int64_t row, int ld, int col, float v) {
@@ -317,7 +332,7 @@ __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? SAPCU_CHAIN_LB1
             }
             lif_selfloop_n<US>(v, nd[j], a.T);
 #pragma unroll
-            for (int z = 0; z < US; ++z) chain_put<CH_PLANE, CB>(X, L, j, i, (e0 + z) >> 2, (e0 + z) & 3, v[z]);
+            for (int z = 0; z < US; z += 2) chain_put2<CH_PLANE, CB>(X, L, j, i, (e0 + z) >> 2, (e0 + z) & 3, v[z], v[z + 1]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -363,6 +378,7 @@ __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? SAPCU_CHAIN_LB1
             for (int z = 0; z < US; ++z) v[z] = __fmaf_rn(acc[b][e0 + z], 0.0625f, b1[j]);      // undoes the x16 of the pre-scaled weights (exact)
             lif_selfloop_n<US>(v, n1[j], a.T);
             __builtin_amdgcn_sched_barrier(0);
+            float ain[US];                                 // attn_in = q_i - k_j + pe
 #pragma unroll
             for (int z = 0; z < US; ++z) {
                 // the row's point: row = 32 i + 8 q + 4 h + u, compile-time per lane half (pad rows: any point)
@@ -370,11 +386,13 @@ __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? SAPCU_CHAIN_LB1
                 const int r0 = 32 * i + 8 * (e >> 2) + (e & 3), r1 = r0 + 4;
                 const int p0 = r0 / KK < PPG ? r0 / KK : PPG - 1, p1 = r1 / KK < PPG ? r1 / KK : PPG - 1;
                 const float qv = p0 == p1 ? qp[j][p0] : (L.h ? qp[j][p1] : qp[j][p0]);
-                chain_put<CH_PLANE, CB>(X, L, j, i, e >> 2, e & 3, __fadd_rn(__fsub_rn(qv, kq[u & 1][z]), v[z]));
+                ain[z] = __fadd_rn(__fsub_rn(qv, kq[u & 1][z]), v[z]);
                 // t = v_j + pe (fn:386-389).  settle: formed HERE — left alone the compiler sank some of these adds to the softmax
                 // and kept both operands alive until then, the gathered one in scratch behind a vmcnt(0) right after its load
                 pe[b][e] = settle(__fadd_rn(vq[u & 1][z], v[z]));
             }
+#pragma unroll
+            for (int z = 0; z < US; z += 2) chain_put2<CH_PLANE, CB>(X, L, j, i, (e0 + z) >> 2, (e0 + z) & 3, ain[z], ain[z + 1]);
             __builtin_amdgcn_sched_barrier(0);
         }
         chain_w_prefetch<D>(wp2, cb0, lane, W);
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? SAPCU_CHAIN_LB1
             for (int z = 0; z < US; ++z) v[z] = __fmaf_rn(acc[b][e0 + z], 0.0625f, b2[j]);
             lif_selfloop_n<US>(v, n2[j], a.T);
 #pragma unroll
-            for (int z = 0; z < US; ++z) chain_put<CH_PLANE, CB>(X, L, j, i, (e0 + z) >> 2, (e0 + z) & 3, v[z]);
+            for (int z = 0; z < US; z += 2) chain_put2<CH_PLANE, CB>(X, L, j, i, (e0 + z) >> 2, (e0 + z) & 3, v[z], v[z + 1]);
             __builtin_amdgcn_sched_barrier(0);
         }
         chain_w_prefetch<D>(wp3, cb0, lane, W);

@@ -23,63 +23,74 @@ struct KnnOut {
     int n;
 };
 
-// Thread (bi, bj) of the 16 x 16 thread grid owns the BT x BT block of pairs (i, j), i in [bi*BT, bi*BT+BT), j likewise:
-// per channel it reads BT + BT values from LDS for BT*BT FMAs (one-pair-per-thread needed 2 reads per FMA and was bound
-// by LDS bandwidth in feature space, c = 64..256).  Every pair still sees ITS chain in ascending channel order, so the
-// scores are bit-identical.  BT = ceil(m / 16): 3 for the model's 48-point patches, 7 for the reference's default m = 100, up to 8.
-// NT = 256, or 512 for m > 64 (BT >= 5): the rank phase — m^3 compares per patch, one wave per row — then has eight waves per
-// workgroup (the score keys of a 100-point patch take 40 KiB of LDS: two workgroups per CU either way); the score phase keeps
-// its 16 x 16 thread grid (threads 256.. only help staging).
-template <int BT, int NT>
+// The inner products run on the matrix pipe (round 3): v_mfma_f32_16x16x4_f32 IS a k-ascending chain of IEEE f32 FMAs
+// (profiles/micro/mfma_f32_exact.hip: 0 of 256 outputs differ from fmaf chains over 256 channels), so a 16 x 16 block of pairs
+// takes one MFMA per 4 channels — operands: one LDS dword per lane, row stride 36: conflict-free — and every pair still sees ITS
+// chain in ascending channel order: bit-identical to the register-tiled VALU form it replaces (BT x BT pairs per thread, BT + BT
+// LDS reads per BT * BT FMAs: bound by the LDS port in feature space).  <xi,xj> = <xj,xi> bit for bit: only the blocks bi <= bj
+// of the ceil(m / 16)^2 block grid are computed (m = 48: 6, m = 100: 28), dealt round-robin to the waves.  Channels are padded
+// with zeros to a multiple of 4 (+ 0 * 0 is exact).
+// NT = 256, or 512 for m > 64: the rank phase — m^3 compares per patch, one wave per row — then has eight waves per workgroup
+// (the score keys of a 100-point patch take 40 KiB of LDS: two workgroups per CU either way).
+constexpr int PK_LD = 36;   // staging row stride (floats)
+
+template <int NT>
 __global__ __launch_bounds__(NT) void patch_knn_kernel(const float* __restrict__ feat, int64_t pstride, int m,
                                                        int c, int ld, const KnnOut out) {
     extern __shared__ float sm[];
     unsigned* K = reinterpret_cast<unsigned*>(sm);   // [m][m+1] score keys
     float* xx = sm + m * (m + 1);       // [m]
-    float* F = xx + m;                  // [16*BT][PK_CH+1]  (rows >= m zero)
+    float* F = xx + m;                  // [16 nb][PK_LD]  (rows >= m, channels >= c of the last chunk: zero)
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g4 = lane >> 4;
     const float* base = feat + (int64_t)blockIdx.x * pstride;
-    const int bi = (tid >> 4) & 15, bj = tid & 15;
-    const bool scorer = NT == 256 || tid < 256;
-    const int mpad = 16 * BT;
-    float acc[BT][BT];
+    const int nb = (m + 15) >> 4, mpad = 16 * nb;
+    constexpr int NW = NT / 64;
+    constexpr int NBW = NT == 256 ? 3 : 5;          // blocks per wave: 10 / 4 (m <= 64), 36 / 8 (m <= 128)
+    // this wave's blocks: t = wave, wave + NW, ... in the row-major enumeration of bi <= bj (wave-uniform)
+    int bi[NBW], bj[NBW];
+    {
+        int t = 0, q = 0;
 #pragma unroll
-    for (int u = 0; u < BT; ++u)
+        for (int u = 0; u < NBW; ++u) bi[u] = bj[u] = -1;
+        for (int i = 0; i < nb; ++i)
+            for (int j = i; j < nb; ++j, ++t)
+                if (t % NW == wave) {
 #pragma unroll
-        for (int v = 0; v < BT; ++v) acc[u][v] = 0.f;
+                    for (int u = 0; u < NBW; ++u)
+                        if (u == q) { bi[u] = i; bj[u] = j; }
+                    ++q;
+                }
+    }
+    f32x4 acc[NBW];
+#pragma unroll
+    for (int u = 0; u < NBW; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     float myxx = 0.f;
     for (int c0 = 0; c0 < c; c0 += PK_CH) {
-        const int cw = min(PK_CH, c - c0);
+        const int cw = min(PK_CH, c - c0), cw4 = (cw + 3) & ~3;
         __syncthreads();
-        for (int e = tid; e < mpad * cw; e += NT) {
-            const int i = e / cw, cc = e % cw;
-            F[i * (PK_CH + 1) + cc] = i < m ? base[(int64_t)i * ld + c0 + cc] : 0.f;
+        if (cw4 == PK_CH) {                             // (whole chunks: no integer division per element)
+            for (int e = tid; e < mpad * PK_CH; e += NT) {
+                const int i = e >> 5, cc = e & (PK_CH - 1);
+                F[i * PK_LD + cc] = (i < m && cc < cw) ? base[(int64_t)i * ld + c0 + cc] : 0.f;
+            }
+        } else {
+            for (int e = tid; e < mpad * cw4; e += NT) {
+                const int i = e / cw4, cc = e % cw4;
+                F[i * PK_LD + cc] = (i < m && cc < cw) ? base[(int64_t)i * ld + c0 + cc] : 0.f;
+            }
         }
         __syncthreads();
-        if (!scorer) continue;                          // (the barriers above are reached by every thread each iteration)
-        const float* fi = F + (bi * BT) * (PK_CH + 1);
-        const float* fj = F + (bj * BT) * (PK_CH + 1);
-        for (int cc = 0; cc < cw; ++cc) {
-            float a[BT], bb[BT];
+        for (int cc = 0; cc < cw4; cc += 4) {
 #pragma unroll
-            for (int u = 0; u < BT; ++u) {
-                a[u] = fi[u * (PK_CH + 1) + cc];
-                bb[u] = fj[u * (PK_CH + 1) + cc];
-            }
-            if (c0 == 0 && cc == 0) {
-#pragma unroll
-                for (int u = 0; u < BT; ++u)
-#pragma unroll
-                    for (int v = 0; v < BT; ++v) acc[u][v] = __fmul_rn(a[u], bb[v]);
-            } else {
-#pragma unroll
-                for (int u = 0; u < BT; ++u)
-#pragma unroll
-                    for (int v = 0; v < BT; ++v) acc[u][v] = __fmaf_rn(a[u], bb[v], acc[u][v]);
-            }
+            for (int u = 0; u < NBW; ++u)
+                if (bi[u] >= 0)
+                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(F[(16 * bi[u] + r16) * PK_LD + cc + g4],
+                                                                  F[(16 * bj[u] + r16) * PK_LD + cc + g4], acc[u], 0, 0, 0);
         }
         if (tid < m) {
-            const float* fr = F + tid * (PK_CH + 1);
+            const float* fr = F + tid * PK_LD;
             for (int cc = 0; cc < cw; ++cc) {
                 const float sq = __fmul_rn(fr[cc], fr[cc]);
                 myxx = (c0 == 0 && cc == 0) ? sq : __fadd_rn(myxx, sq);
@@ -88,18 +99,21 @@ __global__ __launch_bounds__(NT) void patch_knn_kernel(const float* __restrict__
     }
     if (tid < m) xx[tid] = myxx;
     __syncthreads();
-    if (scorer)
 #pragma unroll
-    for (int u = 0; u < BT; ++u)
+    for (int u = 0; u < NBW; ++u) {
+        if (bi[u] < 0) continue;
+        const int j = 16 * bj[u] + r16;
 #pragma unroll
-        for (int v = 0; v < BT; ++v) {
-            const int i = bi * BT + u, j = bj * BT + v;
+        for (int e = 0; e < 4; ++e) {
+            const int i = 16 * bi[u] + 4 * g4 + e;
             if (i < m && j < m) {
-                const float inner = __fmul_rn(-2.0f, acc[u][v]);
+                const float inner = __fmul_rn(-2.0f, acc[u][e]);
                 // stored as the order-preserving integer key of the score (+ 0.0f: -0 and +0 compare equal as floats)
                 K[i * (m + 1) + j] = float_max_key(__fadd_rn(__fsub_rn(__fsub_rn(-xx[j], inner), xx[i]), 0.0f));
+                if (bi[u] != bj[u]) K[j * (m + 1) + i] = float_max_key(__fadd_rn(__fsub_rn(__fsub_rn(-xx[i], inner), xx[j]), 0.0f));
             }
         }
+    }
     __syncthreads();
     // rank by counting: one wave per row, lane owns column lane (and lane + 64 when m > 64); the row's keys sit in the lanes'
     // registers and an inner iteration broadcasts one of them through a scalar register (v_readlane) — no LDS read — and costs
@@ -108,7 +122,6 @@ __global__ __launch_bounds__(NT) void patch_knn_kernel(const float* __restrict__
     // permutation exactly when the row has no two equal scores (tied columns do not count each other, so the ranks then sum to
     // less than m (m - 1) / 2); otherwise the row is redone with (score, index) pairs compared as ONE 64-bit integer — key << 32 |
     // ~index: greater = higher score, or equal score and lower index.
-    const int lane = tid & 63, wave = tid >> 6;
     const int full = m * (m - 1) / 2;
     for (int i = wave; i < m; i += NT / 64) {
         const unsigned* row = K + i * (m + 1);
@@ -179,24 +192,17 @@ int launch_patch_knn_multi(const float* feat, int64_t b, int64_t pstride, int m,
         out.k[t] = t < ntab ? ks[t] : 0;
         if (t < ntab) SAPCU_CHECK_ARG(ks[t] >= 1 && ks[t] <= m && idx[t], "patch_knn: need 1<=k<=m (k=%d m=%d)", ks[t], m);
     }
-    const int bt = (m + 15) / 16;                                   // 1..8
-    const int btk = bt <= 3 ? 3 : bt;                               // pair block per thread: 16 * btk >= m rows / columns
-    const size_t lds = (size_t)(m * (m + 1) + m + 16 * btk * (PK_CH + 1)) * sizeof(float);
-    // m > ~110 needs more than the default 64 KiB of dynamic LDS (m = 128: 83 KiB): raised once per device
-#define SAPCU_PK(BT, NT)                                                                                                  \
-    do {                                                                                                                  \
-        static DeviceOnce once;                                                                                           \
-        if (lds > 65536) SAPCU_SET_MAX_LDS(once, (&patch_knn_kernel<BT, NT>), 98304);                                      \
-        hipLaunchKernelGGL((patch_knn_kernel<BT, NT>), dim3((unsigned)b), dim3(NT), lds, st, feat, pstride, m, c, ld, out); \
+    const int nb = (m + 15) / 16;                                   // 1..8 blocks of 16 rows
+    const size_t lds = (size_t)(m * (m + 1) + m + 16 * nb * PK_LD) * sizeof(float);
+    // m > ~115 needs more than the default 64 KiB of dynamic LDS (m = 128: 83 KiB): raised once per device
+#define SAPCU_PK(NT)                                                                                                  \
+    do {                                                                                                              \
+        static DeviceOnce once;                                                                                       \
+        if (lds > 65536) SAPCU_SET_MAX_LDS(once, (&patch_knn_kernel<NT>), 98304);                                      \
+        hipLaunchKernelGGL((patch_knn_kernel<NT>), dim3((unsigned)b), dim3(NT), lds, st, feat, pstride, m, c, ld, out); \
     } while (0)
-    switch (btk) {
-        case 3: SAPCU_PK(3, 256); break;
-        case 4: SAPCU_PK(4, 256); break;
-        case 5: SAPCU_PK(5, 512); break;
-        case 6: SAPCU_PK(6, 512); break;
-        case 7: SAPCU_PK(7, 512); break;
-        default: SAPCU_PK(8, 512); break;
-    }
+    if (m <= 64) SAPCU_PK(256);
+    else SAPCU_PK(512);
 #undef SAPCU_PK
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
