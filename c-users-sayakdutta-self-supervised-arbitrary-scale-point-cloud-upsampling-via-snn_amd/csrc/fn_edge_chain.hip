@@ -215,7 +215,17 @@ __device__ __forceinline__ void chain_put2(unsigned char* X, const ChainLane<CB>
     unsigned char* p = X + L.xw[j][q & 1] + (unsigned)(i * 2048 + q * 512 + u * 64);
     const f32x2 v = f32x2{v0, v1};
     const half2v hi = __builtin_convertvector(v, half2v);
-    const half2v lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), half2v);
+    // lo = f16(v - hi) as ONE instruction per element: v_fma_mixlo/mixhi_f16 read the f16 half in place, form -hi + v exactly
+    // (v - hi is exact in f32 anyway) and round once to f16 — the bits of cvt(f32(v) - f32(hi)); the compiler does not select
+    // them here on its own (it unpacked the pair instead)
+    half2v lo;
+    {
+        unsigned lp;
+        const unsigned hp = __builtin_bit_cast(unsigned, hi);
+        asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(hp), "v"(v.x));
+        asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp) : "v"(hp), "v"(v.y));
+        lo = __builtin_bit_cast(half2v, lp);
+    }
     *reinterpret_cast<_Float16*>(p) = hi.x;
     *reinterpret_cast<_Float16*>(p + 64) = hi.y;
     *reinterpret_cast<_Float16*>(p + PLANE) = lo.x;
