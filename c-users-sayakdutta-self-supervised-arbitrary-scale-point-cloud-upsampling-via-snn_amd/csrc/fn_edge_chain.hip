@@ -254,7 +254,9 @@ __device__ __forceinline__ NeuronP chain_lif(const float* __restrict__ lif, int 
 
 // threads = 64 x (d / 32 / CB).  d = 128: three 256-thread workgroups per CU (51 KiB of LDS each, <= 170 registers per wave: the
 // kernel takes 144 and no scratch; three ran 1 % faster than two in the same-box A/B of round 3, 2.9 % in round 2's).
-template <int D, int KK>
+// O32: the q|k|v tensor is smaller than 4 GiB — the gathers address it as a scalar base + a 32-bit byte offset per lane (one add
+// per gathered element; the 64-bit form spends a 64-bit multiply-add and two adds on each).
+template <int D, int KK, bool O32>
 __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? SAPCU_CHAIN_LB128 : 1)) void fn_edge_chain_kernel(const ChainArgs a) {
     using S = ChainShape<D>;
     constexpr int CH_ROWS = S::ROWS, RB = S::RB, CB = S::CB, NB = S::NB, CH_PLANE = S::PLANE, CH_KSTEP = S::KSTEP;
@@ -306,7 +308,9 @@ __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? SAPCU_CHAIN_LB1
         const int pl = tid / KK;
         const bool ok = pl < npts;                                           // pad rows replay the group's first edge row
         const int64_t er = ok ? pt0 * KK + tid : pt0 * KK;
-        rinfo[tid] = a.tab[er];
+        const int2 t = a.tab[er];
+        if (O32) reinterpret_cast<unsigned*>(rinfo)[tid] = (unsigned)t.y * (unsigned)(a.ldq * 4);      // byte offset of the neighbour's row
+        else rinfo[tid] = t;
         pdl[tid] = a.pd[er];
     }
     {
@@ -355,9 +359,15 @@ __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? SAPCU_CHAIN_LB1
         const int b = u / UPB, i = b / CB, j = b % CB;
 #pragma unroll
         for (int z = 0; z < US; ++z) {
-            const int nrow = rinfo[row_of(i, US * (u % UPB) + z)].y;
-            kd[z] = a.qkv[(int64_t)nrow * a.ldq + D + L.col[j]];
-            vd[z] = a.qkv[(int64_t)nrow * a.ldq + 2 * D + L.col[j]];
+            if (O32) {
+                const unsigned off = reinterpret_cast<const unsigned*>(rinfo)[row_of(i, US * (u % UPB) + z)] + 4u * (unsigned)L.col[j];
+                kd[z] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.qkv + D) + off);
+                vd[z] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.qkv + 2 * D) + off);
+            } else {
+                const int nrow = rinfo[row_of(i, US * (u % UPB) + z)].y;
+                kd[z] = a.qkv[(int64_t)nrow * a.ldq + D + L.col[j]];
+                vd[z] = a.qkv[(int64_t)nrow * a.ldq + 2 * D + L.col[j]];
+            }
         }
     };
     gather_kv(0, kq[0], vq[0]);                            // in flight during GEMM 1
@@ -491,16 +501,16 @@ __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? SAPCU_CHAIN_LB1
     }
 }
 
-template <int D, int KK>
+template <int D, int KK, bool O32>
 static int launch_chain_t(const ChainArgs& a, hipStream_t st) {
     constexpr int lds = ChainShape<D>::LDS;
     static DeviceOnce lds_once;                         // one per kernel instantiation, one bit per device
-    SAPCU_SET_MAX_LDS(lds_once, (&fn_edge_chain_kernel<D, KK>), lds);
+    SAPCU_SET_MAX_LDS(lds_once, (&fn_edge_chain_kernel<D, KK, O32>), lds);
     constexpr int PPG = ChainShape<D>::ROWS / KK;
     const int64_t ngroups = (a.P + PPG - 1) / PPG;
     const int64_t grid = ngroups < 8 ? ngroups : ((ngroups + 7) / 8) * 8;      // 8 XCD ranges of equal slot count
     SAPCU_CHECK_ARG(grid < 0x7fffffffLL, "edge_chain: too many groups");
-    hipLaunchKernelGGL((fn_edge_chain_kernel<D, KK>), dim3((unsigned)grid), dim3(ChainShape<D>::NW * 64), lds, st, a);
+    hipLaunchKernelGGL((fn_edge_chain_kernel<D, KK, O32>), dim3((unsigned)grid), dim3(ChainShape<D>::NW * 64), lds, st, a);
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
 }
@@ -517,9 +527,11 @@ int launch_fn_edge_chain(ChainArgs a, const float* patch, const int32_t* idx, in
     SAPCU_CHECK_LAUNCH();
     a.tab = tab;
     a.pd = pd;
-    if (d == 128) return launch_chain_t<128, 24>(a, st);
-    if (d == 256) return launch_chain_t<256, 18>(a, st);
-    return launch_chain_t<512, 12>(a, st);
+    // (rows x row pitch + the three column ranges) in bytes below 4 GiB: 32-bit gather offsets
+    const bool o32 = !a.wide_offsets && (uint64_t)a.P * (uint64_t)a.ldq * 4u + 3u * (uint64_t)d * 4u < (1ull << 32) && a.ldq > 0;
+    if (d == 128) return o32 ? launch_chain_t<128, 24, true>(a, st) : launch_chain_t<128, 24, false>(a, st);
+    if (d == 256) return o32 ? launch_chain_t<256, 18, true>(a, st) : launch_chain_t<256, 18, false>(a, st);
+    return o32 ? launch_chain_t<512, 12, true>(a, st) : launch_chain_t<512, 12, false>(a, st);
 }
 
 int launch_pack_chain_weights(const void* w16_hi, const void* w16_lo, int d, void* out, hipStream_t st) {

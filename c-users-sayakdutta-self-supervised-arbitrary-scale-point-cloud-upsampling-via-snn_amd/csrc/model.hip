@@ -93,6 +93,7 @@ struct sapcu_model {
     // forward never calls getenv; tests build a second handle under another environment instead of flipping it mid-process)
     bool opt_bt;               // SAPCU_BT=0: split-row GEMMs on the ring kernel only
     bool opt_chain;            // SAPCU_CHAIN=0: fn blocks as the five-kernel edge chain
+    bool opt_chain_wide;       // SAPCU_CHAIN=wide: the fused chain with 64-bit gather addresses (the form tensors >= 4 GiB take)
     bool opt_fn_maxfuse;       // SAPCU_FN_MAXFUSE=0: conv_final GEMM + rowgroup_max
     bool opt_fd_maxfuse;       // SAPCU_FD_MAXFUSE=0: multi_scale_conv GEMM + rowgroup_max
     bool opt_fd_split;         // SAPCU_FD_SPLIT=0: fd spikes as f32 rows for every step
@@ -345,7 +346,7 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
                 ca.w2p = cw + (int64_t)d * d * 2; ca.b2 = m->p(sb + B_GAMMA_B); ca.lif2 = m->p(sb + B_GAMMA_LIF);
                 ca.w3p = cw + (int64_t)2 * d * d * 2; ca.b3 = m->p(sb + B_GAMMA2_B);
                 ca.inv_sqrt_hd = 1.0f / sqrt_hd;
-                ca.res = RES; ca.res_split = SP; ca.T = 4;
+                ca.res = RES; ca.res_split = SP; ca.T = 4; ca.wide_offsets = m->opt_chain_wide ? 1 : 0;
                 SAPCU_TRY(launch_fn_edge_chain(ca, pc, idx[l], d, kk, tab, pdiff, st));
             } else {
                 // pe1 = LIF(fc_delta(x_i - x_j))                                        fn:310,355-358
@@ -848,6 +849,10 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
     m->sf16 = !(ge && strcmp(ge, "f32") == 0);
     m->opt_bt = !env_off("SAPCU_BT");
     m->opt_chain = !env_off("SAPCU_CHAIN");
+    {
+        const char* v = getenv("SAPCU_CHAIN");
+        m->opt_chain_wide = v && strcmp(v, "wide") == 0;
+    }
     m->opt_fn_maxfuse = !env_off("SAPCU_FN_MAXFUSE");
     m->opt_fd_maxfuse = !env_off("SAPCU_FD_MAXFUSE");
     m->opt_fd_split = !env_off("SAPCU_FD_SPLIT");

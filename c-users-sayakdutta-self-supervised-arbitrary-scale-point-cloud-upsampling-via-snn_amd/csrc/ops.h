@@ -39,6 +39,7 @@ struct ChainArgs {
     float* res;                // [P, d] (split rows when res_split)
     int res_split;
     int T;                     // neuron self-loop steps (4)
+    int wide_offsets;          // 1: 64-bit gather addresses even where 32-bit byte offsets would do (SAPCU_CHAIN=wide; parity tests)
 };
 bool fn_edge_chain_ok(int d, int kk);
 int launch_fn_edge_chain(ChainArgs a, const float* patch, const int32_t* idx, int d, int kk, int2* tab_ws, float4* pd_ws,

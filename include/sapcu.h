@@ -189,7 +189,7 @@ int sapcu_patch_knn(const float* feat, int64_t b, int m, int c, int ld, int k, i
  * (SAPCU_FN_SLOTS / SAPCU_FD_SLOTS entries, order fixed by packing.py and model.hip).
  * The library copies the blob; the caller may free it after the call returns.
  * A handle is immutable after creation: the environment switches (SAPCU_GEMM=f32, SAPCU_CHUNK, SAPCU_WS_BUDGET_MB and the
- * parity / ablation switches SAPCU_BT, SAPCU_CHAIN, SAPCU_FN_MAXFUSE, SAPCU_FD_MAXFUSE, SAPCU_FD_SPLIT, SAPCU_FD_FUSED = 0) are
+ * parity / ablation switches SAPCU_BT, SAPCU_CHAIN (= 0, or "wide"), SAPCU_FN_MAXFUSE, SAPCU_FD_MAXFUSE, SAPCU_FD_SPLIT, SAPCU_FD_FUSED = 0) are
  * read HERE, once; a forward never reads the environment.  Forwards of one handle (or of several) may run concurrently on
  * different streams / host threads as long as each has its own workspace; launch attributes are set once per device. */
 int sapcu_model_create(int kind, const int32_t* hparams_host, int n_hparams, const float* blob,

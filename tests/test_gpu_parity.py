@@ -1507,23 +1507,27 @@ def test_fused_edge_chain_equals_the_unfused_chain_bit_for_bit(weights, monkeypa
     activations in LDS) against the five-kernel chain (a second handle created under SAPCU_CHAIN=0): identical block outputs and normals,
     bit for bit — full groups, a ragged last group (points not a multiple of 5 / 7), one patch, M = 100 (the reference's
     default patch size) and M = 20 (block 1's kk = 20 is not a shape the fused kernel takes: that block stays unfused).
-    All three blocks (d = 128 / 256 / 512) run fused."""
+    All three blocks (d = 128 / 256 / 512) run fused.  A third handle (SAPCU_CHAIN=wide) runs the fused kernel in the form it takes
+    for q|k|v tensors of 4 GiB and more — 64-bit gather addresses instead of scalar base + 32-bit byte offsets — which no test
+    shape reaches by size: same bits again."""
     fn, _, _, _ = U.build_gpu_models_under(weights, monkeypatch, {})
     fn_unfused, _, _, _ = U.build_gpu_models_under(weights, monkeypatch, {"SAPCU_CHAIN": "0"})
+    fn_wide, _, _, _ = U.build_gpu_models_under(weights, monkeypatch, {"SAPCU_CHAIN": "wide"})
     assert fn.fused_blocks(48) == 0b111 and fn.fused_blocks(100) == 0b111 and fn_unfused.fused_blocks(48) == 0
+    assert fn_wide.fused_blocks(48) == 0b111
     assert fn.fused_blocks(20) == 0b110                      # block 1's kk = min(24, 20) is not a shape the fused kernel takes
     for nq, mpts in ((64, 48), (37, 48), (1, 48), (9, 100), (11, 20)):
         patch = U.sphere_patches(nq, mpts, skip=1200).to(U.dev())
         outs = []
-        for model in (fn, fn_unfused):
+        for model in (fn, fn_unfused, fn_wide):
             taps = {k: torch.full((nq, mpts, 64), float("nan"), device=U.dev()) for k in ("block1", "block2", "block3")}
             n = model(patch, taps=taps)
             torch.cuda.synchronize()
             outs.append((n, taps))
         for k in ("block1", "block2", "block3"):
             assert not bool(torch.isnan(outs[0][1][k]).any()), (nq, mpts, k)
-            assert torch.equal(outs[0][1][k], outs[1][1][k]), (nq, mpts, k)
-        assert torch.equal(outs[0][0], outs[1][0]), (nq, mpts)
+            assert torch.equal(outs[0][1][k], outs[1][1][k]) and torch.equal(outs[0][1][k], outs[2][1][k]), (nq, mpts, k)
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0]), (nq, mpts)
     assert fn.gemm_mode() == (True, 0)
 
 
