@@ -47,25 +47,52 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // unrolled loop 4.64; 96-row groups, three per CU (168 registers, 23 of them spilled), rolled loop 4.42; two per CU, no spill: 4.55;
 // round 3, once the t = v_j + pe adds stopped being sunk to the end of the kernel (see the first epilogue): 144 / 182 / 198
 // registers (d = 128 / 256 / 512), no scratch anywhere, three per CU again at d = 128.
-#ifndef SAPCU_CHAIN_WD
-#define SAPCU_CHAIN_WD 2
-#endif
 #ifndef SAPCU_CHAIN_LB128
-#define SAPCU_CHAIN_LB128 3
+#define SAPCU_CHAIN_LB128 2
 #endif
+// Round 3, late: the GEMMs issue v_mfma_f32_16x16x32_f16.  Same flops per cycle as the 32x32x16 shape, but the chip holds a higher
+// clock on it (profiles/micro/mfma_shape.hip: 1.82 against 1.60 GHz, two waves per SIMD, random operands), and one 16x16x32 equals
+// two chained 32x32x16 over the same 32 k values BIT FOR BIT (profiles/micro/mfma_f16_shapes_bits.hip: 0 of 51 200 outputs differ)
+// — so the unfused chain reproduces this kernel exactly by issuing its three split-f16 products per k32 step instead of per k16
+// step (gemm_sf16_ring.hip, pass-major form).  Accumulator layout of the shape: a 16 x 16 block = 4 registers per lane, lane l ->
+// column l & 15, rows 4 (l >> 4) + e: a wave tile ROWS x 32 CB is RS = ROWS / 16 row sub-blocks x CS = 2 CB column sub-blocks.
+// SLOTS.  A row of the panel is a SLOT, and which edge row sits in it is the kernel's choice: lane group g = l >> 4 owns the rows
+// 16 rs + 4 g + e, so point g of the group (g = 0..3) gets the first kk of lane group g's slots, in neighbour order — its whole
+// softmax-aggregate then runs on that lane group's own registers, no cross-lane traffic — and the slots that are left (d = 512: 4 per
+// lane group, d = 256: 14, d = 128: none) hold the group's remaining points (1 / 3 / 0) in lane-group-major order.
 template <int D> struct ChainShape {
     static constexpr int ROWS = D == 128 ? 96 : (D == 256 ? 128 : 64);
-    static constexpr int RB = ROWS / 32;              // 32-row MFMA blocks per wave tile
-    static constexpr int CB = D == 512 ? 2 : 1;       // 32-column blocks per wave
-    static constexpr int NB = RB * CB;                // accumulator blocks per wave (block b: rows i = b / CB, columns j = b % CB)
+    static constexpr int RS = ROWS / 16;              // 16-row sub-blocks of the wave tile
+    static constexpr int CB = D == 512 ? 2 : 1;       // 32 columns per wave x CB
+    static constexpr int CS = 2 * CB;                 // 16-column sub-blocks per wave
     static constexpr int NW = D / (32 * CB);          // waves per workgroup
     static constexpr int PLANE = ROWS * 64;
     static constexpr int KSTEP = 2 * PLANE;
     static constexpr int LDS = ROWS * D * 4 + ROWS * 16 + ROWS * 8;
-    static constexpr int US = 8;                      // elements per lane of one epilogue unit (d = 128 ran units of 4 while its
-                                                      // registers were short: 150 of 170 now, units of 8 are 0.1 ms per step faster)
-    static constexpr int WD = SAPCU_CHAIN_WD;                     // weight fragments this many k16 steps ahead (x CB column blocks x hi, lo) = the
-                                                      // body of the rolled k loop
+    static constexpr int US = 8;                      // elements per lane of one epilogue unit: the quads of two row sub-blocks
+};
+
+// slot (rs, g, e) -> (point of the group, neighbour); point < 0: unused slot
+template <int D, int KK> struct ChainSlots {
+    static constexpr int GS = 4 * ChainShape<D>::RS;          // slots per lane group
+    static constexpr int SP = GS - KK;                        // spare slots per lane group
+    static constexpr int NUA = (4 * SP) / KK;                 // points living in spare slots
+    static constexpr int PPG = 4 + NUA;                       // points per group
+    static constexpr int point(int rs, int g, int e) {
+        const int t = 4 * rs + e;
+        if (t < KK) return g;
+        const int p = 4 + (g * SP + t - KK) / KK;
+        return p < PPG ? p : -1;
+    }
+    static constexpr int nbr(int rs, int g, int e) {
+        const int t = 4 * rs + e;
+        return t < KK ? t : (g * SP + t - KK) % KK;
+    }
+    // where neighbour jj of spare-slot point n (= point 4 + n) sits
+    static constexpr int SP1 = SP > 0 ? SP : 1;
+    static constexpr int ua_g(int n, int jj) { return (n * KK + jj) / SP1; }
+    static constexpr int ua_rs(int n, int jj) { return (KK + (n * KK + jj) % SP1) >> 2; }
+    static constexpr int ua_e(int n, int jj) { return (KK + (n * KK + jj) % SP1) & 3; }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -85,140 +112,117 @@ __global__ __launch_bounds__(256) void edge_prep_kernel(const float* __restrict_
     pd[r] = make_float4(__fsub_rn(pi[0], pj[0]), __fsub_rn(pi[1], pj[1]), __fsub_rn(pi[2], pj[2]), 0.f);
 }
 
-// weights in fragment order: out[((cb * nk16 + s) * 2 + plane) * 64 + lane][j] = w16_plane[32 cb + (lane & 31)][16 s + 8 (lane >> 5) + j]
+// weights in fragment order of the 16x16x32 B operand:
+//   out[((cs * nk32 + s) * 2 + plane) * 64 + lane][j] = w16_plane[16 cs + (lane & 15)][32 s + 8 (lane >> 4) + j]
 __global__ __launch_bounds__(256) void pack_chain_weights_kernel(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo,
                                                                  int d, _Float16* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one 8-half fragment piece per thread
-    const int nk16 = d / 16;
-    const int64_t total = (int64_t)(d / 32) * nk16 * 2 * 64;
+    const int nk32 = d / 32;
+    const int64_t total = (int64_t)(d / 16) * nk32 * 2 * 64;
     if (t >= total) return;
     const int lane = (int)(t & 63);
     const int plane = (int)((t >> 6) & 1);
-    const int64_t cs = t >> 7;
-    const int s = (int)(cs % nk16), cb = (int)(cs / nk16);
-    const _Float16* src = (plane ? lo : hi) + (int64_t)(32 * cb + (lane & 31)) * d + 16 * s + 8 * (lane >> 5);
+    const int64_t cs_s = t >> 7;
+    const int s = (int)(cs_s % nk32), cs = (int)(cs_s / nk32);
+    const _Float16* src = (plane ? lo : hi) + (int64_t)(16 * cs + (lane & 15)) * d + 32 * s + 8 * (lane >> 4);
     *reinterpret_cast<half8*>(out + t * 8) = *reinterpret_cast<const half8*>(src);
 }
 
-// value of the lane half `hr` (0: lanes 0-31, 1: lanes 32-63) of x, in BOTH halves (lane c and lane 32+c get lane (32 hr + c)'s)
-__device__ __forceinline__ float half_bcast(float x, int hr) {
+// the 16 values of lane group `s` (lanes 16 s .. 16 s + 15) of x, in all four lane groups (s compile-time)
+__device__ __forceinline__ float group_bcast(float x, int s) {
     const unsigned a = __float_as_uint(x);
-    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
-    return __uint_as_float(hr ? r[1] : r[0]);
+    const auto r = __builtin_amdgcn_permlane16_swap(a, a, false, false);     // r[0] = groups [0,0,2,2], r[1] = [1,1,3,3]
+    const unsigned z = (s & 1) ? r[1] : r[0];
+    const auto q = __builtin_amdgcn_permlane32_swap(z, z, false, false);     // q[0] = [lo,lo], q[1] = [hi,hi]
+    return __uint_as_float((s & 2) ? q[1] : q[0]);
 }
 
-// lanes 0-31 get the lane half `ha` of a, lanes 32-63 the lane half `hb` of b (ha, hb compile-time; h = this lane's half)
-__device__ __forceinline__ float half_pick(float a, int ha, float b, int hb, int h) {
-    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-    if (ha == 0 && hb == 1) return h ? b : a;
-    if (ha == hb) {
-        const auto r = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);       // r[0] = [a.lo, b.lo], r[1] = [a.hi, b.hi]
-        return __uint_as_float(ha ? r[1] : r[0]);
-    }
-    const unsigned s = h ? ua : ub;                                                  // [b.lo, a.hi]
-    const auto r = __builtin_amdgcn_permlane32_swap(s, s, false, false);             // [b.lo, b.lo], [a.hi, a.hi]
-    return __uint_as_float(h ? r[0] : r[1]);
-}
-
-template <int CB>
+template <int CS>
 struct ChainLane {       // per-lane constants of the epilogues
-    int r32, h;
-    int col[CB];         // this lane's column of column block j
-    unsigned xw[CB][2];  // LDS byte offset of (row 4h + .., column col[j] as k) for rows with ((row>>3)&1) = 0 / 1
+    int c16, g;
+    int col[CS];         // this lane's column of column sub-block cs
+    unsigned xw[CS];     // LDS byte offset of (row 4 g, column col[cs] as k); + rs * 1024 + e * 64
 };
 
-template <int WD, int CB>
-struct ChainW {           // weight fragments of WD k16 steps x CB column blocks (hi, lo)
-    half8 wh[WD][CB], wl[WD][CB];
+template <int CS>
+struct ChainW {           // weight fragments of one k32 step x CS column sub-blocks (hi, lo)
+    half8 wh[CS], wl[CS];
 };
 
-// fragment (column block cb, k16 step s, plane) of a packed matrix: [(cb * NK16 + s) * 2 + plane][64 lanes]
+// fragment (column sub-block cs, k32 step s, plane) of a packed matrix: [(cs * NK32 + s) * 2 + plane][64 lanes]
 template <int D>
-__device__ __forceinline__ half8 chain_w_frag(const half8* __restrict__ wp, int cb, int s, int plane, int lane) {
-    return wp[(((int64_t)cb * (D / 16) + s) * 2 + plane) * 64 + lane];
+__device__ __forceinline__ half8 chain_w_frag(const half8* __restrict__ wp, int cs, int s, int plane, int lane) {
+    return wp[(((int64_t)cs * (D / 32) + s) * 2 + plane) * 64 + lane];
 }
 
-// first WD k16 steps of a GEMM's weight stream: issued well before the GEMM so that their L2 latency is covered
+// first k32 step of a GEMM's weight stream: issued well before the GEMM so that its L2 latency is covered
 template <int D>
-__device__ __forceinline__ void chain_w_prefetch(const half8* __restrict__ wp, int cb0, int lane,
-                                                 ChainW<ChainShape<D>::WD, ChainShape<D>::CB>& W) {
+__device__ __forceinline__ void chain_w_prefetch(const half8* __restrict__ wp, int cs0, int lane, ChainW<ChainShape<D>::CS>& W) {
 #pragma unroll
-    for (int s = 0; s < ChainShape<D>::WD; ++s)
-#pragma unroll
-        for (int j = 0; j < ChainShape<D>::CB; ++j) {
-            W.wh[s][j] = chain_w_frag<D>(wp, cb0 + j, s, 0, lane);
-            W.wl[s][j] = chain_w_frag<D>(wp, cb0 + j, s, 1, lane);
-        }
+    for (int j = 0; j < ChainShape<D>::CS; ++j) {
+        W.wh[j] = chain_w_frag<D>(wp, cs0 + j, 0, 0, lane);
+        W.wl[j] = chain_w_frag<D>(wp, cs0 + j, 0, 1, lane);
+    }
 }
 
+// acc[rs][cs] (+)= panel . W^T for this wave's columns.  Per k32 step the three split-f16 products (a_lo.w_hi, a_hi.w_lo, a_hi.w_hi) go
+// into each accumulator in that order — the order of the pass-major ring kernel.  The column sub-blocks are taken in two halves:
+// the weight fragments of a half are refilled IN PLACE with the next step's right behind the MFMAs that read them (unconditionally:
+// the last step re-loads its own), so a fragment is in flight for half a step while the other half's MFMAs run.
 template <int D>
-__device__ __forceinline__ void chain_gemm(const unsigned char* X, const half8* __restrict__ wp, int cb0, int lane,
-                                           ChainW<ChainShape<D>::WD, ChainShape<D>::CB>& W, f32x16 (&acc)[ChainShape<D>::NB]) {
-    constexpr int NK16 = D / 16, WD = ChainShape<D>::WD;
-    constexpr int RB = ChainShape<D>::RB, CB = ChainShape<D>::CB, NB = ChainShape<D>::NB;
+__device__ __forceinline__ void chain_gemm(const unsigned char* X, const half8* __restrict__ wp, int cs0, int lane,
+                                           ChainW<ChainShape<D>::CS>& W, f32x4 (&acc)[ChainShape<D>::RS][ChainShape<D>::CS]) {
+    constexpr int NK32 = D / 32, RS = ChainShape<D>::RS, CS = ChainShape<D>::CS, HC = CS / 2;
     constexpr int CH_PLANE = ChainShape<D>::PLANE, CH_KSTEP = ChainShape<D>::KSTEP;
-    const int r32 = lane & 31, h = lane >> 5;
-    const int sw = (r32 >> 2) & 3;                         // (row >> 2) & 3 of rows 32 i + r32
-    const unsigned char* xa = X + r32 * 64;
+    const int c16 = lane & 15, g = lane >> 4;
+    const unsigned char* xa = X + c16 * 64 + ((g ^ ((c16 >> 2) & 3)) * 16);      // A operand: row 16 rs + c16, k chunk g
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+    for (int i = 0; i < RS; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
-    // One k16 step S; SJ = its slot of the weight ring (S % WD, a compile-time value: the loop is rolled with a body of WD steps,
-    // which keeps the ring's indices static without letting the scheduler hoist all the steps' operands).  A ring slot is refilled
-    // BEHIND the MFMAs that read it, in place (no copy of the fragments).
-#define SAPCU_CHAIN_STEP_INPLACE(S, SJ)                                                                                     \
-    {                                                                                                                       \
-        const int s_ = (S);                                                                                                 \
-        const unsigned ko = (unsigned)((s_ >> 1) * CH_KSTEP + ((((s_ & 1) * 2 + h) ^ sw) * 16));                            \
-        half8 ah[RB], al[RB];                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                                                    \
-            ah[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048);                                                    \
-            al[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048 + CH_PLANE);                                         \
-        }                                                                                                                   \
-        _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                                      \
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b / CB], W.wh[SJ][b % CB], acc[b], 0, 0, 0);                 \
-        _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                                      \
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / CB], W.wl[SJ][b % CB], acc[b], 0, 0, 0);                 \
-        _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                                      \
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / CB], W.wh[SJ][b % CB], acc[b], 0, 0, 0);                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                                  \
-        /* unconditional (the last WD steps re-load the last fragment): with a branch around the loads the compiler's wait  \
-           counts at the loop head degrade to vmcnt(0), i.e. every iteration waits for the loads it has just issued */      \
-        const int sn_ = s_ + WD < NK16 ? s_ + WD : NK16 - 1;                                                                \
-        _Pragma("unroll") for (int j = 0; j < CB; ++j) {                                                                    \
-            W.wh[SJ][j] = chain_w_frag<D>(wp, cb0 + j, sn_, 0, lane);                                                       \
-            W.wl[SJ][j] = chain_w_frag<D>(wp, cb0 + j, sn_, 1, lane);                                                       \
-        }                                                                                                                   \
-    }
+        for (int j = 0; j < CS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int s0 = 0; s0 < NK16; s0 += WD) {
+    for (int s = 0; s < NK32; ++s) {
+        half8 ah[RS], al[RS];
 #pragma unroll
-        for (int sj = 0; sj < WD; ++sj) SAPCU_CHAIN_STEP_INPLACE(s0 + sj, sj)
+        for (int i = 0; i < RS; ++i) {
+            ah[i] = *reinterpret_cast<const half8*>(xa + s * CH_KSTEP + i * 1024);
+            al[i] = *reinterpret_cast<const half8*>(xa + s * CH_KSTEP + i * 1024 + CH_PLANE);
+        }
+        const int sn = s + 1 < NK32 ? s + 1 : NK32 - 1;
+#pragma unroll
+        for (int hc = 0; hc < 2; ++hc) {
+#pragma unroll
+            for (int i = 0; i < RS; ++i)
+#pragma unroll
+                for (int j = hc * HC; j < (hc + 1) * HC; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], W.wh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RS; ++i)
+#pragma unroll
+                for (int j = hc * HC; j < (hc + 1) * HC; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], W.wl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RS; ++i)
+#pragma unroll
+                for (int j = hc * HC; j < (hc + 1) * HC; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], W.wh[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = hc * HC; j < (hc + 1) * HC; ++j) {
+                W.wh[j] = chain_w_frag<D>(wp, cs0 + j, sn, 0, lane);
+                W.wl[j] = chain_w_frag<D>(wp, cs0 + j, sn, 1, lane);
+            }
+        }
     }
-#undef SAPCU_CHAIN_STEP_INPLACE
 }
 
-// write v (row = 32 i + 8 q + 4 h + u, k = this lane's column) into the panel as the split-f16 operand of the next GEMM
-template <int PLANE, int CB>
-__device__ __forceinline__ void chain_put(unsigned char* X, const ChainLane<CB>& L, int j, int i, int q, int u, float v) {
-    unsigned char* p = X + L.xw[j][q & 1] + (unsigned)(i * 2048 + q * 512 + u * 64);
-    const _Float16 hi = (_Float16)v;
-    *reinterpret_cast<_Float16*>(p) = hi;
-    *reinterpret_cast<_Float16*>(p + PLANE) = (_Float16)(v - (float)hi);
-}
-
-// two elements of one column, rows u and u + 1 of a register quad: the split with the packed conversions of gfx950 (v_cvt_pk_f16_f32:
-// one instruction per PAIR and plane instead of one per element; round-to-nearest-even like the scalar form — the same bits)
+// two elements of one column, rows e and e + 1 of a register quad, into the panel as the split-f16 operand of the next GEMM: the
+// packed conversion of gfx950 for the hi halves (v_cvt_pk_f16_f32, round-to-nearest-even like the scalar form), and each lo half
+// = f16(v - hi) as ONE instruction: v_fma_mixlo/mixhi_f16 read the f16 half in place, form -hi + v exactly (v - hi is exact in
+// f32 anyway) and round once to f16 — the bits of cvt(f32(v) - f32(hi)); the compiler does not select them here on its own
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-template <int PLANE, int CB>
-__device__ __forceinline__ void chain_put2(unsigned char* X, const ChainLane<CB>& L, int j, int i, int q, int u, float v0, float v1) {
-    unsigned char* p = X + L.xw[j][q & 1] + (unsigned)(i * 2048 + q * 512 + u * 64);
+template <int PLANE, int CS>
+__device__ __forceinline__ void chain_put2(unsigned char* X, const ChainLane<CS>& L, int cs, int rs, int e, float v0, float v1) {
+    unsigned char* p = X + L.xw[cs] + (unsigned)(rs * 1024 + e * 64);
     const f32x2 v = f32x2{v0, v1};
     const half2v hi = __builtin_convertvector(v, half2v);
-    // lo = f16(v - hi) as ONE instruction per element: v_fma_mixlo/mixhi_f16 read the f16 half in place, form -hi + v exactly
-    // (v - hi is exact in f32 anyway) and round once to f16 — the bits of cvt(f32(v) - f32(hi)); the compiler does not select
-    // them here on its own (it unpacked the pair instead)
     half2v lo;
     {
         unsigned lp;
@@ -253,17 +257,41 @@ __device__ __forceinline__ NeuronP chain_lif(const float* __restrict__ lif, int 
     return np;
 }
 
-// threads = 64 x (d / 32 / CB).  d = 128: three 256-thread workgroups per CU (51 KiB of LDS each, <= 170 registers per wave: the
-// kernel takes 144 and no scratch; three ran 1 % faster than two in the same-box A/B of round 3, 2.9 % in round 2's).
+// select by this lane's group g = 2 g1 + g0 among four values (compile-time equal ones fold away)
+__device__ __forceinline__ float group_select(float v0, float v1, float v2, float v3, bool g0, bool g1) {
+    const float a = g0 ? v1 : v0, b = g0 ? v3 : v2;
+    return g1 ? b : a;
+}
+
+// per-point softmax over the kk neighbours and aggregation with t = v_j + pe, fn_softmax_agg_kernel's operation order
+template <int KK>
+__device__ __forceinline__ float chain_softmax_agg(float (&xs)[KK], const float (&ts)[KK]) {
+    float mx = -__builtin_huge_valf();
+#pragma unroll
+    for (int jj = 0; jj < KK; ++jj) mx = fmaxf(mx, xs[jj]);
+    float den = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < KK; ++jj) {
+        xs[jj] = fast_exp(__fsub_rn(xs[jj], mx));
+        den = __fadd_rn(den, xs[jj]);
+    }
+    const float inv_den = __fdiv_rn(1.0f, den);
+    float out = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < KK; ++jj) out = __fmaf_rn(__fmul_rn(xs[jj], inv_den), ts[jj], out);
+    return out;
+}
+
+// threads = 64 x (d / 32 / CB).  d = 128: three 256-thread workgroups per CU (51 KiB of LDS each, <= 170 registers per wave).
 // O32: the q|k|v tensor is smaller than 4 GiB — the gathers address it as a scalar base + a 32-bit byte offset per lane (one add
 // per gathered element; the 64-bit form spends a 64-bit multiply-add and two adds on each).
 template <int D, int KK, bool O32>
 __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? SAPCU_CHAIN_LB128 : 1)) void fn_edge_chain_kernel(const ChainArgs a) {
     using S = ChainShape<D>;
-    constexpr int CH_ROWS = S::ROWS, RB = S::RB, CB = S::CB, NB = S::NB, CH_PLANE = S::PLANE, CH_KSTEP = S::KSTEP;
-    constexpr int PPG = CH_ROWS / KK;                      // points per group
-    constexpr int US = S::US, UPB = 16 / US;               // elements per epilogue unit, units per accumulator block
-    constexpr int NU = NB * UPB;                           // units per wave; unit u: block u / UPB, elements US (u % UPB) .. + US - 1
+    using M = ChainSlots<D, KK>;
+    constexpr int CH_ROWS = S::ROWS, RS = S::RS, CS = S::CS, CH_PLANE = S::PLANE, CH_KSTEP = S::KSTEP;
+    constexpr int PPG = M::PPG, NUA = M::NUA, SP = M::SP;
+    constexpr int NUP = RS / 2;                            // epilogue units per column sub-block: the quads of row sub-blocks 2 up, 2 up + 1
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* X = smem;
     float4* pdl = reinterpret_cast<float4*>(smem + CH_ROWS * D * 4);
@@ -272,228 +300,230 @@ __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? SAPCU_CHAIN_LB1
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cb0 = w * CB;                                // first column block of this wave
-    ChainLane<CB> L;
-    L.r32 = lane & 31;
-    L.h = lane >> 5;
-    // element (row, k = col): k32 step = column block, chunk = r32 >> 3, half = r32 & 7; (row >> 2) & 3 = (2 q + h) & 3
+    const int cs0 = w * CS;                                // first column sub-block of this wave
+    ChainLane<CS> L;
+    L.c16 = lane & 15;
+    L.g = lane >> 4;
+    const bool g0 = (L.g & 1) != 0, g1 = (L.g & 2) != 0;
+    // element (row = 16 rs + 4 g + e, k = col): k32 step = col / 32, chunk = (col % 32) / 8, half = col % 8; (row >> 2) & 3 = g
 #pragma unroll
-    for (int j = 0; j < CB; ++j) {
-        L.col[j] = 32 * (cb0 + j) + L.r32;
-#pragma unroll
-        for (int qo = 0; qo < 2; ++qo)
-            L.xw[j][qo] = (unsigned)((cb0 + j) * CH_KSTEP + L.h * 256 + (((L.r32 >> 3) ^ ((2 * qo + L.h) & 3)) * 16) + (L.r32 & 7) * 2);
+    for (int j = 0; j < CS; ++j) {
+        L.col[j] = 16 * (cs0 + j) + L.c16;
+        L.xw[j] = (unsigned)((L.col[j] >> 5) * CH_KSTEP + L.g * 256 + ((((L.col[j] >> 3) & 3) ^ L.g) * 16) + (L.col[j] & 7) * 2);
     }
-    // row of element e of row block i (this lane half)
-    auto row_of = [&](int i, int e) { return 32 * i + 8 * (e >> 2) + 4 * L.h + (e & 3); };
+    const int rowg = 4 * L.g;                              // this lane's rows: 16 rs + rowg + e
 
     // group of this workgroup: contiguous ranges of groups per XCD (blockIdx & 7), so that the tiles of one patch — which
     // gather the same q / k / v rows — share an L2
     const int64_t ngroups = (a.P + PPG - 1) / PPG;
-    int64_t g;
+    int64_t grp;
     {
         const int64_t nx = gridDim.x < 8 ? 1 : 8;
         const int64_t x = nx == 1 ? 0 : (blockIdx.x & 7), slot = nx == 1 ? blockIdx.x : (blockIdx.x >> 3);
         const int64_t qd = ngroups / nx, rem = ngroups % nx;
-        g = x * qd + (x < rem ? x : rem) + slot;
+        grp = x * qd + (x < rem ? x : rem) + slot;
         if (slot >= qd + (x < rem ? 1 : 0)) return;
     }
-    const int64_t pt0 = g * PPG;
+    const int64_t pt0 = grp * PPG;
     const int npts = (int)((a.P - pt0) < PPG ? (a.P - pt0) : PPG);
 
-    f32x16 acc[NB], pe[NB];
-    ChainW<S::WD, CB> W;
-    // ---- phase 0: edge records of the group's rows; pe1 = LIF(fc_delta(x_i - x_j)) -> panel              fn:310,355-358
-    float qp[CB][PPG];                                     // q_i of the group's points, this lane's columns
+    f32x4 acc[RS][CS], pe[RS][CS];
+    ChainW<CS> W;
+    // ---- phase 0: edge records of the group's slots; pe1 = LIF(fc_delta(x_i - x_j)) -> panel              fn:310,355-358
     if (tid < CH_ROWS) {
-        const int pl = tid / KK;
-        const bool ok = pl < npts;                                           // pad rows replay the group's first edge row
-        const int64_t er = ok ? pt0 * KK + tid : pt0 * KK;
-        const int2 t = a.tab[er];
-        if (O32) reinterpret_cast<unsigned*>(rinfo)[tid] = (unsigned)t.y * (unsigned)(a.ldq * 4);      // byte offset of the neighbour's row
-        else rinfo[tid] = t;
+        const int rs = tid >> 4, sg = (tid >> 2) & 3, e = tid & 3, t = 4 * rs + e;
+        int p, jj;
+        if (t < KK) {
+            p = sg;
+            jj = t;
+        } else {
+            const int u = sg * SP + t - KK;
+            p = 4 + u / KK;
+            jj = u % KK;
+        }
+        const bool ok = p < npts;                                            // unused slots replay the group's first edge row
+        const int64_t er = ok ? (pt0 + p) * KK + jj : pt0 * KK;
+        const int2 t2 = a.tab[er];
+        if (O32) reinterpret_cast<unsigned*>(rinfo)[tid] = (unsigned)t2.y * (unsigned)(a.ldq * 4);      // byte offset of the neighbour's row
+        else rinfo[tid] = t2;
         pdl[tid] = a.pd[er];
     }
-    {
-        // accumulator layout, like the epilogues: this lane's column(s) for its rows (the neuron parameters are per-lane
-        // constants; the position differences are LDS broadcasts)
-        float wx[CB], wy[CB], wz[CB], bd[CB];
-        NeuronP nd[CB];
+    lds_barrier();                                         // edge records are in
 #pragma unroll
-        for (int j = 0; j < CB; ++j) {
-            wx[j] = a.wd[L.col[j] * 3];
-            wy[j] = a.wd[L.col[j] * 3 + 1];
-            wz[j] = a.wd[L.col[j] * 3 + 2];
-            bd[j] = a.bd[L.col[j]];
-            nd[j] = chain_lif(a.lifd, D, L.col[j]);
-        }
-        lds_barrier();                                     // edge records are in
-        // q_i of the group's points for the first epilogue (fn:368): issued here, consumed after GEMM 1
+    for (int j = 0; j < CS; ++j) {
+        // accumulator layout, like the epilogues: this lane's column for its rows (the neuron parameters are per-lane constants;
+        // the position differences are LDS broadcasts)
+        const float wx = a.wd[L.col[j] * 3], wy = a.wd[L.col[j] * 3 + 1], wz = a.wd[L.col[j] * 3 + 2], bd = a.bd[L.col[j]];
+        const NeuronP nd = chain_lif(a.lifd, D, L.col[j]);
 #pragma unroll
-        for (int j = 0; j < CB; ++j)
+        for (int up = 0; up < NUP; ++up) {
+            float v[8];
 #pragma unroll
-            for (int p = 0; p < PPG; ++p) qp[j][p] = __builtin_nontemporal_load(&a.qkv[(pt0 + (p < npts ? p : 0)) * a.ldq + L.col[j]]);
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int b = u / UPB, i = b / CB, j = b % CB, e0 = US * (u % UPB);
-            float v[US];
-#pragma unroll
-            for (int z = 0; z < US; ++z) {
-                const float4 dd = pdl[row_of(i, e0 + z)];
-                float t0 = __fmul_rn(wx[j], dd.x);
-                t0 = __fmaf_rn(wy[j], dd.y, t0);
-                t0 = __fmaf_rn(wz[j], dd.z, t0);
-                v[z] = __fadd_rn(t0, bd[j]);
+            for (int z = 0; z < 8; ++z) {
+                const float4 dd = pdl[16 * (2 * up + (z >> 2)) + rowg + (z & 3)];
+                float t0 = __fmul_rn(wx, dd.x);
+                t0 = __fmaf_rn(wy, dd.y, t0);
+                t0 = __fmaf_rn(wz, dd.z, t0);
+                v[z] = __fadd_rn(t0, bd);
             }
-            lif_selfloop_n<US>(v, nd[j], a.T);
+            lif_selfloop_n<8>(v, nd, a.T);
 #pragma unroll
-            for (int z = 0; z < US; z += 2) chain_put2<CH_PLANE, CB>(X, L, j, i, (e0 + z) >> 2, (e0 + z) & 3, v[z], v[z + 1]);
+            for (int z = 0; z < 8; z += 2) chain_put2<CH_PLANE, CS>(X, L, j, 2 * up + (z >> 2), z & 3, v[z], v[z + 1]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     const half8* const wp1 = reinterpret_cast<const half8*>(a.w1p);
     const half8* const wp2 = reinterpret_cast<const half8*>(a.w2p);
     const half8* const wp3 = reinterpret_cast<const half8*>(a.w3p);
-    // k_j and v_j of one epilogue unit u, this lane's column of the unit's column block
-    float kq[2][US], vq[2][US];
-    auto gather_kv = [&](int u, float (&kd)[US], float (&vd)[US]) {
-        const int b = u / UPB, i = b / CB, j = b % CB;
+    // k_j and v_j of one epilogue unit (column sub-block j, row sub-blocks 2 up, 2 up + 1), this lane's column
+    float kq[2][8], vq[2][8];
+    auto gather_kv = [&](int j, int up, float (&kd)[8], float (&vd)[8]) {
 #pragma unroll
-        for (int z = 0; z < US; ++z) {
+        for (int z = 0; z < 8; ++z) {
+            const int row = 16 * (2 * up + (z >> 2)) + rowg + (z & 3);
             if (O32) {
-                const unsigned off = reinterpret_cast<const unsigned*>(rinfo)[row_of(i, US * (u % UPB) + z)] + 4u * (unsigned)L.col[j];
+                const unsigned off = reinterpret_cast<const unsigned*>(rinfo)[row] + 4u * (unsigned)L.col[j];
                 kd[z] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.qkv + D) + off);
                 vd[z] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.qkv + 2 * D) + off);
             } else {
-                const int nrow = rinfo[row_of(i, US * (u % UPB) + z)].y;
+                const int nrow = rinfo[row].y;
                 kd[z] = a.qkv[(int64_t)nrow * a.ldq + D + L.col[j]];
                 vd[z] = a.qkv[(int64_t)nrow * a.ldq + 2 * D + L.col[j]];
             }
         }
     };
-    gather_kv(0, kq[0], vq[0]);                            // in flight during GEMM 1
-    chain_w_prefetch<D>(wp1, cb0, lane, W);
+    // q_i (fn:368) of this lane's column: of lane group g's own point, and of the points that live in the spare slots
+    auto load_q = [&](int j, float& qa, float (&qu)[NUA > 0 ? NUA : 1]) {
+        qa = __builtin_nontemporal_load(&a.qkv[(pt0 + (L.g < npts ? L.g : 0)) * a.ldq + L.col[j]]);
+#pragma unroll
+        for (int n = 0; n < NUA; ++n) qu[n] = __builtin_nontemporal_load(&a.qkv[(pt0 + (4 + n < npts ? 4 + n : 0)) * a.ldq + L.col[j]]);
+    };
+    float qa[2], qu[2][NUA > 0 ? NUA : 1];
+    load_q(0, qa[0], qu[0]);
+    gather_kv(0, 0, kq[0], vq[0]);                         // in flight during GEMM 1
+    chain_w_prefetch<D>(wp1, cs0, lane, W);
     lds_barrier();                                         // pe1 panel complete
 
     // ---- GEMM 1: fc_delta2; epilogue pe = LIF(.), attn_in = q_i - k_j + pe -> panel, t = v_j + pe stays      fn:360-368
     {
-        float b1[CB];
-        NeuronP n1[CB];
-#pragma unroll
-        for (int j = 0; j < CB; ++j) {
-            b1[j] = a.b1[L.col[j]];
-            n1[j] = chain_lif(a.lif1, D, L.col[j]);
-        }
-        chain_gemm<D>(X, wp1, cb0, lane, W, acc);
+        chain_gemm<D>(X, wp1, cs0, lane, W, acc);
         lds_barrier();                                     // every wave has read the pe1 panel: it may be overwritten
         // software pipeline over the units: the gathers of unit u + 1 are issued before the neuron arithmetic of unit u
         // and consumed after the one of unit u + 1 (the in-order vector-memory counter then waits for loads that are one
         // arithmetic block old)
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int b = u / UPB, i = b / CB, j = b % CB, e0 = US * (u % UPB);
-            if (u + 1 < NU) gather_kv(u + 1, kq[(u + 1) & 1], vq[(u + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            float v[US];
+        for (int j = 0; j < CS; ++j) {
+            const float b1 = a.b1[L.col[j]];
+            const NeuronP n1 = chain_lif(a.lif1, D, L.col[j]);
+            if (j + 1 < CS) load_q(j + 1, qa[(j + 1) & 1], qu[(j + 1) & 1]);
 #pragma unroll
-            for (int z = 0; z < US; ++z) v[z] = __fmaf_rn(acc[b][e0 + z], 0.0625f, b1[j]);      // undoes the x16 of the pre-scaled weights (exact)
-            lif_selfloop_n<US>(v, n1[j], a.T);
-            __builtin_amdgcn_sched_barrier(0);
-            float ain[US];                                 // attn_in = q_i - k_j + pe
+            for (int up = 0; up < NUP; ++up) {
+                const int u = j * NUP + up;
+                if (up + 1 < NUP) gather_kv(j, up + 1, kq[(u + 1) & 1], vq[(u + 1) & 1]);
+                else if (j + 1 < CS) gather_kv(j + 1, 0, kq[(u + 1) & 1], vq[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                float v[8];
 #pragma unroll
-            for (int z = 0; z < US; ++z) {
-                // the row's point: row = 32 i + 8 q + 4 h + u, compile-time per lane half (pad rows: any point)
-                const int e = e0 + z;
-                const int r0 = 32 * i + 8 * (e >> 2) + (e & 3), r1 = r0 + 4;
-                const int p0 = r0 / KK < PPG ? r0 / KK : PPG - 1, p1 = r1 / KK < PPG ? r1 / KK : PPG - 1;
-                const float qv = p0 == p1 ? qp[j][p0] : (L.h ? qp[j][p1] : qp[j][p0]);
-                ain[z] = __fadd_rn(__fsub_rn(qv, kq[u & 1][z]), v[z]);
-                // t = v_j + pe (fn:386-389).  settle: formed HERE — left alone the compiler sank some of these adds to the softmax
-                // and kept both operands alive until then, the gathered one in scratch behind a vmcnt(0) right after its load
-                pe[b][e] = settle(__fadd_rn(vq[u & 1][z], v[z]));
+                for (int z = 0; z < 8; ++z) v[z] = __fmaf_rn(acc[2 * up + (z >> 2)][j][z & 3], 0.0625f, b1);      // undoes the x16 of the pre-scaled weights (exact)
+                lif_selfloop_n<8>(v, n1, a.T);
+                __builtin_amdgcn_sched_barrier(0);
+                float ain[8];                              // attn_in = q_i - k_j + pe
+#pragma unroll
+                for (int z = 0; z < 8; ++z) {
+                    const int rs = 2 * up + (z >> 2), e = z & 3;
+                    // the slot's point: lane group g's own point, or (spare slots) a compile-time point per lane group
+                    float qv;
+                    if (4 * rs + e < KK) {
+                        qv = qa[j & 1];
+                    } else {
+                        float c[4];
+#pragma unroll
+                        for (int sg = 0; sg < 4; ++sg) {
+                            const int p = M::point(rs, sg, e);
+                            c[sg] = p >= 4 ? qu[j & 1][p - 4 < NUA ? p - 4 : 0] : qa[j & 1];       // (unused slots: any value)
+                        }
+                        qv = group_select(c[0], c[1], c[2], c[3], g0, g1);
+                    }
+                    ain[z] = __fadd_rn(__fsub_rn(qv, kq[u & 1][z]), v[z]);
+                    // t = v_j + pe (fn:386-389).  settle: formed HERE — left alone the compiler sank some of these adds to the softmax
+                    // and kept both operands alive until then, the gathered one in scratch behind a vmcnt(0) right after its load
+                    pe[rs][j][e] = settle(__fadd_rn(vq[u & 1][z], v[z]));
+                }
+#pragma unroll
+                for (int z = 0; z < 8; z += 2) chain_put2<CH_PLANE, CS>(X, L, j, 2 * up + (z >> 2), z & 3, ain[z], ain[z + 1]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int z = 0; z < US; z += 2) chain_put2<CH_PLANE, CB>(X, L, j, i, (e0 + z) >> 2, (e0 + z) & 3, ain[z], ain[z + 1]);
-            __builtin_amdgcn_sched_barrier(0);
         }
-        chain_w_prefetch<D>(wp2, cb0, lane, W);
+        chain_w_prefetch<D>(wp2, cs0, lane, W);
     }
     lds_barrier();                                         // attn_in panel complete
     // ---- GEMM 2: fc_gamma; epilogue g = LIF(.) -> panel                                                   fn:373-376
     {
-        float b2[CB];
-        NeuronP n2[CB];
-#pragma unroll
-        for (int j = 0; j < CB; ++j) {
-            b2[j] = a.b2[L.col[j]];
-            n2[j] = chain_lif(a.lif2, D, L.col[j]);
-        }
-        chain_gemm<D>(X, wp2, cb0, lane, W, acc);
+        chain_gemm<D>(X, wp2, cs0, lane, W, acc);
         lds_barrier();
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int b = u / UPB, i = b / CB, j = b % CB, e0 = US * (u % UPB);
-            float v[US];
+        for (int j = 0; j < CS; ++j) {
+            const float b2 = a.b2[L.col[j]];
+            const NeuronP n2 = chain_lif(a.lif2, D, L.col[j]);
 #pragma unroll
-            for (int z = 0; z < US; ++z) v[z] = __fmaf_rn(acc[b][e0 + z], 0.0625f, b2[j]);
-            lif_selfloop_n<US>(v, n2[j], a.T);
+            for (int up = 0; up < NUP; ++up) {
+                float v[8];
 #pragma unroll
-            for (int z = 0; z < US; z += 2) chain_put2<CH_PLANE, CB>(X, L, j, i, (e0 + z) >> 2, (e0 + z) & 3, v[z], v[z + 1]);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int z = 0; z < 8; ++z) v[z] = __fmaf_rn(acc[2 * up + (z >> 2)][j][z & 3], 0.0625f, b2);
+                lif_selfloop_n<8>(v, n2, a.T);
+#pragma unroll
+                for (int z = 0; z < 8; z += 2) chain_put2<CH_PLANE, CS>(X, L, j, 2 * up + (z >> 2), z & 3, v[z], v[z + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        chain_w_prefetch<D>(wp3, cb0, lane, W);
+        chain_w_prefetch<D>(wp3, cs0, lane, W);
     }
     lds_barrier();                                         // g panel complete
     // ---- GEMM 3: fc_gamma2; per-point softmax over the kk neighbours, aggregation with v_j + pe           fn:378-389
     {
-        chain_gemm<D>(X, wp3, cb0, lane, W, acc);
+        chain_gemm<D>(X, wp3, cs0, lane, W, acc);
 #pragma unroll
-        for (int j = 0; j < CB; ++j) {
+        for (int j = 0; j < CS; ++j) {
             const float b3 = a.b3[L.col[j]];
             // own rows: x = (a + b) / sqrt(hd) in place of the accumulators (pe already holds t = v_j + pe)
 #pragma unroll
-            for (int i = 0; i < RB; ++i)
+            for (int i = 0; i < RS; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    acc[i * CB + j][e] = __fmul_rn(__fmaf_rn(acc[i * CB + j][e], 0.0625f, b3), a.inv_sqrt_hd);
-            // per point: its kk rows alternate between the lane halves in quads.  Points are taken in PAIRS: lane half 0 runs the
-            // neighbour-ordered sums (fn_softmax_agg_kernel's operation order) of point pp, half 1 those of point pp + 1, each
-            // half fetching its point's values from whichever half holds them (an odd last point: both halves, as before r3 —
-            // every point used to be summed by both halves).
-#pragma unroll
-            for (int pp = 0; pp < PPG; pp += 2) {
-                const bool pair = pp + 1 < PPG;            // compile-time after unrolling
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = __fmul_rn(__fmaf_rn(acc[i][j][e], 0.0625f, b3), a.inv_sqrt_hd);
+            // lane group g's own point: its kk rows are this lane's registers, in neighbour order
+            {
                 float xs[KK], ts[KK];
 #pragma unroll
                 for (int jj = 0; jj < KK; ++jj) {
-                    const int r = pp * KK + jj, i = r >> 5, rr = r & 31;
-                    const int e = ((rr >> 3) << 2) | (rr & 3), hr = (rr >> 2) & 1;
-                    if (pair) {
-                        const int r1 = r + KK, i1 = r1 >> 5, rr1 = r1 & 31;
-                        const int e1 = ((rr1 >> 3) << 2) | (rr1 & 3), hr1 = (rr1 >> 2) & 1;
-                        xs[jj] = half_pick(acc[i * CB + j][e], hr, acc[i1 * CB + j][e1], hr1, L.h);
-                        ts[jj] = half_pick(pe[i * CB + j][e], hr, pe[i1 * CB + j][e1], hr1, L.h);
-                    } else {
-                        xs[jj] = half_bcast(acc[i * CB + j][e], hr);
-                        ts[jj] = half_bcast(pe[i * CB + j][e], hr);
-                    }
+                    xs[jj] = acc[jj >> 2][j][jj & 3];
+                    ts[jj] = pe[jj >> 2][j][jj & 3];
                 }
-                float mx = -__builtin_huge_valf();
-#pragma unroll
-                for (int jj = 0; jj < KK; ++jj) mx = fmaxf(mx, xs[jj]);
-                float den = 0.f;
+                const float out = chain_softmax_agg<KK>(xs, ts);
+                if (L.g < npts) {
+                    const int64_t pt = pt0 + L.g;
+                    if (a.res_split) chain_store_split_nt(a.res, pt, D, L.col[j], out);
+                    else __builtin_nontemporal_store(out, &a.res[pt * D + L.col[j]]);
+                }
+            }
+            // the points in the spare slots: point 4 + n is summed by lane group n, which fetches the point's values from the lane
+            // groups that hold them (two swaps per value and source; a value no lane group asks for costs nothing)
+            if (NUA > 0) {
+                float xs[KK], ts[KK];
 #pragma unroll
                 for (int jj = 0; jj < KK; ++jj) {
-                    xs[jj] = fast_exp(__fsub_rn(xs[jj], mx));
-                    den = __fadd_rn(den, xs[jj]);
-                }
-                const float inv_den = __fdiv_rn(1.0f, den);
-                float out = 0.f;
+                    float cx[4] = {0.f, 0.f, 0.f, 0.f}, ct[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int jj = 0; jj < KK; ++jj) out = __fmaf_rn(__fmul_rn(xs[jj], inv_den), ts[jj], out);
-                const int p = pair ? pp + L.h : pp;        // this half's point
-                if (p < npts && (pair || L.h == 0)) {
-                    const int64_t pt = pt0 + p;
+                    for (int n = 0; n < NUA; ++n) {
+                        const int rs = M::ua_rs(n, jj), e = M::ua_e(n, jj), sg = M::ua_g(n, jj);
+                        cx[n] = group_bcast(acc[rs][j][e], sg);
+                        ct[n] = group_bcast(pe[rs][j][e], sg);
+                    }
+                    xs[jj] = NUA == 1 ? cx[0] : group_select(cx[0], cx[1], cx[2], cx[3], g0, g1);
+                    ts[jj] = NUA == 1 ? ct[0] : group_select(ct[0], ct[1], ct[2], ct[3], g0, g1);
+                }
+                const float out = chain_softmax_agg<KK>(xs, ts);
+                if (L.g < NUA && 4 + L.g < npts) {
+                    const int64_t pt = pt0 + 4 + L.g;
                     if (a.res_split) chain_store_split_nt(a.res, pt, D, L.col[j], out);
                     else __builtin_nontemporal_store(out, &a.res[pt * D + L.col[j]]);
                 }
@@ -507,7 +537,7 @@ static int launch_chain_t(const ChainArgs& a, hipStream_t st) {
     constexpr int lds = ChainShape<D>::LDS;
     static DeviceOnce lds_once;                         // one per kernel instantiation, one bit per device
     SAPCU_SET_MAX_LDS(lds_once, (&fn_edge_chain_kernel<D, KK, O32>), lds);
-    constexpr int PPG = ChainShape<D>::ROWS / KK;
+    constexpr int PPG = ChainSlots<D, KK>::PPG;
     const int64_t ngroups = (a.P + PPG - 1) / PPG;
     const int64_t grid = ngroups < 8 ? ngroups : ((ngroups + 7) / 8) * 8;      // 8 XCD ranges of equal slot count
     SAPCU_CHECK_ARG(grid < 0x7fffffffLL, "edge_chain: too many groups");
@@ -536,7 +566,7 @@ int launch_fn_edge_chain(ChainArgs a, const float* patch, const int32_t* idx, in
 }
 
 int launch_pack_chain_weights(const void* w16_hi, const void* w16_lo, int d, void* out, hipStream_t st) {
-    const int64_t total = (int64_t)(d / 32) * (d / 16) * 2 * 64;
+    const int64_t total = (int64_t)(d / 16) * (d / 32) * 2 * 64;
     hipLaunchKernelGGL(pack_chain_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        (const _Float16*)w16_hi, (const _Float16*)w16_lo, d, (_Float16*)out);
     SAPCU_CHECK_LAUNCH();

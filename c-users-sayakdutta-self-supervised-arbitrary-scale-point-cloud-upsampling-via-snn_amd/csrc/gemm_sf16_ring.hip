@@ -242,6 +242,37 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
                 for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
             for (int kt = 0; kt < nk; ++kt, ++gstep) {
                 read_frags(ca, cw, 1, f1);                          // second half of this step: lands behind mfma6(f0)
+                if (g.pass_major) {
+                    // PASS-MAJOR form (parity path only: the unfused edge chain under SAPCU_CHAIN=0): per k32 step and accumulator
+                    // a_lo.w_hi over both k16 halves, then a_hi.w_lo, then a_hi.w_hi — the accumulation order of a kernel that issues
+                    // one v_mfma_f32_16x16x32_f16 per product (fn_edge_chain.hip): two chained 32x32x16 over the same 32 k values
+                    // equal one 16x16x32 bit for bit (profiles/micro/mfma_f16_shapes_bits.hip)
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.al, f0.wh[0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.al, f0.wh[1], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.al, f1.wh[0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.al, f1.wh[1], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.ah, f0.wl[0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.ah, f0.wl[1], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.ah, f1.wl[0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.ah, f1.wl[1], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.ah, f0.wh[0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.ah, f0.wh[1], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.ah, f1.wh[0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.ah, f1.wh[1], acc[1], 0, 0, 0);
+                    if (gstep + 1 < total_steps) {
+                        wait_landed(gstep + 1);
+                        lds_barrier();
+                        if (issued < total_steps) issue();
+                        read_frags(na, nw, 0, f0);
+                    } else {
+                        lds_barrier();
+                    }
+                    ca = na;
+                    cw = nw;
+                    if (++na == RA_SLOTS) na = 0;
+                    if (++nw == RW_SLOTS) nw = 0;
+                    continue;
+                }
                 mfma6(f0);
                 if (gstep + 1 < total_steps) {
                     wait_landed(gstep + 1);
