@@ -19,7 +19,7 @@ contiguously over the ranks, one all-gather of the refined cloud per step; the d
 the extra object "strong_scaling" so that the driver's N = 1, 2, 4, 8 runs give a strong-scaling curve too.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel (fn_edge_chain_kernel<512, 12>: block 3 of fn, its whole per-edge chain fn/snn_coder.py:355-389
+  roofline      the dominant kernel (fn_edge_chain_kernel<512, 12, .>: block 3 of fn, its whole per-edge chain fn/snn_coder.py:355-389
                 in one launch), launched alone through its C-ABI entry between two events on the current stream: achieved =
                 issued f16 MFMA TFLOP/s against the 2.5 PFLOP/s dense peak; beside it SURVEY.md 8(d)'s fp32-MFMA model figure,
                 the VALU neuron-loop rate against its measured floor, HBM bytes per launch and per step from the committed
@@ -98,11 +98,12 @@ def recorded_pmc():
 
 # algorithmic HBM bytes per query = 2 x 576 B patches in + 16 B out + ~410 B outer-kNN share
 ALGO_BYTES_PER_QUERY = 2 * 576 + 16 + 410
+DOMINANT_KERNEL = "fn_edge_chain_kernel<512, 12, true>"      # rocprofv3's name (third argument: 32-bit gather offsets)
 NEURON_FLOOR_NS_PER_1000 = 1.51       # profiles/micro/lif_rate.hip on MI355X: the 4-step LIF loop alone, 2 waves per SIMD
 
 
 def roofline_leg(dev, reps=5):
-    """Time the dominant kernel alone: fn_edge_chain_kernel<512, 12> (csrc/fn_edge_chain.hip; 40 % of the step's GPU time) — block 3
+    """Time the dominant kernel alone: fn_edge_chain_kernel<512, 12, .> (csrc/fn_edge_chain.hip; 40 % of the step's GPU time) — block 3
     of fn, the whole per-edge chain (fn/snn_coder.py:355-389: pe1 -> fc_delta2 -> attn_in -> fc_gamma -> fc_gamma2 ->
     softmax-aggregate) of one 4096-patch batch in ONE launch — through its C-ABI entry, on the current stream between two events.
 
@@ -156,7 +157,7 @@ def roofline_leg(dev, reps=5):
     recs, src = recorded_pmc()
     traffic, busy, step_traffic = None, None, None
     if recs is not None:
-        rec = recs.get("fn_edge_chain_kernel<512, 12>")
+        rec = recs.get(DOMINANT_KERNEL)
         if rec:
             traffic, busy = float(rec["hbm_bytes_per_launch"]), rec.get("mfma_busy_frac")
         st = recs.get("_step")
@@ -169,7 +170,7 @@ def roofline_leg(dev, reps=5):
     ns_per_1000 = avg_s * 1e9 / (elems / 1000.0)
     return {"bound": "mfma", "achieved": round(issued / avg_s / 1e12, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(issued / avg_s / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
-            "traffic": traffic, "traffic_source": src, "kernel": "fn_edge_chain_kernel<512, 12>",
+            "traffic": traffic, "traffic_source": src, "kernel": DOMINANT_KERNEL,
             "avg_launch_ms": round(avg_s * 1e3, 4), "launches_timed": reps,
             "flops_per_launch": {"algorithmic": flop, "issued_f16": issued},
             "algorithmic_tflops": round(flop / avg_s / 1e12, 2),

@@ -16,17 +16,18 @@
 // ds_read_b128).  Nothing of the chain reaches HBM: the kernel reads xyz differences + neighbour rows (24 B per edge row), the
 // q / k / v rows of the patch (L2) and the pre-packed weights (L2), and writes res [points, d].
 //
-// Shape of the work.  d/32 waves per workgroup; wave w owns output columns 32w .. 32w+31 of all three GEMMs and all ROWS rows:
-// wave tile ROWS x 32 = 3 / 4 MFMA blocks of 32x32 (d = 512: d/64 waves, 64 x 64 = 4 blocks).  A wave's weight fragments are not shared with any other wave,
-// so they bypass LDS: pre-packed at model build in fragment order (one contiguous KiB per (column block, k16, plane)),
-// streamed L2 -> registers two k16 steps ahead.  No barrier inside a GEMM; six workgroup barriers per group.
-// The epilogues run in the accumulator layout (lane = column: bias and neuron parameters are per-lane constants; register
-// e of block i = row 32i + 8(e>>2) + 4h + (e&3)), pe stays in registers until the aggregation, the per-point softmax gets
-// its rows from the two lane halves with v_permlane32_swap and sums them in neighbour order — every value equals the
-// unfused chain's bit for bit (same split-f16 products in the same order, same neuron arithmetic, same softmax order).
-// d = 128: 256-thread workgroups, 51 KiB of LDS, two per CU (192 registers, see the kernel).  d = 256: 512 threads, 131 KiB, one per CU.  d = 512: 512
-// threads (wave tile 64 x 64), 131 KiB.  The k loops are rolled (two k16 steps per iteration).  What bounds them (each pipe at its practical rate, the
-// kernel time their sum) and the overlap designs that were measured without gain: DESIGN.md section 4.1c.
+// Shape of the work.  d/32 waves per workgroup (d = 512: d/64); wave w owns 32 (64) output columns of all three GEMMs and all ROWS rows.
+// A wave's weight fragments are not shared with any other wave, so they bypass LDS: pre-packed at model build in fragment order (one
+// contiguous KiB per (column sub-block, k32 step, plane)), streamed L2 -> registers half a k32 step ahead.  No barrier inside a GEMM;
+// six workgroup barriers per group.  The GEMMs issue v_mfma_f32_16x16x32_f16 (see ChainShape below: why, and why the results still equal
+// the unfused chain's bit for bit).  The epilogues run in the accumulator layout (lane = column: bias and neuron parameters are
+// per-lane constants; register e of sub-block (rs, cs) = row 16 rs + 4 (lane >> 4) + e), pe stays in registers until the aggregation,
+// and the panel's rows are SLOTS dealt so that a point's kk rows sit in ONE lane group: the per-point softmax of the first four points
+// of a group reads nothing but its own lane's registers — every value equals the unfused chain's bit for bit (same split-f16 products
+// in the same order, same neuron arithmetic, same softmax order).
+// d = 128: 256-thread workgroups, 51 KiB of LDS, two per CU.  d = 256: 512 threads, 131 KiB, one per CU.  d = 512: 512 threads (wave
+// tile 64 x 64), 131 KiB.  What bounds them (each pipe at its practical rate, the kernel time their sum) and the overlap designs that
+// were measured without gain: DESIGN.md section 4.1c.
 #include "common.h"
 #include "gemm_epi.h"
 #include "ops.h"
@@ -34,19 +35,13 @@
 namespace sapcu {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-// Shape of a workgroup's work.  ROWS = MFMA rows per group = whole points: d = 128: 96 rows = 4 points of 24 neighbours (no idle
-// row; 51 KiB of LDS; two 4-wave workgroups per CU at 192 registers per wave), d = 256: 128 rows = 7 points of 18 (one 8-wave
-// workgroup, 256 registers), d = 512: 64 rows = 5 points of 12 (a 128-row panel of 512 columns would be 256 KiB; one 8-wave
-// workgroup, 256 registers).  One plane of one k32 step is [ROWS][32 halves]; a k32 step = hi plane | lo plane.  A wave owns CB
-// column blocks of 32 and all ROWS rows: RB x CB accumulator blocks.  CB = 2 at d = 512 (wave tile 64 x 64): half the LDS
-// fragment reads of a 16-wave form and room for t = v + pe in registers (the 16-wave form, 128 registers per wave, parked it in
-// scratch: 10 GB of HBM traffic per step).  Measured, ms per launch at 4096 x 48 points — d = 512: 16 waves 17.3; 16 waves with
-// the weight ring refilled in place and unconditionally (exact wait counts in the rolled k loop) 17.2; 8 waves, same loop 16.6;
-// 8 waves, epilogue units of 8 elements 16.3 (before the wait counts were exact the 8-wave form lost: 18.4 against 17.6).
-// d = 256: fully unrolled k loop 8.27, rolled 8.10.  d = 128: 128-row groups (5 points + 8 idle rows), two workgroups per CU,
-// unrolled loop 4.64; 96-row groups, three per CU (168 registers, 23 of them spilled), rolled loop 4.42; two per CU, no spill: 4.55;
-// round 3, once the t = v_j + pe adds stopped being sunk to the end of the kernel (see the first epilogue): 144 / 182 / 198
-// registers (d = 128 / 256 / 512), no scratch anywhere, three per CU again at d = 128.
+// Shape of a workgroup's work.  ROWS = MFMA rows per group: d = 128: 96 rows = 4 points of 24 neighbours (no idle row), d = 256: 128
+// rows = 7 points of 18, d = 512: 64 rows = 5 points of 12 (a 128-row panel of 512 columns would be 256 KiB).  One plane of one k32
+// step is [ROWS][32 halves]; a k32 step = hi plane | lo plane.
+// History of the 32x32x16 form this replaced (ms per launch at 4096 x 48 points) — d = 512: 16 waves 17.3; 8 waves, exact wait counts
+// in the rolled k loop, epilogue units of 8 elements 16.3; t = v_j + pe pinned to the first epilogue (no scratch) + softmax in point
+// pairs + packed panel conversions + 32-bit gather offsets 15.2; this form 13.7.  d = 256: 8.27 -> 8.10 -> 7.56 -> 7.4.  d = 128:
+// 4.64 -> 4.42 -> 3.93 -> 4.0 (two workgroups per CU here: a k32 step's operand fragments are 48 registers, three per CU would spill).
 #ifndef SAPCU_CHAIN_LB128
 #define SAPCU_CHAIN_LB128 2
 #endif

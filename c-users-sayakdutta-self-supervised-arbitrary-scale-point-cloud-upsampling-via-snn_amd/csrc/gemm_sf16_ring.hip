@@ -64,7 +64,9 @@ __device__ __forceinline__ void wait_vm() {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int EPI, bool VEC>
+// PM: the pass-major accumulation order (see the k loop); a template parameter — as a run-time branch in the loop it cost the default
+// form a third of its speed.  Instantiated for the three epilogues of the unfused edge chain only.
+template <int EPI, bool VEC, bool PM = false>
 __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     const int RA_SLOTS = g.k <= 128 ? 6 : 5, RW_SLOTS = RING_SLOTS - RA_SLOTS;     // wave-uniform
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
                 for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
             for (int kt = 0; kt < nk; ++kt, ++gstep) {
                 read_frags(ca, cw, 1, f1);                          // second half of this step: lands behind mfma6(f0)
-                if (g.pass_major) {
+                if (PM) {
                     // PASS-MAJOR form (parity path only: the unfused edge chain under SAPCU_CHAIN=0): per k32 step and accumulator
                     // a_lo.w_hi over both k16 halves, then a_hi.w_lo, then a_hi.w_hi — the accumulation order of a kernel that issues
                     // one v_mfma_f32_16x16x32_f16 per product (fn_edge_chain.hip): two chained 32x32x16 over the same 32 k values
@@ -397,15 +399,15 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
     }
 }
 
-template <int EPI, bool VEC>
+template <int EPI, bool VEC, bool PM = false>
 static int launch_ring_tv(const GemmArgs& g, hipStream_t st) {
     static DeviceOnce lds_once;                         // one per kernel instantiation, one bit per device
-    SAPCU_SET_MAX_LDS(lds_once, (&gemm_ring_kernel<EPI, VEC>), RING_LDS_BYTES);
+    SAPCU_SET_MAX_LDS(lds_once, (&gemm_ring_kernel<EPI, VEC, PM>), RING_LDS_BYTES);
     const int g_num_cus_ring = device_cu_count();
     const int row_step = RBM;
     const int64_t tiles = ((g.r + row_step - 1) / row_step) * ((g.n + RBN - 1) / RBN);
     const int64_t grid = tiles < g_num_cus_ring ? tiles : g_num_cus_ring;
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, VEC>), dim3((unsigned)grid), dim3(1024), RING_LDS_BYTES, st, g);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, VEC, PM>), dim3((unsigned)grid), dim3(1024), RING_LDS_BYTES, st, g);
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
 }
@@ -424,6 +426,10 @@ template <int EPI>
 static int launch_ring_t(const GemmArgs& g, hipStream_t st) {
     return ring_vec_ok(g) ? launch_ring_tv<EPI, true>(g, st) : launch_ring_tv<EPI, false>(g, st);
 }
+template <int EPI>
+static int launch_ring_pm(const GemmArgs& g, hipStream_t st) {      // pass-major accumulation (the unfused edge chain's GEMMs)
+    return ring_vec_ok(g) ? launch_ring_tv<EPI, true, true>(g, st) : launch_ring_tv<EPI, false, true>(g, st);
+}
 
 int launch_gemm_sf16_ring(const GemmArgs& g, hipStream_t st) {
     if (g.r == 0 || g.n == 0) return SAPCU_OK;
@@ -434,6 +440,16 @@ int launch_gemm_sf16_ring(const GemmArgs& g, hipStream_t st) {
                     "gemm_ring: operands must be 16-byte aligned with lda %% 8 == 0 (lda=%d)", g.lda);
     if (g.epi == EPI_LIF || g.epi == EPI_LIF_ATTN) SAPCU_CHECK_ARG(g.lif, "gemm_ring: missing neuron parameters");
     if (g.epi == EPI_RESID || g.epi == EPI_RESID_GELU) SAPCU_CHECK_ARG(g.resid, "gemm_ring: missing residual");
+    if (g.pass_major) {
+        switch (g.epi) {
+            case EPI_BIAS: return launch_ring_pm<EPI_BIAS>(g, st);
+            case EPI_LIF: return launch_ring_pm<EPI_LIF>(g, st);
+            case EPI_LIF_ATTN:
+                SAPCU_CHECK_ARG(g.ldq > 0 && g.tab && g.q && g.kf && g.c2, "gemm_ring: bad attn operands");
+                return launch_ring_pm<EPI_LIF_ATTN>(g, st);
+            default: set_error("gemm_ring: no pass-major form of epilogue %d", g.epi); return SAPCU_ERR_ARG;
+        }
+    }
     switch (g.epi) {
         case EPI_BIAS: return launch_ring_t<EPI_BIAS>(g, st);
         case EPI_LIF: return launch_ring_t<EPI_LIF>(g, st);
