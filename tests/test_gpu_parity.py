@@ -1830,3 +1830,36 @@ def test_bench_gpus_2_as_a_plain_command_rehearsal():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["rehearsal"] is True and line["scaling"] == "weak" and line["value"] > 0
     assert line["strong_scaling"]["seeds"] == 385582 and line["strong_scaling"]["n_gpus"] == 2
+
+
+# ---------------------------------------------------------------------------------------------
+# Hardware rounding facts the kernels rely on (round 3).  The parity tests above would catch a violation indirectly; these say
+# which fact broke.
+# ---------------------------------------------------------------------------------------------
+def _build_and_run_micro(name, tmp_path):
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "micro", name + ".hip")
+    exe = str(tmp_path / name)
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", src, "-o", exe], check=True, capture_output=True, timeout=600)
+    return subprocess.run([exe], check=True, capture_output=True, text=True, timeout=120).stdout
+
+
+def test_f32_mfma_is_a_k_ascending_fma_chain(tmp_path):
+    """The in-patch kNN scores are DEFINED as one channel-ascending f32 FMA chain per pair (oracle/snn_path.py); patch_knn_kernel
+    and the fused fd encoder compute them with v_mfma_f32_16x16x4_f32.  That is exact only because the instruction adds its
+    k products in ascending k with one IEEE rounding each (profiles/micro/mfma_f32_exact.hip)."""
+    out = _build_and_run_micro("mfma_f32_exact", tmp_path)
+    assert "32x32x2_f32, K = 256, 1024 outputs: differ from the k-ascending FMA chain 0," in out, out
+    assert "16x16x4_f32, K = 256, 256 outputs: differ from the k-ascending FMA chain 0" in out, out
+
+
+def test_one_16x16x32_f16_mfma_equals_two_chained_32x32x16(tmp_path):
+    """fn_edge_chain.hip issues v_mfma_f32_16x16x32_f16, the unfused chain's ring kernel two chained 32x32x16 per product: their
+    bit-identity (test_fused_edge_chain_equals_the_unfused_chain_bit_for_bit) rests on the two shapes rounding alike
+    (profiles/micro/mfma_f16_shapes_bits.hip)."""
+    out = _build_and_run_micro("mfma_f16_shapes_bits", tmp_path)
+    assert "two chained 32x32x16 vs one 16x16x32 differ in 0 " in out, out
