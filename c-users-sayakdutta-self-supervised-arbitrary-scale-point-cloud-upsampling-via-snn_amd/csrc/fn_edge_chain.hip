@@ -25,7 +25,7 @@
 // and the panel's rows are SLOTS dealt so that a point's kk rows sit in ONE lane group: the per-point softmax of the first four points
 // of a group reads nothing but its own lane's registers — every value equals the unfused chain's bit for bit (same split-f16 products
 // in the same order, same neuron arithmetic, same softmax order).
-// d = 128: 256-thread workgroups, 51 KiB of LDS, two per CU.  d = 256: 512 threads, 131 KiB, one per CU.  d = 512: 512 threads (wave
+// d = 128: 256-thread workgroups, 51 KiB of LDS, three per CU.  d = 256: 512 threads, 131 KiB, one per CU.  d = 512: 512 threads (wave
 // tile 64 x 64), 131 KiB.  What bounds them (each pipe at its practical rate, the kernel time their sum) and the overlap designs that
 // were measured without gain: DESIGN.md section 4.1c.
 #include "common.h"
@@ -41,9 +41,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // History of the 32x32x16 form this replaced (ms per launch at 4096 x 48 points) — d = 512: 16 waves 17.3; 8 waves, exact wait counts
 // in the rolled k loop, epilogue units of 8 elements 16.3; t = v_j + pe pinned to the first epilogue (no scratch) + softmax in point
 // pairs + packed panel conversions + 32-bit gather offsets 15.2; this form 13.7.  d = 256: 8.27 -> 8.10 -> 7.56 -> 7.4.  d = 128:
-// 4.64 -> 4.42 -> 3.93 -> 4.0 (two workgroups per CU here: a k32 step's operand fragments are 48 registers, three per CU would spill).
+// 4.64 -> 4.42 -> 3.93 -> 3.8 (three workgroups per CU: the k32 step's operand fragments half the row sub-blocks at a time, 160 registers).
 #ifndef SAPCU_CHAIN_LB128
-#define SAPCU_CHAIN_LB128 2
+#define SAPCU_CHAIN_LB128 3
 #endif
 // Round 3, late: the GEMMs issue v_mfma_f32_16x16x32_f16.  Same flops per cycle as the 32x32x16 shape, but the chip holds a higher
 // clock on it (profiles/micro/mfma_shape.hip: 1.82 against 1.60 GHz, two waves per SIMD, random operands), and one 16x16x32 equals
@@ -175,6 +175,53 @@ __device__ __forceinline__ void chain_gemm(const unsigned char* X, const half8* 
     for (int i = 0; i < RS; ++i)
 #pragma unroll
         for (int j = 0; j < CS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (D == 128) {
+        // d = 128 (three workgroups per CU: <= 170 registers): the operand fragments of HALF the row sub-blocks at a time (24 registers
+        // instead of 48); a column sub-block's weight fragments are refilled behind the second half's MFMAs that read them — only a
+        // quarter step of lead, which the three waves of a SIMD cover for each other.
+        constexpr int RH = RS / 2;
+#pragma unroll 1
+        for (int s = 0; s < NK32; ++s) {
+            const int sn = s + 1 < NK32 ? s + 1 : NK32 - 1;
+#pragma unroll
+            for (int rc = 0; rc < 2; ++rc) {
+                half8 ah[RH], al[RH];
+#pragma unroll
+                for (int i = 0; i < RH; ++i) {
+                    ah[i] = *reinterpret_cast<const half8*>(xa + s * CH_KSTEP + (rc * RH + i) * 1024);
+                    al[i] = *reinterpret_cast<const half8*>(xa + s * CH_KSTEP + (rc * RH + i) * 1024 + CH_PLANE);
+                }
+#pragma unroll
+                for (int hc = 0; hc < 2; ++hc) {
+#pragma unroll
+                    for (int i = 0; i < RH; ++i)
+#pragma unroll
+                        for (int j = hc * HC; j < (hc + 1) * HC; ++j)
+                            acc[rc * RH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], W.wh[j], acc[rc * RH + i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < RH; ++i)
+#pragma unroll
+                        for (int j = hc * HC; j < (hc + 1) * HC; ++j)
+                            acc[rc * RH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], W.wl[j], acc[rc * RH + i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < RH; ++i)
+#pragma unroll
+                        for (int j = hc * HC; j < (hc + 1) * HC; ++j)
+                            acc[rc * RH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], W.wh[j], acc[rc * RH + i][j], 0, 0, 0);
+                    if (rc == 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = hc * HC; j < (hc + 1) * HC; ++j) {
+                            W.wh[j] = chain_w_frag<D>(wp, cs0 + j, sn, 0, lane);
+                            W.wl[j] = chain_w_frag<D>(wp, cs0 + j, sn, 1, lane);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return;
+    }
 #pragma unroll 1
     for (int s = 0; s < NK32; ++s) {
         half8 ah[RS], al[RS];
