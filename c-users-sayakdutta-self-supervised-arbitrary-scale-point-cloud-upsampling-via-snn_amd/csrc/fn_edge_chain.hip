@@ -336,7 +336,11 @@ __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? SAPCU_CHAIN_LB1
     constexpr int NUP = RS / 2;                            // epilogue units per column sub-block: the quads of row sub-blocks 2 up, 2 up + 1
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* X = smem;
-    float4* pdl = reinterpret_cast<float4*>(smem + CH_ROWS * D * 4);
+    // position differences of the group's slots, one array per coordinate: the four rows of a register quad are 16 contiguous bytes,
+    // and two neighbouring rows one operand pair of the packed arithmetic
+    float* pdx = reinterpret_cast<float*>(smem + CH_ROWS * D * 4);
+    float* pdy = pdx + CH_ROWS;
+    float* pdz = pdy + CH_ROWS;
     int2* rinfo = reinterpret_cast<int2*>(smem + CH_ROWS * D * 4 + CH_ROWS * 16);
 
     const int tid = threadIdx.x;
@@ -388,7 +392,10 @@ __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? SAPCU_CHAIN_LB1
         const int2 t2 = a.tab[er];
         if (O32) reinterpret_cast<unsigned*>(rinfo)[tid] = (unsigned)t2.y * (unsigned)(a.ldq * 4);      // byte offset of the neighbour's row
         else rinfo[tid] = t2;
-        pdl[tid] = a.pd[er];
+        const float4 dv = a.pd[er];
+        pdx[tid] = dv.x;
+        pdy[tid] = dv.y;
+        pdz[tid] = dv.z;
     }
     lds_barrier();                                         // edge records are in
 #pragma unroll
@@ -401,12 +408,17 @@ __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? SAPCU_CHAIN_LB1
         for (int up = 0; up < NUP; ++up) {
             float v[8];
 #pragma unroll
-            for (int z = 0; z < 8; ++z) {
-                const float4 dd = pdl[16 * (2 * up + (z >> 2)) + rowg + (z & 3)];
-                float t0 = __fmul_rn(wx, dd.x);
-                t0 = __fmaf_rn(wy, dd.y, t0);
-                t0 = __fmaf_rn(wz, dd.z, t0);
-                v[z] = __fadd_rn(t0, bd);
+            for (int hq = 0; hq < 2; ++hq) {               // the two quads of the unit; element-wise mul, fma, fma, add as fn_pe1_kernel
+                const int r0 = 16 * (2 * up + hq) + rowg;
+                const float4 qx = *reinterpret_cast<const float4*>(pdx + r0), qy = *reinterpret_cast<const float4*>(pdy + r0),
+                             qz = *reinterpret_cast<const float4*>(pdz + r0);
+                const f32x2 wx2 = f32x2{wx, wx}, wy2 = f32x2{wy, wy}, wz2 = f32x2{wz, wz}, bd2 = f32x2{bd, bd};
+                const f32x2 ta = pk_fma(wz2, f32x2{qz.x, qz.y}, pk_fma(wy2, f32x2{qy.x, qy.y}, wx2 * f32x2{qx.x, qx.y})) + bd2;
+                const f32x2 tb = pk_fma(wz2, f32x2{qz.z, qz.w}, pk_fma(wy2, f32x2{qy.z, qy.w}, wx2 * f32x2{qx.z, qx.w})) + bd2;
+                v[4 * hq] = ta.x;
+                v[4 * hq + 1] = ta.y;
+                v[4 * hq + 2] = tb.x;
+                v[4 * hq + 3] = tb.y;
             }
             lif_selfloop_n<8>(v, nd, a.T);
 #pragma unroll
