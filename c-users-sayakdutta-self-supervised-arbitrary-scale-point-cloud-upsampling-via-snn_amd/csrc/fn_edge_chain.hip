@@ -311,16 +311,27 @@ __device__ __forceinline__ float chain_softmax_agg(float (&xs)[KK], const float 
     float mx = -__builtin_huge_valf();
 #pragma unroll
     for (int jj = 0; jj < KK; ++jj) mx = fmaxf(mx, xs[jj]);
+    // (kk is even: the element-wise steps — subtract, scale into exp2's argument, scale by 1 / den — on operand pairs; the two sums stay
+    // sequential in neighbour order)
     float den = 0.f;
+    const f32x2 mx2 = f32x2{mx, mx}, l2e = f32x2{1.4426950408889634074f, 1.4426950408889634074f};
 #pragma unroll
-    for (int jj = 0; jj < KK; ++jj) {
-        xs[jj] = fast_exp(__fsub_rn(xs[jj], mx));
+    for (int jj = 0; jj < KK; jj += 2) {
+        const f32x2 e2 = (f32x2{xs[jj], xs[jj + 1]} - mx2) * l2e;      // fast_exp(x - mx) = exp2((x - mx) * log2 e)
+        xs[jj] = __builtin_amdgcn_exp2f(e2.x);
+        xs[jj + 1] = __builtin_amdgcn_exp2f(e2.y);
         den = __fadd_rn(den, xs[jj]);
+        den = __fadd_rn(den, xs[jj + 1]);
     }
     const float inv_den = __fdiv_rn(1.0f, den);
+    const f32x2 inv2 = f32x2{inv_den, inv_den};
     float out = 0.f;
 #pragma unroll
-    for (int jj = 0; jj < KK; ++jj) out = __fmaf_rn(__fmul_rn(xs[jj], inv_den), ts[jj], out);
+    for (int jj = 0; jj < KK; jj += 2) {
+        const f32x2 w2 = f32x2{xs[jj], xs[jj + 1]} * inv2;
+        out = __fmaf_rn(w2.x, ts[jj], out);
+        out = __fmaf_rn(w2.y, ts[jj + 1], out);
+    }
     return out;
 }
 
@@ -541,9 +552,12 @@ __global__ __launch_bounds__(ChainShape<D>::NW * 64, (D == 128 ? SAPCU_CHAIN_LB1
             const float b3 = a.b3[L.col[j]];
             // own rows: x = (a + b) / sqrt(hd) in place of the accumulators (pe already holds t = v_j + pe)
 #pragma unroll
-            for (int i = 0; i < RS; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][j][e] = __fmul_rn(__fmaf_rn(acc[i][j][e], 0.0625f, b3), a.inv_sqrt_hd);
+            for (int i = 0; i < RS; ++i) {                 // (packed: fma, then mul, per element as fn_softmax_agg_kernel)
+                const f32x2 k16 = f32x2{0.0625f, 0.0625f}, b32 = f32x2{b3, b3}, is2 = f32x2{a.inv_sqrt_hd, a.inv_sqrt_hd};
+                const f32x2 lo = pk_fma(f32x2{acc[i][j][0], acc[i][j][1]}, k16, b32) * is2;
+                const f32x2 hi = pk_fma(f32x2{acc[i][j][2], acc[i][j][3]}, k16, b32) * is2;
+                acc[i][j] = f32x4{lo.x, lo.y, hi.x, hi.y};
+            }
             // lane group g's own point: its kk rows are this lane's registers, in neighbour order
             {
                 float xs[KK], ts[KK];
