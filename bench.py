@@ -331,6 +331,8 @@ def main():
     want_strong_leg = strong or not args.no_strong_leg
     all_seeds = None
     if want_strong_leg:       # the cloud's real seeds (in-process dense grid flood, same on every rank), resident before timing
+        # every rank floods the same cloud before the timed region: share the host's cores between the ranks of the node
+        os.environ.setdefault("SAPCU_SEED_THREADS", str(min(16, max(1, (os.cpu_count() or 16) // max(1, world)))))
         all_seeds = torch.as_tensor(sgen.dense_seeds(cloud_host, STRONG_CLOUD_SPACING), device=dev)
 
     def weak_step():
