@@ -485,9 +485,6 @@ struct GemmArgs {
     // (float_max_key; the buffer starts at 0 = below every key; launch_decode_max_keys turns it into floats)
     unsigned* max_keys;
     int max_m;
-    // ring kernel only, parity path: the three split-f16 products per k32 step instead of per k16 step — the accumulation order of
-    // fn_edge_chain.hip's 16x16x32 MFMAs (gemm_sf16_ring.hip); the unfused edge chain (SAPCU_CHAIN=0) sets it
-    int pass_major;
 };
 int launch_gemm(const GemmArgs& g, hipStream_t st);        // f32 MFMA (exact f32 products)
 int launch_gemm_sf16(const GemmArgs& g, hipStream_t st);   // 3 x f16 MFMA, f32-quality (needs w16_hi/lo); f32 A

@@ -110,61 +110,82 @@ __device__ __forceinline__ f32x2 fe_spike0(f32x2 x, const NeuronP& p) {
     return ns.step(x, true);
 }
 
-// ---- fragment-ordered weights: frag (column block cb, k16 step s, plane) of a [n, k] matrix = 64 lanes x 8 halves
-__device__ __forceinline__ half8 fe_wfrag(const half8* __restrict__ wp, int nk16, int cb, int s, int plane, int lane) {
-    return wp[(((int64_t)cb * nk16 + s) * 2 + plane) * 64 + lane];
+// ---- fragment-ordered weights (16x16x32 B operand): frag (column sub-block cs, k32 step s, plane) of a [n, k] matrix = 64 lanes x 8 halves
+__device__ __forceinline__ half8 fe_wfrag(const half8* __restrict__ wp, int nk32, int cs, int s, int plane, int lane) {
+    return wp[(((int64_t)cs * nk32 + s) * 2 + plane) * 64 + lane];
 }
 
-// C[64 rows, NCB column blocks] = panel[64, 16 nk16] . W^T for this wave's column blocks cb[]: both 32-row blocks, weights
-// L2 -> registers two k16 steps ahead, products (a_lo w_hi, a_hi w_lo, a_hi w_hi) per k16 step in ascending k — the order of
-// every split-f16 GEMM of the library.  acc[i * NCB + j] = row block i, column block cb[j].
-template <int NCB, int NRB = 2>
-__device__ __forceinline__ void fe_gemm64(const unsigned char* X, const half8* __restrict__ wp, int nk16, const int (&cb)[NCB],
-                                          int lane, f32x16 (&acc)[NRB * NCB], int rb0 = 0) {
-    const int r32 = lane & 31, h = lane >> 5, sw = (r32 >> 2) & 3;
-    const unsigned char* xa = X + r32 * 64 + rb0 * 2048;         // NRB row blocks starting at row block rb0
+// C[16 NRS rows, 16 NCS columns] = panel . W^T for this wave's column sub-blocks cs[]: v_mfma_f32_16x16x32_f16 (fn_edge_chain.hip:
+// the clock the chip holds on it, and why it equals two chained 32x32x16 bit for bit), per k32 step and accumulator a_lo w_hi, then
+// a_hi w_lo, then a_hi w_hi — the pass-major order of every split-f16 GEMM of the library.  acc[i][j] = rows 16 (rs0 + i) + 4 (lane >>
+// 4) + e, column 16 cs[j] + (lane & 15).  One k32 step of weight fragments in registers; the column sub-blocks go in two halves whose
+// fragments are refilled in place behind their MFMAs (NCS = 1: behind the step).  RH > 0: the operand fragments of RH row sub-blocks
+// at a time (registers), re-read for the second column half.
+template <int NCS, int NRS, int RH = 0>
+__device__ __forceinline__ void fe_gemm16(const unsigned char* X, int plane_bytes, const half8* __restrict__ wp, int nk32, const int (&cs)[NCS],
+                                          int lane, f32x4 (&acc)[NRS][NCS], int rs0 = 0, int s_first = 0, int nsteps = -1, int nk32_total = -1,
+                                          half8 (*Wh)[NCS] = nullptr, half8 (*Wl)[NCS] = nullptr) {
+    // (Wh / Wl: the caller keeps the fragment registers across calls — multi_scale_conv's rounds; nullptr: local, fresh accumulators)
+    const int c16 = lane & 15, g = lane >> 4;
+    const unsigned char* xa = X + (16 * rs0 + c16) * 64 + ((g ^ ((c16 >> 2) & 3)) * 16);      // A operand: row 16 rs + c16, k chunk g
+    const int kstep = 2 * plane_bytes;
+    constexpr int HC = NCS > 1 ? NCS / 2 : 1, NH = NCS > 1 ? 2 : 1;
+    constexpr int RC = RH > 0 ? RH : NRS, NRC = NRS / RC;
+    const int nk_all = nk32_total < 0 ? nk32 : nk32_total;
+    if (nsteps < 0) nsteps = nk32;
+    half8 whl[NCS], wll[NCS];
+    half8(&wh)[NCS] = Wh ? *Wh : whl;
+    half8(&wl)[NCS] = Wl ? *Wl : wll;
+    if (!Wh) {
 #pragma unroll
-    for (int b = 0; b < NRB * NCB; ++b)
+        for (int i = 0; i < NRS; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
-    half8 wh[2][NCB], wl[2][NCB];
+            for (int j = 0; j < NCS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < NCB; ++j) {
-            wh[s][j] = fe_wfrag(wp, nk16, cb[j], s < nk16 ? s : nk16 - 1, 0, lane);
-            wl[s][j] = fe_wfrag(wp, nk16, cb[j], s < nk16 ? s : nk16 - 1, 1, lane);
+        for (int j = 0; j < NCS; ++j) {
+            wh[j] = fe_wfrag(wp, nk_all, cs[j], s_first, 0, lane);
+            wl[j] = fe_wfrag(wp, nk_all, cs[j], s_first, 1, lane);
         }
-#define SAPCU_FE_STEP(S, SJ)                                                                                          \
-    {                                                                                                                 \
-        const int s_ = (S);                                                                                           \
-        const unsigned ko = (unsigned)((s_ >> 1) * 8192 + ((((s_ & 1) * 2 + h) ^ sw) * 16));                          \
-        half8 ah[NRB], al[NRB];                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < NRB; ++i) {                                                             \
-            ah[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048);                                              \
-            al[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048 + 4096);                                       \
-        }                                                                                                             \
-        _Pragma("unroll") for (int b = 0; b < NRB * NCB; ++b)                                                         \
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b / NCB], wh[SJ][b % NCB], acc[b], 0, 0, 0);           \
-        _Pragma("unroll") for (int b = 0; b < NRB * NCB; ++b)                                                         \
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / NCB], wl[SJ][b % NCB], acc[b], 0, 0, 0);           \
-        _Pragma("unroll") for (int b = 0; b < NRB * NCB; ++b)                                                         \
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / NCB], wh[SJ][b % NCB], acc[b], 0, 0, 0);           \
-        __builtin_amdgcn_sched_barrier(0);                                                                            \
-        const int sn_ = s_ + 2 < nk16 ? s_ + 2 : nk16 - 1;                                                            \
-        _Pragma("unroll") for (int j = 0; j < NCB; ++j) {                                                             \
-            wh[SJ][j] = fe_wfrag(wp, nk16, cb[j], sn_, 0, lane);                                                      \
-            wl[SJ][j] = fe_wfrag(wp, nk16, cb[j], sn_, 1, lane);                                                      \
-        }                                                                                                             \
     }
 #pragma unroll 1
-    for (int s0 = 0; s0 < nk16; s0 += 2) {
-        SAPCU_FE_STEP(s0, 0)
-        SAPCU_FE_STEP(s0 + 1, 1)
+    for (int s = 0; s < nsteps; ++s) {
+        const int sa = s_first + s + 1;
+        const int sn = sa < nk_all ? sa : nk_all - 1;             // (the tail re-loads the last fragment: unconditional loads)
+#pragma unroll
+        for (int hc = 0; hc < NH; ++hc) {
+#pragma unroll
+            for (int rc = 0; rc < NRC; ++rc) {
+                half8 ah[RC], al[RC];
+#pragma unroll
+                for (int i = 0; i < RC; ++i) {
+                    ah[i] = *reinterpret_cast<const half8*>(xa + s * kstep + (rc * RC + i) * 1024);
+                    al[i] = *reinterpret_cast<const half8*>(xa + s * kstep + (rc * RC + i) * 1024 + plane_bytes);
+                }
+#pragma unroll
+                for (int i = 0; i < RC; ++i)
+#pragma unroll
+                    for (int j = hc * HC; j < (hc + 1) * HC && j < NCS; ++j)
+                        acc[rc * RC + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], wh[j], acc[rc * RC + i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < RC; ++i)
+#pragma unroll
+                    for (int j = hc * HC; j < (hc + 1) * HC && j < NCS; ++j)
+                        acc[rc * RC + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], wl[j], acc[rc * RC + i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < RC; ++i)
+#pragma unroll
+                    for (int j = hc * HC; j < (hc + 1) * HC && j < NCS; ++j)
+                        acc[rc * RC + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], wh[j], acc[rc * RC + i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = hc * HC; j < (hc + 1) * HC && j < NCS; ++j) {
+                wh[j] = fe_wfrag(wp, nk_all, cs[j], sn, 0, lane);
+                wl[j] = fe_wfrag(wp, nk_all, cs[j], sn, 1, lane);
+            }
+        }
     }
-#undef SAPCU_FE_STEP
 }
-
 
 // sum of v over the 64 lanes (wave-uniform result): DPP butterflies inside rows of 16, then four scalar reads — the
 // ds_bpermute shuffles of __shfl_xor cost an LDS round trip each
@@ -391,48 +412,11 @@ __device__ __forceinline__ void fe_emit4(const float (&x)[4], const NeuronP& p, 
 // wave's 2 row blocks x 3 column blocks cb0 .. cb0 + 2 (ALL emb columns are covered by the eight waves in one sweep over K, so
 // every spike is generated once).  Weight fragments L2 -> registers two k16 steps ahead, refilled in place behind the MFMAs
 // that read them; the loop is rolled (a fully unrolled K sweep makes the compiler precompute — and spill — every fragment address).
-struct FeW {
-    half8 wh[2][3], wl[2][3];      // two k16 steps ahead (slot = step & 1)
-};
-__device__ __forceinline__ void fe_msc_round(const unsigned char* X, const half8* __restrict__ wp, int cb0, int s_abs, int nk16, int lane,
-                                             FeW& W, f32x16 (&acc)[6]) {
-    const int r32 = lane & 31, h = lane >> 5, sw = (r32 >> 2) & 3;
-    const unsigned char* xa = X + r32 * 64;
-#define SAPCU_FE_MSTEP(S, SJ)                                                                                           \
-    {                                                                                                                   \
-        const int s_ = (S);                                                                                             \
-        const unsigned ko = (unsigned)((s_ >> 1) * (FE_PR * 128) + ((((s_ & 1) * 2 + h) ^ sw) * 16));                   \
-        half8 ah[2], al[2];                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                 \
-            ah[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048);                                                \
-            al[i] = *reinterpret_cast<const half8*>(xa + ko + i * 2048 + FE_PR * 64);                                   \
-        }                                                                                                               \
-        /* acc[i * 3 + j]: row block i, column block cb0 + j; per accumulator a_lo w_hi, a_hi w_lo, a_hi w_hi */        \
-        _Pragma("unroll") for (int b = 0; b < 6; ++b)                                                                   \
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b / 3], W.wh[SJ][b % 3], acc[b], 0, 0, 0);                \
-        _Pragma("unroll") for (int b = 0; b < 6; ++b)                                                                   \
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / 3], W.wl[SJ][b % 3], acc[b], 0, 0, 0);                \
-        _Pragma("unroll") for (int b = 0; b < 6; ++b)                                                                   \
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b / 3], W.wh[SJ][b % 3], acc[b], 0, 0, 0);                \
-        __builtin_amdgcn_sched_barrier(0);                                                                              \
-        const int sa_ = s_abs + s_ + 2;                     /* (60 k16 steps in all; the tail re-loads the last fragment) */ \
-        const int sn_ = sa_ < 60 ? sa_ : 59;                                                                            \
-        _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                 \
-            W.wh[SJ][j] = fe_wfrag(wp, 60, cb0 + j, sn_, 0, lane);                                                      \
-            W.wl[SJ][j] = fe_wfrag(wp, 60, cb0 + j, sn_, 1, lane);                                                      \
-        }                                                                                                               \
-    }
-#pragma unroll 1
-    for (int s0 = 0; s0 < nk16; s0 += 2) {
-        SAPCU_FE_MSTEP(s0, 0)
-        SAPCU_FE_MSTEP(s0 + 1, 1)
-    }
-#undef SAPCU_FE_MSTEP
-}
-
-__device__ __forceinline__ unsigned fe_half_max(unsigned x) {     // max of the two lane halves' values, in both halves
-    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-    return r[0] > r[1] ? r[0] : r[1];
+__device__ __forceinline__ unsigned fe_group_max(unsigned x) {    // max over the four lane groups' values, in all of them
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);       // [g0,g0,g2,g2], [g1,g1,g3,g3]
+    const unsigned m1 = r[0] > r[1] ? r[0] : r[1];
+    const auto q = __builtin_amdgcn_permlane32_swap(m1, m1, false, false);
+    return q[0] > q[1] ? q[0] : q[1];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -512,13 +496,13 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
     FE_STAMP(4 * L + 1);
     // (3) GEMM: pairs pr = w + 8 q; accumulators acc[q][rows i][A' | B]
     const bool active = L != 1 || w < 4;                   // block 1 has only four pairs
-    f32x16 acc[NPW][4];                                    // [pair][i * 2 + (0: A' = (W1 + W2) x, 1: B = W1 x)]
+    f32x4 acc[NPW][3][4];                                  // [pair][row sub-block][0, 1: A' = (W1 + W2) x | 2, 3: B = W1 x] (rows < 48 only)
     if (active) {
 #pragma unroll
         for (int q = 0; q < NPW; ++q) {
             const int pr = w + 8 * q;
-            const int cbs[2] = {pr, COUT / 32 + pr};
-            fe_gemm64<2>(R2, reinterpret_cast<const half8*>(a.edge_wp[L - 1]), CIN / 16, cbs, lane, acc[q]);
+            const int css[4] = {2 * pr, 2 * pr + 1, 2 * (COUT / 32 + pr), 2 * (COUT / 32 + pr) + 1};
+            fe_gemm16<4, 3>(R2, 4096, reinterpret_cast<const half8*>(a.edge_wp[L - 1]), CIN / 32, css, lane, acc[q]);
         }
     }
     __syncthreads();                                       // every wave has read the panel: R2 becomes the staging area
@@ -528,22 +512,21 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
     //     one 16-byte tile read per neighbour serves four channels (a lane-per-channel walk spends 4 instructions per element and
     //     neighbour) —, written back over the tile, and picked up in the accumulator layout: pre = LeakyReLU((max - B) + shift)
     float* SAw = reinterpret_cast<float*>(R2) + w * FE_TILE;
-    const int r32 = lane & 31, h = lane >> 5;
+    const int c16 = lane & 15, g4 = lane >> 4;                  // accumulator layout: column 16 cj + c16, rows 16 rs + 4 g4 + e
     const int qd = lane & 7, g6 = 6 * (lane >> 3);              // the max phase's mapping: channels 4 qd .. 4 qd + 3, rows g6 .. g6 + 5
 #pragma unroll
     for (int q = 0; q < NPW; ++q) {
-        float pre[2][16];
+        float pre[3][2][4];
         if (active) {
-            const int col = 32 * (w + 8 * q) + r32;            // channel of this lane inside the block
-            const float sh = a.shift[L - 1][col];
+            const int col0 = 32 * (w + 8 * q) + c16;           // channel of this lane inside the block (column sub-block cj: + 16 cj)
+            const float sh[2] = {a.shift[L - 1][col0], a.shift[L - 1][col0 + 16]};
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int rs = 0; rs < 3; ++rs)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    if (32 * i + 8 * (e >> 2) >= FE_M) continue;              // 48 = 6 x 8: whole groups of 8 rows are in or out
-                    const int row = 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
-                    SAw[row * FE_TLD + r32] = __fadd_rn(__fmul_rn(acc[q][i * 2][e], 0.0625f), 0.0f);    // the GEMM epilogue's value (no bias)
-                }
+                for (int cj = 0; cj < 2; ++cj)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)               // the GEMM epilogue's value (no bias)
+                        SAw[(16 * rs + 4 * g4 + e) * FE_TLD + 16 * cj + c16] = __fadd_rn(__fmul_rn(acc[q][rs][cj][e], 0.0625f), 0.0f);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             {
@@ -587,38 +570,35 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
                 __builtin_amdgcn_wave_barrier();
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int rs = 0; rs < 3; ++rs)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    if (32 * i + 8 * (e >> 2) >= FE_M) continue;
-                    const int row = 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
-                    const float mxv = SAw[row * FE_TLD + r32];
-                    const float xb = __fadd_rn(__fmul_rn(acc[q][i * 2 + 1][e], 0.0625f), 0.0f);
-                    pre[i][e] = lrelu02(__fadd_rn(__fsub_rn(mxv, xb), sh));
-                    if (a.tap_x0 && row < m) a.tap_x0[((a.s0 + patch_i) * m + row) * 960 + COFF_OUT + col] = pre[i][e];
-                }
+                for (int cj = 0; cj < 2; ++cj)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = 16 * rs + 4 * g4 + e;
+                        const float mxv = SAw[row * FE_TLD + 16 * cj + c16];
+                        const float xb = __fadd_rn(__fmul_rn(acc[q][rs][2 + cj][e], 0.0625f), 0.0f);
+                        pre[rs][cj][e] = lrelu02(__fadd_rn(__fsub_rn(mxv, xb), sh[cj]));
+                        if (a.tap_x0 && row < m) a.tap_x0[((a.s0 + patch_i) * m + row) * 960 + COFF_OUT + col0 + 16 * cj] = pre[rs][cj][e];
+                    }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();               // this wave's reads of its tile are done before it is rewritten
             if (L <= 2) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int rs = 0; rs < 3; ++rs)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        if (32 * i + 8 * (e >> 2) >= FE_M) continue;
-                        const int row = 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
-                        XS[row * FE_XLD + COFF_OUT + col] = pre[i][e];
-                    }
+                    for (int cj = 0; cj < 2; ++cj)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) XS[(16 * rs + 4 * g4 + e) * FE_XLD + COFF_OUT + col0 + 16 * cj] = pre[rs][cj][e];
             } else {
                 // block 3: into the tile again, then every thread picks up its (channel, six rows) elements of multi_scale_conv's
                 // K rounds: round j of this half = columns 64 j .. 64 j + 63 = the tiles of waves 2 j, 2 j + 1
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int rs = 0; rs < 3; ++rs)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        if (32 * i + 8 * (e >> 2) >= FE_M) continue;
-                        const int row = 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
-                        SAw[row * FE_TLD + r32] = pre[i][e];
-                    }
+                    for (int cj = 0; cj < 2; ++cj)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) SAw[(16 * rs + 4 * g4 + e) * FE_TLD + 16 * cj + c16] = pre[rs][cj][e];
             }
         }
         if (L == 3) {
@@ -652,7 +632,6 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
     float* xx = reinterpret_cast<float*>(smem + FE_OFF_XX);
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r32 = lane & 31, h = lane >> 5;
     const int m = a.m;
     const int64_t patch_i = blockIdx.x;
     const float* __restrict__ pp = a.patch + patch_i * m * 3;
@@ -756,24 +735,22 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
     __syncthreads();
     FE_STAMP(2);
     // ---- block 0: scale_fusion (64 S -> 64) + BN + LeakyReLU = x0 of block 0                                fd:420-421
-    if (w < 4) {                                           // four 32 x 32 output blocks, one per wave (one wave per SIMD)
-        f32x16 acc[1];
-        const int cbs[1] = {w & 1};
-        const int i = w >> 1;
-        fe_gemm64<1, 1>(R2, reinterpret_cast<const half8*>(a.fuse_wp), 4 * a.nscale, cbs, lane, acc, i);
-        const int col = 32 * (w & 1) + r32;
+    if (w < 4) {                                           // 48 rows x 16 columns per wave (one wave per SIMD)
+        f32x4 acc[3][1];
+        const int css[1] = {w};
+        fe_gemm16<1, 3>(R2, 4096, reinterpret_cast<const half8*>(a.fuse_wp), 2 * a.nscale, css, lane, acc);
+        const int col = 16 * w + (lane & 15);
         const float bias = a.fuse_b[col];
-        {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                if (32 * i + 8 * (e >> 2) >= FE_M) continue;
-                const int row = 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
-                const float v = lrelu02(__fadd_rn(__fmul_rn(acc[0][e], 0.0625f), bias));
+        for (int rs = 0; rs < 3; ++rs)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = 16 * rs + 4 * (lane >> 4) + e;
+                const float v = lrelu02(__fadd_rn(__fmul_rn(acc[rs][0][e], 0.0625f), bias));
                 XS[row * FE_XLD + col] = v;
                 if (a.tap_fused0 && row < m) a.tap_fused0[((a.s0 + patch_i) * m + row) * 64 + col] = v;
                 if (a.tap_x0 && row < m) a.tap_x0[((a.s0 + patch_i) * m + row) * 960 + col] = v;
             }
-        }
     }
     __syncthreads();
     FE_STAMP(3);
@@ -812,9 +789,11 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
         const int ncb = a.emb / 32;
         const int cbw = sweep * 24 + 3 * w;
         const int cb0 = cbw + 2 < ncb ? cbw : (ncb >= 3 ? ncb - 3 : 0);
-        float bias[3];
+        // this wave's six 16-column sub-blocks: column 16 css[j] + (lane & 15)
+        const int css[6] = {2 * cb0, 2 * cb0 + 1, 2 * cb0 + 2, 2 * cb0 + 3, 2 * cb0 + 4, 2 * cb0 + 5};
+        float bias[6];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) bias[j] = a.msc_b[32 * (cb0 + j) + r32];
+        for (int j = 0; j < 6; ++j) bias[j] = a.msc_b[16 * css[j] + (lane & 15)];
         for (int t0 = 0; t0 < a.T; t0 += 4) {
             const int nemit = a.T - t0 < 4 ? a.T - t0 : 4;
             const bool count = sweep == 0 && t0 + nemit == a.T;        // the gate check runs once, over all T steps
@@ -824,9 +803,9 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
             float* tap = (a.tap_spikes && sweep == 0) ? a.tap_spikes + (a.s0 + patch_i) * (int64_t)m * 960 : nullptr;
 #endif
             const bool fast = t0 == 0 && nemit == 4 && tap == nullptr;         // (workgroup-uniform)
-            unsigned best[3][4];
+            unsigned best[6][4];
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < 6; ++j)
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) best[j][tt] = 0u;
             // one third of the patch; TH is compile-time (a generic lambda called with integral constants: x3 must be indexed
@@ -834,19 +813,17 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
             auto third = [&](auto th_c) {
                 constexpr int TH = decltype(th_c)::value;
                 const int pt0 = FE_TP * TH + 4 * rg;                    // this thread's first point
-                f32x16 acc[6];
+                f32x4 acc[4][6];                                        // [row sub-block: points 4 rs + (lane >> 4), step e][column sub-block]
 #pragma unroll
-                for (int b = 0; b < 6; ++b)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
-                FeW W;
+                    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                half8 Wh[6], Wl[6];                                     // one k32 step of weight fragments, carried from round to round
 #pragma unroll
-                for (int sj = 0; sj < 2; ++sj)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        W.wh[sj][j] = fe_wfrag(mscw, 60, cb0 + j, sj, 0, lane);
-                        W.wl[sj][j] = fe_wfrag(mscw, 60, cb0 + j, sj, 1, lane);
-                    }
+                for (int j = 0; j < 6; ++j) {
+                    Wh[j] = fe_wfrag(mscw, 30, css[j], 0, 0, lane);
+                    Wl[j] = fe_wfrag(mscw, 30, css[j], 0, 1, lane);
+                }
                 NeuronP pnext = fe_load_np(a.nprm, 64 * cw + lane);      // a chunk's neuron parameters are loaded one round ahead
 #pragma unroll 1
                 for (int R = 0; R < 8; ++R) {
@@ -885,34 +862,37 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
                     }
                     lds_barrier();
                     FE_TACC(fe_t_emit);
-                    fe_msc_round(R2, mscw, cb0, 8 * R, R < 7 ? 8 : 4, lane, W, acc);
+                    fe_gemm16<6, 4, 2>(R2, FE_PR * 64, mscw, 30, css, lane, acc, 0, 4 * R, R < 7 ? 4 : 2, 30, &Wh, &Wl);
                     lds_barrier();
                     FE_TACC(fe_t_mfma);
                 }
                 // epilogue of this third: + bias, LeakyReLU, running max per step over the third's points (row = 4 point + step:
                 // register u of a quad is step u), integer keys
 #pragma unroll
-                for (int b = 0; b < 6; ++b)
+                for (int i = 0; i < 4; ++i) {
+                    const int pl = 4 * i + (lane >> 4);                 // point inside the third
+                    if (FE_TP * TH + pl < m) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int pl = 8 * (b / 3) + 2 * (e >> 2) + h;    // point inside the third
-                        if (FE_TP * TH + pl < m) {
-                            const unsigned key = float_max_key(lrelu02(__fadd_rn(__fmul_rn(acc[b][e], 0.0625f), bias[b % 3])));
-                            best[b % 3][e & 3] = best[b % 3][e & 3] > key ? best[b % 3][e & 3] : key;
-                        }
+                        for (int j = 0; j < 6; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const unsigned key = float_max_key(lrelu02(__fadd_rn(__fmul_rn(acc[i][j][e], 0.0625f), bias[j])));
+                                best[j][e] = best[j][e] > key ? best[j][e] : key;
+                            }
                     }
+                }
             };
             third(std::integral_constant<int, 0>{});
             third(std::integral_constant<int, 1>{});
             third(std::integral_constant<int, 2>{});
             if (cbw + 2 < ncb || sweep == 0) {                          // (a clamped tail wave of a later sweep stores nothing new)
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
+                for (int j = 0; j < 6; ++j)
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
-                        const unsigned k2 = fe_half_max(best[j][tt]);
-                        if (h == 0 && tt < nemit)
-                            a.pooled[((int64_t)(t0 + tt) * a.b + patch_i) * a.emb + 32 * (cb0 + j) + r32] = float_from_max_key(k2);
+                        const unsigned k2 = fe_group_max(best[j][tt]);
+                        if (lane < 16 && tt < nemit)
+                            a.pooled[((int64_t)(t0 + tt) * a.b + patch_i) * a.emb + 16 * css[j] + lane] = float_from_max_key(k2);
                     }
             }
         }
@@ -930,24 +910,24 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
 // ---------------------------------------------------------------------------------------------
 // model-build helpers: weights in fragment order, clamped neuron parameters
 // ---------------------------------------------------------------------------------------------
-// out[((cb * nk16 + s) * 2 + plane) * 64 + lane][j] = w16_plane[32 cb + (lane & 31)][16 s + 8 (lane >> 5) + j],  w [n, k] row-major
+// out[((cs * nk32 + s) * 2 + plane) * 64 + lane][j] = w16_plane[16 cs + (lane & 15)][32 s + 8 (lane >> 4) + j],  w [n, k] row-major
 __global__ __launch_bounds__(256) void pack_frag_weights_kernel(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo,
                                                                 int n, int k, _Float16* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int nk16 = k / 16;
-    const int64_t total = (int64_t)(n / 32) * nk16 * 2 * 64;
+    const int nk32 = k / 32;
+    const int64_t total = (int64_t)(n / 16) * nk32 * 2 * 64;
     if (t >= total) return;
     const int lane = (int)(t & 63);
     const int plane = (int)((t >> 6) & 1);
-    const int64_t cs = t >> 7;
-    const int s = (int)(cs % nk16), cb = (int)(cs / nk16);
-    const _Float16* src = (plane ? lo : hi) + (int64_t)(32 * cb + (lane & 31)) * k + 16 * s + 8 * (lane >> 5);
+    const int64_t cs_s = t >> 7;
+    const int s = (int)(cs_s % nk32), cs = (int)(cs_s / nk32);
+    const _Float16* src = (plane ? lo : hi) + (int64_t)(16 * cs + (lane & 15)) * k + 32 * s + 8 * (lane >> 4);
     *reinterpret_cast<half8*>(out + t * 8) = *reinterpret_cast<const half8*>(src);
 }
 
 int launch_pack_frag_weights(const void* w16_hi, const void* w16_lo, int n, int k, void* out, hipStream_t st) {
-    SAPCU_CHECK_ARG(n % 32 == 0 && k % 16 == 0, "pack_frag_weights: need n %% 32 == 0 and k %% 16 == 0 (n=%d k=%d)", n, k);
-    const int64_t total = (int64_t)(n / 32) * (k / 16) * 2 * 64;
+    SAPCU_CHECK_ARG(n % 16 == 0 && k % 32 == 0, "pack_frag_weights: need n %% 16 == 0 and k %% 32 == 0 (n=%d k=%d)", n, k);
+    const int64_t total = (int64_t)(n / 16) * (k / 32) * 2 * 64;
     hipLaunchKernelGGL(pack_frag_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const _Float16*)w16_hi,
                        (const _Float16*)w16_lo, n, k, (_Float16*)out);
     SAPCU_CHECK_LAUNCH();

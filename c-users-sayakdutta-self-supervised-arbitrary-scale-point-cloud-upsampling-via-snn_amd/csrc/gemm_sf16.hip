@@ -179,20 +179,36 @@ __global__ __launch_bounds__(1024) void gemm_sf16_kernel(const GemmArgs g) {
                     }
                     const unsigned char* st = smem_raw + cur * STAGE_BYTES;
                     const unsigned char* sA = st + arow_l * (SBK * 2);
+                    // pass-major order per k32 step (the library's accumulation order since round 3, gemm_sf16_bt.hip): a_lo.w_hi over
+                    // both k16 halves, then a_hi.w_lo, then a_hi.w_hi
 #pragma unroll
-                    for (int k16 = 0; k16 < SBK / 16; ++k16) {
-                        const int ca = ((k16 * 2 + h) ^ asw) * 16;
-                        const half8 ah = *reinterpret_cast<const half8*>(sA + ca);
-                        const half8 al = *reinterpret_cast<const half8*>(sA + PLANE_BYTES + ca);
+                    for (int k32 = 0; k32 < SBK / 32; ++k32) {
+                        half8 ah[2], al[2], wh[2][2], wl[2][2];
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const unsigned char* sW = st + 2 * PLANE_BYTES + wrow_l[j] * (SBK * 2) + (((k16 * 2 + h) ^ wsw[j]) * 16);
-                            const half8 wh = *reinterpret_cast<const half8*>(sW);
-                            const half8 wl = *reinterpret_cast<const half8*>(sW + PLANE_BYTES);
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, acc[j], 0, 0, 0);
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, acc[j], 0, 0, 0);
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc[j], 0, 0, 0);
+                        for (int t = 0; t < 2; ++t) {
+                            const int k16 = 2 * k32 + t;
+                            const int ca = ((k16 * 2 + h) ^ asw) * 16;
+                            ah[t] = *reinterpret_cast<const half8*>(sA + ca);
+                            al[t] = *reinterpret_cast<const half8*>(sA + PLANE_BYTES + ca);
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const unsigned char* sW = st + 2 * PLANE_BYTES + wrow_l[j] * (SBK * 2) + (((k16 * 2 + h) ^ wsw[j]) * 16);
+                                wh[t][j] = *reinterpret_cast<const half8*>(sW);
+                                wl[t][j] = *reinterpret_cast<const half8*>(sW + PLANE_BYTES);
+                            }
                         }
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], wh[t][j], acc[j], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], wl[t][j], acc[j], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], wh[t][j], acc[j], 0, 0, 0);
                     }
                     if (kt + 1 < nk) {
                         store_a(cur ^ 1);

@@ -275,22 +275,14 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
         }
     };
     f32x16 acc[4][CT];
-    auto mfma_all = [&](const Frags& f) {
-        // same product order per accumulator as the ring kernel (a_lo.w_hi, a_hi.w_lo, a_hi.w_hi); consecutive MFMAs go to
-        // different accumulators.  (Tried: the weight fragment as the first operand, which transposes the block into the row
-        // layout of gemm_epi.h — 16-byte stores, but only 32 contiguous bytes per row and instruction: 10 % slower.)
+    // one product over all accumulators; consecutive MFMAs go to different accumulators.  (Tried: the weight fragment as the first
+    // operand, which transposes the block into the row layout of gemm_epi.h — 16-byte stores, but only 32 contiguous bytes per row
+    // and instruction: 10 % slower.)
+    auto mfma_pass = [&](const half8 (&av)[4], const half8 (&wv)[CT]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.wh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.wl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.wh[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], wv[j], acc[i][j], 0, 0, 0);
     };
 
     wait_landed(0);
@@ -309,8 +301,18 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         read_frags(ca, cw, 0, f0);          // (not prefetched across the tile boundary: the epilogue needs those 48 registers)
         for (int kt = 0; kt < nk; ++kt, ++gstep) {
+            // PASS-MAJOR order (round 3): per k32 step and accumulator a_lo.w_hi over both k16 halves, then a_hi.w_lo, then a_hi.w_hi —
+            // what one v_mfma_f32_16x16x32_f16 per product accumulates (two chained 32x32x16 over the same 32 k values equal one
+            // 16x16x32 bit for bit, profiles/micro/mfma_f16_shapes_bits.hip), so that kernels can move to that shape one at a time
+            // and stay bit-identical to this one.  The two fragment sets are used as before: P1(f0) runs under f1's LDS latency,
+            // the barrier / refill / read of the next step's f0 sit behind P3(f0), P3(f1) covers that read.  Measured against the
+            // k16-major step: 1401 -> 1386, 537 -> 565, 3216 -> 3220 us on three of the step's shapes.
             read_frags(ca, cw, 1, f1);
-            mfma_all(f0);
+            mfma_pass(f0.al, f0.wh);
+            mfma_pass(f1.al, f1.wh);
+            mfma_pass(f0.ah, f0.wl);
+            mfma_pass(f1.ah, f1.wl);
+            mfma_pass(f0.ah, f0.wh);
             if (gstep + 1 < total_steps) {
                 wait_landed(gstep + 1);
                 lds_barrier();                                        // step gstep+1 is in for everyone; this step's slots fully read
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
             } else {
                 lds_barrier();
             }
-            mfma_all(f1);
+            mfma_pass(f1.ah, f1.wh);
             ca = na;
             cw = nw;
             if (++na == TA_SLOTS) na = 0;

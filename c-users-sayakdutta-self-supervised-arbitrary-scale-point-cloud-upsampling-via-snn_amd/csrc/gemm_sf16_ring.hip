@@ -64,8 +64,8 @@ __device__ __forceinline__ void wait_vm() {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// PM: the pass-major accumulation order (see the k loop); a template parameter — as a run-time branch in the loop it cost the default
-// form a third of its speed.  Instantiated for the three epilogues of the unfused edge chain only.
+// PM: the pass-major accumulation order (see the k loop) — the only form launched since the whole library moved to it (round 3);
+// the k16-major body below it is kept for reference and for A/B builds (PM = false).
 template <int EPI, bool VEC, bool PM = false>
 __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
@@ -245,10 +245,10 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
             for (int kt = 0; kt < nk; ++kt, ++gstep) {
                 read_frags(ca, cw, 1, f1);                          // second half of this step: lands behind mfma6(f0)
                 if (PM) {
-                    // PASS-MAJOR form (parity path only: the unfused edge chain under SAPCU_CHAIN=0): per k32 step and accumulator
-                    // a_lo.w_hi over both k16 halves, then a_hi.w_lo, then a_hi.w_hi — the accumulation order of a kernel that issues
-                    // one v_mfma_f32_16x16x32_f16 per product (fn_edge_chain.hip): two chained 32x32x16 over the same 32 k values
-                    // equal one 16x16x32 bit for bit (profiles/micro/mfma_f16_shapes_bits.hip)
+                    // PASS-MAJOR form: per k32 step and accumulator a_lo.w_hi over both k16 halves, then a_hi.w_lo, then a_hi.w_hi —
+                    // the accumulation order of a kernel that issues one v_mfma_f32_16x16x32_f16 per product (fn_edge_chain.hip,
+                    // fd_encoder.hip): two chained 32x32x16 over the same 32 k values equal one 16x16x32 bit for bit
+                    // (profiles/micro/mfma_f16_shapes_bits.hip)
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.al, f0.wh[0], acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.al, f0.wh[1], acc[1], 0, 0, 0);
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.al, f1.wh[0], acc[0], 0, 0, 0);
@@ -424,13 +424,8 @@ static bool ring_vec_ok(const GemmArgs& g) {
 
 template <int EPI>
 static int launch_ring_t(const GemmArgs& g, hipStream_t st) {
-    return ring_vec_ok(g) ? launch_ring_tv<EPI, true>(g, st) : launch_ring_tv<EPI, false>(g, st);
-}
-template <int EPI>
-static int launch_ring_pm(const GemmArgs& g, hipStream_t st) {      // pass-major accumulation (the unfused edge chain's GEMMs)
     return ring_vec_ok(g) ? launch_ring_tv<EPI, true, true>(g, st) : launch_ring_tv<EPI, false, true>(g, st);
 }
-
 int launch_gemm_sf16_ring(const GemmArgs& g, hipStream_t st) {
     if (g.r == 0 || g.n == 0) return SAPCU_OK;
     SAPCU_CHECK_ARG(g.a_split, "gemm_ring: A must be in split rows");
@@ -440,16 +435,6 @@ int launch_gemm_sf16_ring(const GemmArgs& g, hipStream_t st) {
                     "gemm_ring: operands must be 16-byte aligned with lda %% 8 == 0 (lda=%d)", g.lda);
     if (g.epi == EPI_LIF || g.epi == EPI_LIF_ATTN) SAPCU_CHECK_ARG(g.lif, "gemm_ring: missing neuron parameters");
     if (g.epi == EPI_RESID || g.epi == EPI_RESID_GELU) SAPCU_CHECK_ARG(g.resid, "gemm_ring: missing residual");
-    if (g.pass_major) {
-        switch (g.epi) {
-            case EPI_BIAS: return launch_ring_pm<EPI_BIAS>(g, st);
-            case EPI_LIF: return launch_ring_pm<EPI_LIF>(g, st);
-            case EPI_LIF_ATTN:
-                SAPCU_CHECK_ARG(g.ldq > 0 && g.tab && g.q && g.kf && g.c2, "gemm_ring: bad attn operands");
-                return launch_ring_pm<EPI_LIF_ATTN>(g, st);
-            default: set_error("gemm_ring: no pass-major form of epilogue %d", g.epi); return SAPCU_ERR_ARG;
-        }
-    }
     switch (g.epi) {
         case EPI_BIAS: return launch_ring_t<EPI_BIAS>(g, st);
         case EPI_LIF: return launch_ring_t<EPI_LIF>(g, st);

@@ -149,8 +149,7 @@ static int run_gemm(const sapcu_model* m, GemmArgs& g, hipStream_t st) {
         g.w16_hi = (const _Float16*)m->w16_hi + off;
         g.w16_lo = (const _Float16*)m->w16_lo + off;
         g.ovf = m->ovf_dev;
-        // A already split by its producer: all-DMA kernels (pass-major accumulation: the ring kernel has that form, gemm_sf16_ring.hip)
-        if (g.a_split) return launch_gemm_split_rows(g, st, m->opt_bt && !g.pass_major);
+        if (g.a_split) return launch_gemm_split_rows(g, st, m->opt_bt);   // A already split by its producer: all-DMA kernels
         if (g.k % 64 == 0) return launch_gemm_sf16(g, st);
     }
     if (g.a_split || g.c_split || g.c2_split) {
@@ -163,12 +162,12 @@ static int run_gemm(const sapcu_model* m, GemmArgs& g, hipStream_t st) {
 // fmt bit 0: A is in split rows; bit 1: write C in split rows (both only in split-f16 mode)
 static int gemm(const sapcu_model* m, const float* a, int64_t r, int k, int lda, const float* w, int n,
                 const float* bias, float* c, int ldc, int epi, hipStream_t st, const float* lif = nullptr,
-                int lifT = 0, const float* resid = nullptr, int ldr = 0, int fmt = 0, int pass_major = 0) {
+                int lifT = 0, const float* resid = nullptr, int ldr = 0, int fmt = 0) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.a = a; g.r = r; g.k = k; g.lda = lda; g.w = w; g.n = n; g.bias = bias; g.c = c; g.ldc = ldc;
     g.epi = epi; g.lif = lif; g.lif_T = lifT; g.resid = resid; g.ldr = ldr;
-    g.a_split = fmt & 1; g.c_split = (fmt >> 1) & 1; g.pass_major = pass_major;
+    g.a_split = fmt & 1; g.c_split = (fmt >> 1) & 1;
     return run_gemm(m, g, st);
 }
 
@@ -362,17 +361,16 @@ static int fn_forward(const sapcu_model* m, const float* patch, int64_t b, int m
                     g.lif = m->p(sb + B_DELTA2_LIF); g.lif_T = 4; g.c2 = B3;
                     g.q = QKV; g.kf = QKV + d; g.ldq = 3 * d; g.tab = tab;
                     g.a_split = SP; g.c2_split = SP;
-                    g.pass_major = SP;                   // the three edge GEMMs accumulate in the fused chain's order (bit-identical to it)
                     SAPCU_TRY(launch_edge_table(idx[l], R, mp, kk, tab, st));
                     SAPCU_TRY(run_gemm(m, g, st));
                 }
                 // g = LIF(fc_gamma(attn_in)) -> B1                                      fn:373-376
                 SAPCU_TRY(gemm(m, B3, R, d, d, m->p(sb + B_GAMMA_W), d, m->p(sb + B_GAMMA_B), B1, d, EPI_LIF, st,
-                               m->p(sb + B_GAMMA_LIF), 4, nullptr, 0, SP | (SP << 1), SP));
+                               m->p(sb + B_GAMMA_LIF), 4, nullptr, 0, SP | (SP << 1)));
                 {
                     // a = fc_gamma2(g) -> B3                                            fn:378
                     SAPCU_TRY(gemm(m, B1, R, d, d, m->p(sb + B_GAMMA2_W), d, m->p(sb + B_GAMMA2_B), B3, d, EPI_BIAS, st, nullptr, 0,
-                                   nullptr, 0, SP, SP));
+                                   nullptr, 0, SP));
                     // res = sum_j softmax_j(a / sqrt(hd)) * (v_j + pe)                  fn:379-389
                     SAPCU_TRY(launch_fn_softmax_agg(B3, B2, QKV + 2 * d, 3 * d, idx[l], P, mp, kk, d, sqrt_hd, RES, SP, st));
                 }
