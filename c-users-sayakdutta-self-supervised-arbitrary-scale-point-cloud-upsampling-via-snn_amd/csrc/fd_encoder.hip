@@ -803,11 +803,13 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
             float* tap = (a.tap_spikes && sweep == 0) ? a.tap_spikes + (a.s0 + patch_i) * (int64_t)m * 960 : nullptr;
 #endif
             const bool fast = t0 == 0 && nemit == 4 && tap == nullptr;         // (workgroup-uniform)
-            unsigned best[6][4];
+            // running maxima of the RAW accumulators per (column sub-block, step): x -> LeakyReLU(x / 16 + bias) -> integer key is
+            // monotone, so the max over the points commutes with it bit for bit — bias, LeakyReLU and the key once per result
+            float best[6][4];
 #pragma unroll
             for (int j = 0; j < 6; ++j)
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) best[j][tt] = 0u;
+                for (int tt = 0; tt < 4; ++tt) best[j][tt] = -__builtin_huge_valf();
             // one third of the patch; TH is compile-time (a generic lambda called with integral constants: x3 must be indexed
             // statically to stay in registers), the rounds are a rolled loop
             auto third = [&](auto th_c) {
@@ -875,10 +877,7 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
 #pragma unroll
                         for (int j = 0; j < 6; ++j)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const unsigned key = float_max_key(lrelu02(__fadd_rn(__fmul_rn(acc[i][j][e], 0.0625f), bias[j])));
-                                best[j][e] = best[j][e] > key ? best[j][e] : key;
-                            }
+                            for (int e = 0; e < 4; ++e) best[j][e] = fmaxf(best[j][e], acc[i][j][e]);
                     }
                 }
             };
@@ -890,7 +889,8 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
                 for (int j = 0; j < 6; ++j)
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
-                        const unsigned k2 = fe_group_max(best[j][tt]);
+                        // (a lane group none of whose points exist contributes -inf: key below every real one)
+                        const unsigned k2 = fe_group_max(float_max_key(lrelu02(__fadd_rn(__fmul_rn(best[j][tt], 0.0625f), bias[j]))));
                         if (lane < 16 && tt < nemit)
                             a.pooled[((int64_t)(t0 + tt) * a.b + patch_i) * a.emb + 16 * css[j] + lane] = float_from_max_key(k2);
                     }
