@@ -7,9 +7,10 @@
 //
 //   ring kernel   128x128 tile, 16 waves (8 MFMA + 8 epilogue), 128 registers per wave: every operand byte that reaches LDS
 //                 feeds 128 rows/columns of the other operand; per MFMA one 16-byte LDS fragment read per lane.
-//   this kernel   256xBN tile (BN = 256 or 128), 8 waves of 256 registers, wave tile 128 x BN/4 (4 x 2 MFMA blocks = 128
-//                 accumulator registers): half the operand bytes per flop through the DMA path and through the LDS read
-//                 port (12 fragment reads per 24 MFMAs), four times the matrix work between two barriers.  The epilogue
+//   this kernel   256xBN tile (BN = 256 or 128), 8 waves of 256 registers, wave tile 128 x BN/4 (128 accumulator registers):
+//                 half the operand bytes per flop through the DMA path and through the LDS read port, four times the matrix
+//                 work between two barriers.  Since round 3 the MFMAs are v_mfma_f32_16x16x32_f16 (8 x 4 sub-blocks of 16 x 16
+//                 per wave; 4.5 % faster at the clock the chip holds on that shape), accumulated pass-major per k32 step.  The epilogue
 //                 runs in the MFMA waves themselves, in the accumulator layout (lane = column: bias and neuron parameters
 //                 are per-lane constants; a register quad = 4 consecutive rows -> gemm_epi.h epilogue_group4; a store
 //                 instruction writes two full 128-byte lines).
@@ -58,54 +59,53 @@ __device__ __forceinline__ float bt_load_f32(const float* p) {
 //   C_SPLIT / C2_SPLIT: c / c2 (attn_in) leave as split rows instead of f32.
 
 
-template <int EPI, int CT, bool C_SPLIT, bool C2_SPLIT>
-__device__ __forceinline__ void bt_epilogue_fast(const GemmArgs& g, const f32x16 (&acc)[4][CT], int64_t row0, int col0, int r32, int h,
-                                                 const float (&pbias)[CT], const NeuronP (&pnp)[CT]) {
+template <int EPI, int CS, bool C_SPLIT, bool C2_SPLIT>
+__device__ __forceinline__ void bt_epilogue_fast(const GemmArgs& g, const f32x4 (&acc)[8][CS], int64_t row0, int col0, int c16, int g4,
+                                                 const float (&pbias)[CS], const NeuronP (&pnp)[CS]) {
     constexpr bool ATTN = EPI == EPI_LIF_ATTN;
-    // Attention epilogue, software-pipelined over the 16 row groups: the (point, neighbour) rows of group n+1 are loaded and
-    // the q / k gathers of group n issued BEFORE the neuron arithmetic of group n, so every wait of the in-order counter is
-    // for loads issued one arithmetic block earlier (and the stores issued before them).
+    // Attention epilogue, software-pipelined over the 8 row groups (one register quad = rows 16 rs + 4 g4 + 0..3): the (point,
+    // neighbour) rows of group n+1 are loaded and the q / k gathers of group n issued BEFORE the neuron arithmetic of group n, so
+    // every wait of the in-order counter is for loads issued one arithmetic block earlier (and the stores issued before them).
     int2 t_nxt[4];
     if (ATTN) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) t_nxt[u] = g.tab[row0 + 4 * h + u];
+        for (int u = 0; u < 4; ++u) t_nxt[u] = g.tab[row0 + 4 * g4 + u];
     }
 #pragma unroll
-    for (int gi = 0; gi < 16; ++gi) {
-        const int i = gi >> 2, q4 = gi & 3;
-        const int64_t row = row0 + i * 32 + 8 * q4 + 4 * h;
-        float qv[CT][4], kv[CT][4];
+    for (int rs = 0; rs < 8; ++rs) {
+        const int64_t row = row0 + rs * 16 + 4 * g4;
+        float qv[CS][4], kv[CS][4];
         if (ATTN) {
             int2 t4[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) t4[u] = t_nxt[u];
 #pragma unroll
-            for (int j = 0; j < CT; ++j) {
-                const int col = col0 + j * 32 + r32;
+            for (int j = 0; j < CS; ++j) {
+                const int col = col0 + j * 16 + c16;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     qv[j][u] = g.q[(int64_t)t4[u].x * g.ldq + col];
                     kv[j][u] = g.kf[(int64_t)t4[u].y * g.ldq + col];
                 }
             }
-            if (gi + 1 < 16) {
-                const int64_t nrow = row0 + ((gi + 1) >> 2) * 32 + 8 * ((gi + 1) & 3) + 4 * h;
+            if (rs + 1 < 8) {
+                const int64_t nrow = row0 + (rs + 1) * 16 + 4 * g4;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) t_nxt[u] = g.tab[nrow + u];
             }
             __builtin_amdgcn_sched_barrier(0);              // loads first, arithmetic after
         }
-        float v[CT][4];
+        float v[CS][4];
 #pragma unroll
-        for (int j = 0; j < CT; ++j) {
+        for (int j = 0; j < CS; ++j) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[j][u] = __fadd_rn(__fmul_rn(acc[i][j][q4 * 4 + u], 0.0625f), pbias[j]);
+            for (int u = 0; u < 4; ++u) v[j][u] = __fadd_rn(__fmul_rn(acc[rs][j][u], 0.0625f), pbias[j]);
             if (EPI == EPI_LIF || ATTN) lif_selfloop_n<4>(v[j], pnp[j], g.lif_T);
         }
         if (ATTN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < CT; ++j) {
-            const int col = col0 + j * 32 + r32;
+        for (int j = 0; j < CS; ++j) {
+            const int col = col0 + j * 16 + c16;
             float* cp = g.c + row * g.ldc + col;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -149,7 +149,6 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int r32 = lane & 31, h = lane >> 5;
 
     const int ntn = g.n / BN;
     const int64_t ntm = (g.r + TBM - 1) / TBM;
@@ -252,92 +251,106 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
         }
     };
 
-    // ---- MFMA role: fragments of the wave tile (rows wm*128 + i*32 + r32, weight rows wn*32*CT + j*32 + r32)
-    const int sw = (r32 >> 2) & 3;
-    const unsigned a_frag0 = (unsigned)((wm * 128 + r32) * (TBK * 2));
-    const unsigned w_frag0 = (unsigned)(A_BYTES + (wn * 32 * CT + r32) * (TBK * 2));
-    struct Frags {
-        half8 ah[4], al[4], wh[CT], wl[CT];
-    };
-    auto read_frags = [&](int a_slot, int w_slot, int k16, Frags& f) {
-        const unsigned ko = (unsigned)(((k16 * 2 + h) ^ sw) * 16);
-        const unsigned char* sA = smem_raw + a_slot * TA_SLOT + a_frag0 + ko;
+    // ---- MFMA role (round 3: v_mfma_f32_16x16x32_f16 — the chip holds a higher clock on it than on 32x32x16, and one of it equals
+    // two chained 32x32x16 bit for bit, fn_edge_chain.hip): the wave tile 128 x 32 CT is RS = 8 row sub-blocks x CS = 2 CT column
+    // sub-blocks of 16; lane l supplies row / weight row (l & 15), k chunk (l >> 4) of a k32 step and holds rows 4 (l >> 4) + e,
+    // column (l & 15) of each sub-block.
+    constexpr int CS = 2 * CT;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const unsigned frag_ko = (unsigned)((g4 ^ ((c16 >> 2) & 3)) * 16);           // (the rows' swizzle term (row >> 2) & 3 = (c16 >> 2) & 3)
+    const unsigned a_frag0 = (unsigned)((wm * 128 + c16) * (TBK * 2)) + frag_ko;
+    const unsigned w_frag0 = (unsigned)(A_BYTES + (wn * 32 * CT + c16) * (TBK * 2)) + frag_ko;
+    half8 ah0[4], al0[4], ah1[4], al1[4], wh[CS], wl[CS];       // operand fragments of row sub-blocks 0-3 | 4-7 | all column sub-blocks
+    auto read_a = [&](int a_slot, int half, half8 (&ah)[4], half8 (&al)[4]) {
+        const unsigned char* sA = smem_raw + a_slot * TA_SLOT + a_frag0 + half * 4 * 16 * (TBK * 2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f.ah[i] = *reinterpret_cast<const half8*>(sA + i * 32 * (TBK * 2));
-            f.al[i] = *reinterpret_cast<const half8*>(sA + i * 32 * (TBK * 2) + TA_PLANE);
-        }
-        const unsigned char* sW = smem_raw + w_slot * W_SLOT + w_frag0 + ko;
-#pragma unroll
-        for (int j = 0; j < CT; ++j) {
-            f.wh[j] = *reinterpret_cast<const half8*>(sW + j * 32 * (TBK * 2));
-            f.wl[j] = *reinterpret_cast<const half8*>(sW + j * 32 * (TBK * 2) + W_PLANE);
+            ah[i] = *reinterpret_cast<const half8*>(sA + i * 16 * (TBK * 2));
+            al[i] = *reinterpret_cast<const half8*>(sA + i * 16 * (TBK * 2) + TA_PLANE);
         }
     };
-    f32x16 acc[4][CT];
-    // one product over all accumulators; consecutive MFMAs go to different accumulators.  (Tried: the weight fragment as the first
-    // operand, which transposes the block into the row layout of gemm_epi.h — 16-byte stores, but only 32 contiguous bytes per row
-    // and instruction: 10 % slower.)
-    auto mfma_pass = [&](const half8 (&av)[4], const half8 (&wv)[CT]) {
+    auto read_w = [&](int w_slot, int chalf) {                 // column sub-blocks chalf * CT .. chalf * CT + CT - 1
+        const unsigned char* sW = smem_raw + w_slot * W_SLOT + w_frag0;
+#pragma unroll
+        for (int j = chalf * CT; j < (chalf + 1) * CT; ++j) {
+            wh[j] = *reinterpret_cast<const half8*>(sW + j * 16 * (TBK * 2));
+            wl[j] = *reinterpret_cast<const half8*>(sW + j * 16 * (TBK * 2) + W_PLANE);
+        }
+    };
+    f32x4 acc[8][CS];
+    // the three products of a k32 step (a_lo.w_hi, a_hi.w_lo, a_hi.w_hi, per accumulator in that order) for 4 row sub-blocks x CT
+    // column sub-blocks; consecutive MFMAs go to different accumulators
+    auto mfma_group = [&](int rhalf, const half8 (&ah)[4], const half8 (&al)[4], int chalf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], wv[j], acc[i][j], 0, 0, 0);
+            for (int j = chalf * CT; j < (chalf + 1) * CT; ++j)
+                acc[4 * rhalf + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], wh[j], acc[4 * rhalf + i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = chalf * CT; j < (chalf + 1) * CT; ++j)
+                acc[4 * rhalf + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], wl[j], acc[4 * rhalf + i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = chalf * CT; j < (chalf + 1) * CT; ++j)
+                acc[4 * rhalf + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], wh[j], acc[4 * rhalf + i][j], 0, 0, 0);
     };
 
     wait_landed(0);
     lds_barrier();
     int ca = 0, cw = 0, na = 1, nw = 1;
-    Frags f0, f1;
     int64_t gstep = 0;
     int64_t tm = first_tm;
     int tn = first_tn;
     for (int64_t ti = 0; ti < my_tiles; ++ti) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < CT; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        read_frags(ca, cw, 0, f0);          // (not prefetched across the tile boundary: the epilogue needs those 48 registers)
+            for (int j = 0; j < CS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (not prefetched across the tile boundary: the epilogue needs the fragment registers)
+        read_w(cw, 0);
+        read_w(cw, 1);
+        read_a(ca, 0, ah0, al0);
         for (int kt = 0; kt < nk; ++kt, ++gstep) {
-            // PASS-MAJOR order (round 3): per k32 step and accumulator a_lo.w_hi over both k16 halves, then a_hi.w_lo, then a_hi.w_hi —
-            // what one v_mfma_f32_16x16x32_f16 per product accumulates (two chained 32x32x16 over the same 32 k values equal one
-            // 16x16x32 bit for bit, profiles/micro/mfma_f16_shapes_bits.hip), so that kernels can move to that shape one at a time
-            // and stay bit-identical to this one.  The two fragment sets are used as before: P1(f0) runs under f1's LDS latency,
-            // the barrier / refill / read of the next step's f0 sit behind P3(f0), P3(f1) covers that read.  Measured against the
-            // k16-major step: 1401 -> 1386, 537 -> 565, 3216 -> 3220 us on three of the step's shapes.
-            read_frags(ca, cw, 1, f1);
-            mfma_pass(f0.al, f0.wh);
-            mfma_pass(f1.al, f1.wh);
-            mfma_pass(f0.ah, f0.wl);
-            mfma_pass(f1.ah, f1.wl);
-            mfma_pass(f0.ah, f0.wh);
+            // One k32 step = one ring slot per operand.  Rows 0-63 of the wave tile first (their fragments were read during the previous
+            // step), under whose MFMAs the fragments of rows 64-127 arrive; then the barrier / refill, after which the NEXT step's
+            // fragments are read under the MFMAs of rows 64-127: rows 0-63's operand behind the barrier, each half of the weight
+            // fragments behind the MFMAs that read it last.
+            read_a(ca, 1, ah1, al1);
+            mfma_group(0, ah0, al0, 0);
+            mfma_group(0, ah0, al0, 1);
+            const bool more = kt + 1 < nk;
             if (gstep + 1 < total_steps) {
                 wait_landed(gstep + 1);
                 lds_barrier();                                        // step gstep+1 is in for everyone; this step's slots fully read
                 // the activation waves defer the refill of a tile's LAST step to the start of the epilogue (see there)
                 if (issued < total_steps && !(is_a && kt + 1 == nk)) issue();
-                if (kt + 1 < nk) read_frags(na, nw, 0, f0);
+                if (more) read_a(na, 0, ah0, al0);
             } else {
                 lds_barrier();
             }
-            mfma_pass(f1.ah, f1.wh);
+            mfma_group(1, ah1, al1, 0);
+            if (more) read_w(nw, 0);
+            mfma_group(1, ah1, al1, 1);
+            if (more) read_w(nw, 1);
             ca = na;
             cw = nw;
             if (++na == TA_SLOTS) na = 0;
             if (++nw == TW_SLOTS) nw = 0;
         }
-        // ---- epilogue in the accumulator layout: lane = column, register quad q = rows 8q + 4h + 0..3 of the 32x32 block
+        // ---- epilogue in the accumulator layout: lane = column (l & 15) of each column sub-block, register quad of row sub-block rs =
+        // rows 16 rs + 4 (l >> 4) + 0..3
         const int64_t row0 = tm * TBM + wm * 128;
         const int col0 = tn * BN + wn * 32 * CT;
-        // column parameters of this lane for BOTH column blocks up front: a load waited for in the middle of the epilogue would
+        // column parameters of this lane for ALL its column sub-blocks up front: a load waited for in the middle of the epilogue would
         // also wait (in-order counter) for every store issued before it
-        float pbias[CT], praw[CT][4];
-        NeuronP pnp[CT];
+        float pbias[CS], praw[CS][4];
+        NeuronP pnp[CS];
 #pragma unroll
-        for (int j = 0; j < CT; ++j) {
-            const int col = col0 + j * 32 + r32;
+        for (int j = 0; j < CS; ++j) {
+            const int col = col0 + j * 16 + c16;
             pbias[j] = 0.f;
             if (g.bias) pbias[j] = bt_load_f32(g.bias + col);
             if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) {
@@ -356,7 +369,7 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
         if (is_a && issued < total_steps) issue();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < CT; ++j) {
+        for (int j = 0; j < CS; ++j) {
             pnp[j] = NeuronP{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (EPI == EPI_LIF || EPI == EPI_LIF_ATTN) {
                 pnp[j].decay = clampf(praw[j][0], 0.1f, 0.99f);
@@ -369,20 +382,20 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
         const bool interior = tm * TBM + TBM <= g.r;
         if (EPI == EPI_LRELU_MAX) {
             // LeakyReLU, then the max over groups of max_m rows instead of a store (fd/snn_coder.py:476-480).  A lane walks its
-            // column's 64 rows in ascending order and keeps a running maximum per group: one integer atomicMax per (group,
-            // column) and lane half instead of one per value (the maximum does not depend on the order: exact).
+            // column's 32 rows in ascending order and keeps a running maximum per group: one integer atomicMax per (group,
+            // column) and lane group instead of one per value (the maximum does not depend on the order: exact).
 #pragma unroll
-            for (int j = 0; j < CT; ++j) {
-                const int col = col0 + j * 32 + r32;
+            for (int j = 0; j < CS; ++j) {
+                const int col = col0 + j * 16 + c16;
                 int64_t cur = -1, boundary = 0;
                 float best = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int rs = 0; rs < 8; ++rs) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int64_t rr = row0 + i * 32 + 8 * (e >> 2) + 4 * h + (e & 3);
+                    for (int e = 0; e < 4; ++e) {
+                        const int64_t rr = row0 + rs * 16 + 4 * g4 + e;
                         if (rr >= g.r) continue;
-                        const float v = lrelu02(__fadd_rn(__fmul_rn(acc[i][j][e], 0.0625f), pbias[j]));
+                        const float v = lrelu02(__fadd_rn(__fmul_rn(acc[rs][j][e], 0.0625f), pbias[j]));
                         if (rr >= boundary) {                 // first row, or a new group starts
                             if (cur >= 0) atomicMax(g.max_keys + cur * g.n + col, float_max_key(best));
                             cur = rr / g.max_m;
@@ -396,40 +409,37 @@ __global__ __launch_bounds__(512) void gemm_bt_kernel(const GemmArgs g) {
                 if (cur >= 0) atomicMax(g.max_keys + cur * g.n + col, float_max_key(best));
             }
         } else if (interior && EPI == EPI_LIF_ATTN && !g.c_split && g.c2_split) {
-            bt_epilogue_fast<EPI, CT, false, true>(g, acc, row0, col0, r32, h, pbias, pnp);
+            bt_epilogue_fast<EPI, CS, false, true>(g, acc, row0, col0, c16, g4, pbias, pnp);
         } else if (interior && EPI == EPI_LIF && g.c_split) {
-            bt_epilogue_fast<EPI, CT, true, false>(g, acc, row0, col0, r32, h, pbias, pnp);
+            bt_epilogue_fast<EPI, CS, true, false>(g, acc, row0, col0, c16, g4, pbias, pnp);
         } else if (interior && EPI != EPI_LIF_ATTN && !g.c_split) {
-            bt_epilogue_fast<EPI, CT, false, false>(g, acc, row0, col0, r32, h, pbias, pnp);
+            bt_epilogue_fast<EPI, CS, false, false>(g, acc, row0, col0, c16, g4, pbias, pnp);
         } else
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int rs = 0; rs < 8; ++rs) {
+            const int64_t row = row0 + rs * 16 + 4 * g4;
+            if (row >= g.r) continue;
+            int2 t4[4];                                      // (point row, neighbour row) of this group's 4 edge rows: once for all column sub-blocks
+            if (EPI == EPI_LIF_ATTN) {
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int64_t row = row0 + i * 32 + 8 * q4 + 4 * h;
-                if (row >= g.r) continue;
-                int2 t4[4];                                  // (point row, neighbour row) of this group's 4 edge rows: once for both column blocks
+                for (int u = 0; u < 4; ++u) t4[u] = row + u < g.r ? g.tab[row + u] : make_int2(0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < CS; ++j) {
+                const int col = col0 + j * 16 + c16;
+                float a4[4], cq[4] = {0.f, 0.f, 0.f, 0.f}, ckf[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a4[u] = __fmul_rn(acc[rs][j][u], 0.0625f);      // undo W x 16
                 if (EPI == EPI_LIF_ATTN) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) t4[u] = row + u < g.r ? g.tab[row + u] : make_int2(0, 0);
-                }
-#pragma unroll
-                for (int j = 0; j < CT; ++j) {
-                    const int col = col0 + j * 32 + r32;
-                    float a4[4], cq[4] = {0.f, 0.f, 0.f, 0.f}, ckf[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) a4[u] = __fmul_rn(acc[i][j][q4 * 4 + u], 0.0625f);      // undo W x 16
-                    if (EPI == EPI_LIF_ATTN) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            cq[u] = g.q[(int64_t)t4[u].x * g.ldq + col];
-                            ckf[u] = g.kf[(int64_t)t4[u].y * g.ldq + col];
-                        }
+                    for (int u = 0; u < 4; ++u) {
+                        cq[u] = g.q[(int64_t)t4[u].x * g.ldq + col];
+                        ckf[u] = g.kf[(int64_t)t4[u].y * g.ldq + col];
                     }
-                    epilogue_group4<EPI>(g, a4, row, col, pbias[j], pnp[j], cq, ckf);
                 }
-                __builtin_amdgcn_sched_barrier(0);          // keep the groups apart (128 accumulators live)
+                epilogue_group4<EPI>(g, a4, row, col, pbias[j], pnp[j], cq, ckf);
             }
+            __builtin_amdgcn_sched_barrier(0);              // keep the groups apart (128 accumulators live)
         }
         tm += step_tm;
         tn += step_tn;
