@@ -18,8 +18,9 @@
 // Pipeline: k-step = 32.  Waves 0-3 stream the activation operand (3 slots of 32 KiB, 2 k-steps ahead: first touches, HBM
 // latency), waves 4-7 the weight operand (2 slots, 1 step ahead, L2 hits); one stream per wave because a wave's vector-
 // memory counter completes in order.  The rings run on across tile boundaries (global step counter).  Per step:
-// fragment reads of the second k16 half -> 24 MFMAs -> own DMAs of the next step landed -> barrier -> refill the slot just
-// read -> fragment reads of the next step's first half -> 24 MFMAs.  LDS = 96 + 64 (BN = 256) KiB = all 160 KiB.
+// fragment reads of the tile's rows 64-127 -> the MFMAs of rows 0-63 -> own DMAs of the next step landed -> barrier -> refill the
+// slot just read -> the next step's fragments, read under the MFMAs of rows 64-127 (rows 0-63's operand first, each half of the
+// weight fragments behind the MFMAs that read it last).  LDS = 96 + 64 (BN = 256) KiB = all 160 KiB.
 // The epilogue's global stores also count in vmcnt: the waits after a tile boundary over-wait for them (safe: completion is
 // in order), which costs a short bubble per 256x256 tile.
 #include "common.h"
