@@ -183,32 +183,28 @@ __global__ __launch_bounds__(1024) void gemm_sf16_kernel(const GemmArgs g) {
                     // both k16 halves, then a_hi.w_lo, then a_hi.w_hi
 #pragma unroll
                     for (int k32 = 0; k32 < SBK / 32; ++k32) {
-                        half8 ah[2], al[2], wh[2][2], wl[2][2];
+                        // one product at a time, its six fragments read just before it (w_hi is read twice: holding all twelve
+                        // fragments of a k32 step cost 12 more spilled registers at this kernel's 128 and 10 % of its speed)
+                        auto product = [&](int a_plane, int w_plane) {
+                            half8 a2[2], w2[2][2];
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            const int k16 = 2 * k32 + t;
-                            const int ca = ((k16 * 2 + h) ^ asw) * 16;
-                            ah[t] = *reinterpret_cast<const half8*>(sA + ca);
-                            al[t] = *reinterpret_cast<const half8*>(sA + PLANE_BYTES + ca);
+                            for (int t = 0; t < 2; ++t) {
+                                const int k16 = 2 * k32 + t;
+                                a2[t] = *reinterpret_cast<const half8*>(sA + a_plane * PLANE_BYTES + ((k16 * 2 + h) ^ asw) * 16);
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) {
-                                const unsigned char* sW = st + 2 * PLANE_BYTES + wrow_l[j] * (SBK * 2) + (((k16 * 2 + h) ^ wsw[j]) * 16);
-                                wh[t][j] = *reinterpret_cast<const half8*>(sW);
-                                wl[t][j] = *reinterpret_cast<const half8*>(sW + PLANE_BYTES);
+                                for (int j = 0; j < 2; ++j)
+                                    w2[t][j] = *reinterpret_cast<const half8*>(st + (2 + w_plane) * PLANE_BYTES + wrow_l[j] * (SBK * 2) +
+                                                                               (((k16 * 2 + h) ^ wsw[j]) * 16));
                             }
-                        }
 #pragma unroll
-                        for (int t = 0; t < 2; ++t)
+                            for (int t = 0; t < 2; ++t)
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], wh[t][j], acc[j], 0, 0, 0);
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], wl[t][j], acc[j], 0, 0, 0);
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], wh[t][j], acc[j], 0, 0, 0);
+                                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[t], w2[t][j], acc[j], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        };
+                        product(1, 0);      // a_lo . w_hi
+                        product(0, 1);      // a_hi . w_lo
+                        product(0, 0);      // a_hi . w_hi
                     }
                     if (kt + 1 < nk) {
                         store_a(cur ^ 1);
