@@ -16,12 +16,13 @@
 // so ALL T spikes of a (point, channel) are a function of its ONE pre-activation x0 at t = 0.  The kernel therefore keeps x0 —
 // 48 x 960 floats: blocks 0-2 in LDS (84 KiB), block 3 in registers (48 per lane) — and regenerates the spikes where they are
 // consumed: step-0 spikes as the f32 features of the next block's neighbour search and as the split-f16 operand of its EdgeConv
-// GEMM; all steps as the operand of multi_scale_conv.  That contraction stacks the T steps as ROWS (row = 48 t + point: 192 rows
-// = six 32x32 MFMA row blocks, no padded row at T = 4) and walks N in passes of 256 columns (one column block per wave, 96
-// accumulator registers), K in rounds of 64 columns: per round every thread runs the T-step neuron loop of six (point, channel)
-// elements with the state in registers, writes the spikes into a 48 KiB split-f16 panel and the waves multiply the panel with
-// weight fragments streamed L2 -> registers in fragment order (the fn_edge_chain.hip recipe).  The max over the points is taken
-// in the accumulator layout on order-preserving integer keys, like the GEMM epilogue it replaces.
+// GEMM; all steps as the operand of multi_scale_conv.  That contraction takes the patch in thirds of 16 points with the T steps
+// stacked as ROWS (row = 4 point + step: 64 rows, no padded row at T = 4), every wave 96 of ALL emb columns (96 accumulator
+// registers: one sweep over K per third), K in rounds of 128 columns: per round every thread runs the T-step neuron loop of four
+// (point, channel) elements with the state in registers, writes the spikes into a 32 KiB split-f16 panel and the waves multiply the
+// panel with weight fragments streamed L2 -> registers in fragment order (the fn_edge_chain.hip recipe; v_mfma_f32_16x16x32_f16,
+// pass-major, since round 3).  The max over the points is a running maximum of the raw accumulators in the accumulator layout
+// (bias, LeakyReLU and the order-preserving integer key are monotone: once per result), like the GEMM epilogue it replaces.
 //
 // Bit-identical to the per-stage path (tests/test_gpu_parity.py::test_fused_fd_encoder_equals_the_per_stage_path_bit_for_bit):
 // same score chains and tie rule in the neighbour searches, same split-f16 products in the same k order, same neuron arithmetic
@@ -408,10 +409,6 @@ __device__ __forceinline__ void fe_emit4(const float (&x)[4], const NeuronP& p, 
     }
 }
 
-// one K round of multi_scale_conv: nk16 k16 steps (8: 128 columns; 4 in the last round) starting at absolute step s_abs, this
-// wave's 2 row blocks x 3 column blocks cb0 .. cb0 + 2 (ALL emb columns are covered by the eight waves in one sweep over K, so
-// every spike is generated once).  Weight fragments L2 -> registers two k16 steps ahead, refilled in place behind the MFMAs
-// that read them; the loop is rolled (a fully unrolled K sweep makes the compiler precompute — and spill — every fragment address).
 __device__ __forceinline__ unsigned fe_group_max(unsigned x) {    // max over the four lane groups' values, in all of them
     const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);       // [g0,g0,g2,g2], [g1,g1,g3,g3]
     const unsigned m1 = r[0] > r[1] ? r[0] : r[1];
