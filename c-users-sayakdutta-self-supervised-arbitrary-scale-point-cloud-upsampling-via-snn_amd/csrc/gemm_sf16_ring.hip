@@ -3,7 +3,8 @@
 //   C[r, n] = epi( A[r, k] . W[n, k]^T + bias[n] )
 //
 // Same arithmetic as gemm_sf16.hip (x = hi + lo halves, three v_mfma_f32_32x32x16_f16 per product into one
-// f32 accumulator, weights pre-scaled by 16), but A arrives ALREADY SPLIT ("split rows", gemm_epi.h: the
+// f32 accumulator, weights pre-scaled by 16; since round 3 accumulated pass-major per k32 step — a_lo.w_hi over both k16 halves, then
+// a_hi.w_lo, then a_hi.w_hi: what the 16x16x32 kernels of the library produce bit for bit), but A arrives ALREADY SPLIT ("split rows", gemm_epi.h: the
 // producing epilogue / element-wise kernel wrote hi and lo halves instead of an f32), so BOTH operands are
 // plain f16 planes that stream global -> LDS by LDS-DMA with no registers and no VALU in between.
 //
