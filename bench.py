@@ -227,6 +227,36 @@ def m100_leg(fn, fd, dev, cloud, seeds, steps=3):
             "unit": "query-points/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps}
 
 
+def ref_default_leg(dev, cloud, seeds, steps=2):
+    """The configuration `generate.py` + `config/*.yaml` of the reference really run: k_neighbors = 100 (generation.py:68; generate.py:135
+    keeps it), fn time_steps_enc = 6 (config/fn.yaml:41), fd time_steps_enc = 7 (config/fd.yaml:47) — BASELINE's M = 48, T = 4 is a benchmark
+    choice.  Own model handles (the temporal-integration weights have shape [T]); same cloud, same 4096 queries, conditioned weights seed 0."""
+    import sapcu_amd
+    from sapcu_amd import testing as T
+    gold = os.path.join(ROOT, "tests", "golden")
+    fn = sapcu_amd.ImprovedSNNNormalEstimation(**dict(FN_KW, time_steps_enc=6))
+    fd = sapcu_amd.EnhancedSNNDistanceEstimation(**dict(FD_KW, time_steps_enc=7))
+    for m, kind in ((fn, "fn"), (fd, "fd")):
+        p = os.path.join(gold, "bn_calib_%s.npz" % kind)
+        m.load_state_dict(T.conditioned_state_dict(m.state_dict(), 0, bn_stats=dict(np.load(p)) if os.path.exists(p) else None))
+    fn, fd = fn.to(dev), fd.to(dev)
+    fn.knn_cache_mode = "fresh"
+    g = sapcu_amd.Generator3D6(fn, fd, dev, k_neighbors=100, batch_size=B_PER_GPU)
+    with torch.no_grad():
+        g.refine(cloud, seeds)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out, _, _ = g.refine(cloud, seeds)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(out).all()
+    g.check_numeric_guards()
+    return {"workload": "as config.workload with the reference's defaults: M=100 neighbours (generation.py:68), fn T=6 (config/fn.yaml:41), "
+                        "fd T=7 (config/fd.yaml:47)", "value": round(B_PER_GPU / dt, 2), "unit": "query-points/s",
+            "ms_per_step": round(dt * 1e3, 3), "steps": steps}
+
+
 def cpu_baseline(sdn, sdd, sample=256):
     """Oracle on `sample` of the same queries (kNN + fn + rotate + fd + displace), all host threads.  256 = ONE full chunk of the
     reference's own batching (generate.py:135 batch_size=256), ~45 s on the GPU box's 16 host cores."""
@@ -254,12 +284,27 @@ def cpu_baseline(sdn, sdd, sample=256):
             "sample": "%d of the %d queries = one reference-sized chunk (generate.py:135 batch_size=256), oracle (torch-CPU restatement), %.1f s" % (sample, B_PER_GPU, dt)}
 
 
+def _count_gpus_in_child():
+    """Fallback of spawn_ranks when sysfs has no KFD topology: the runtime's own device count, taken in a child process so
+    that THIS process still never loads HIP."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=600)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        raise SystemExit("bench.py: cannot count the GPUs (no /sys/class/kfd topology, and the runtime query failed: %s)" % r.stderr[-500:])
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` as a plain command: start one rank per GPU through torch.distributed.run as a CHILD
-    process (this process has not touched the GPU: device_count() does not initialise it) and return its exit code."""
+    process and return its exit code.  This parent is GPU-free BY CONSTRUCTION: the devices are counted from the KFD topology
+    in sysfs + the visibility variables (sapcu_amd.dist.visible_gpu_count), never through the HIP runtime."""
     import socket
     import subprocess
-    n_dev = torch.cuda.device_count()
+    from sapcu_amd.dist import visible_gpu_count
+    n_dev = visible_gpu_count()
+    if n_dev is None:                 # no KFD topology in sysfs: ask the runtime, but in a throw-away CHILD process
+        n_dev = _count_gpus_in_child()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if n_dev < args.gpus:
@@ -288,6 +333,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-strong-leg", action="store_true", help="skip the extra whole-cloud pass of the weak mode")
     ap.add_argument("--no-m100", action="store_true", help="skip the secondary M=100 figure")
+    ap.add_argument("--no-ref-default", action="store_true", help="skip the figure at the reference's default configuration (M=100, fn T=6, fd T=7)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -363,7 +409,9 @@ def main():
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
     def timed(fn_step, k):
-        """k steps between barrier + synchronize on both sides; MAX over ranks (seconds)"""
+        """k steps between barrier + synchronize on both sides; MAX over ranks (seconds).  Also returns (min, max) over the ranks
+        of each rank's OWN time from the first barrier to its last step's completion — before it waits for the others — so that
+        a skewed rank shows in the record."""
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -371,15 +419,46 @@ def main():
         for _ in range(k):
             out = fn_step()
         torch.cuda.synchronize()
+        own = time.perf_counter() - t0
         barrier()
         dt = time.perf_counter() - t0
         assert torch.isfinite(out).all()
+        spread = (own, own)
         if use_pg:
             import torch.distributed as dist
-            tt = torch.tensor([dt], dtype=torch.float64, device=torch.device("cpu") if rehearse else dev)
+            cdev = torch.device("cpu") if rehearse else dev
+            tt = torch.tensor([dt, own, -own], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt, out
+            dt, spread = float(tt[0].item()), (-float(tt[2].item()), float(tt[1].item()))
+        return dt, out, spread
+
+    def allgather_alone(n_total, reps=10):
+        """The path's one collective by itself: all-gather of [ceil(n/G), 3] f64 slabs (what gather_refined sends), `reps` calls
+        between two events on the current stream (RCCL's own stream is ordered against it by torch on both sides); gloo
+        rehearsals: wall clock.  Returns microseconds per call, max over the ranks."""
+        import torch.distributed as dist
+        s, e = sdist.shard_range(n_total, rank, world)
+        slab = torch.zeros((e - s, 3), dtype=torch.float64, device=dev)
+        for _ in range(2):
+            sdist.gather_refined(slab, n_total)
+        torch.cuda.synchronize()
+        barrier()
+        if rehearse:
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                sdist.gather_refined(slab, n_total)
+            us = (time.perf_counter() - t0) * 1e6 / reps
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                sdist.gather_refined(slab, n_total)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+        tt = torch.tensor([us], dtype=torch.float64, device=torch.device("cpu") if rehearse else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return round(float(tt.item()), 1)
 
     log("models and inputs resident; warmup x%d" % args.warmup)
     for i in range(args.warmup):
@@ -387,9 +466,11 @@ def main():
         step()
         torch.cuda.synchronize()
         log("warmup step %d: %.1f ms" % (i, (time.perf_counter() - tw) * 1e3))
-    dt, out = timed(step, args.steps)
+    dt, out, spread = timed(step, args.steps)
     per_step = all_seeds.shape[0] if strong else B_PER_GPU * world
-    log("timed %d steps: %.1f ms/step" % (args.steps, dt / args.steps * 1e3))
+    log("timed %d steps: %.1f ms/step (per rank, own time: %.1f .. %.1f ms/step)"
+        % (args.steps, dt / args.steps * 1e3, spread[0] / args.steps * 1e3, spread[1] / args.steps * 1e3))
+    allgather_us = allgather_alone(per_step) if use_pg else None
 
     strong_leg = None
     if want_strong_leg and not strong:
@@ -397,10 +478,13 @@ def main():
         # that RCCL's buffers for this message size exist
         if use_pg:
             strong_step()
-        dts, outs = timed(strong_step, 1)
+        dts, outs, sspread = timed(strong_step, 1)
         strong_leg = {"seeds": int(all_seeds.shape[0]), "n_gpus": world, "ms_per_pass": round(dts * 1e3, 2),
                       "value": round(all_seeds.shape[0] / dts, 2), "unit": "query-points/s", "scaling": "strong",
-                      "collective": "one all-gather of the refined [n,3] f64 cloud per pass"}
+                      "collective": "one all-gather of the refined [n,3] f64 cloud per pass",
+                      "rank_ms_per_pass": {"min": round(sspread[0] * 1e3, 2), "max": round(sspread[1] * 1e3, 2)}}
+        if use_pg:
+            strong_leg["allgather_us"] = allgather_alone(int(all_seeds.shape[0]))
         log("strong-scaling leg: %s" % strong_leg)
 
     line = None
@@ -430,6 +514,9 @@ def main():
         if use_pg:
             import torch.distributed as dist
             line["collective_backend"] = dist.get_backend()
+            # the record explains itself: the collective alone, and each rank's own step time (before it waits for the others)
+            line["allgather_us"] = allgather_us
+            line["rank_ms_per_step"] = {"min": round(spread[0] / args.steps * 1e3, 3), "max": round(spread[1] / args.steps * 1e3, 3)}
         if strong_leg:
             line["strong_scaling"] = strong_leg
         if not args.no_roofline:
@@ -439,6 +526,9 @@ def main():
             if not args.no_m100:
                 line["m100"] = m100_leg(fn, fd, dev, cloud, seeds)
                 log("M=100 leg: %s" % line["m100"])
+            if not args.no_ref_default:
+                line["ref_default"] = ref_default_leg(dev, cloud, seeds)
+                log("reference-default leg: %s" % line["ref_default"])
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sdn, sdd)
             log("cpu baseline done: %s" % line["cpu_baseline"])

@@ -17,6 +17,7 @@ EXACT_LIB_PATH = os.path.join(_HERE, "csrc", "libsapcu_hip_exact.so")
 FN_TAPS = ("stem", "block1", "block2", "block3", "pooled", "enc", "logits")
 FD_TAPS = ("fused0", "spikes", "knn", "pooled", "enc", "x0")
 KIND_FN, KIND_FD = 0, 1
+ABI_VERSION = 2        # include/sapcu.h SAPCU_ABI_VERSION this binding was written against (2: six fd taps)
 
 
 class SapcuLibraryError(RuntimeError):
@@ -55,6 +56,7 @@ _SIGNATURES = {
     "sapcu_group_max_forward": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sapcu_group_max_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "sapcu_neuron_selfloop": (c_int, [c_void_p, c_int64, c_int, c_int] + [c_void_p] * 6 + [c_void_p] * 4 + [c_void_p]),
+    "sapcu_neuron_drive": (c_int, [c_void_p, c_int64, c_int, c_int] + [c_void_p] * 6 + [c_int] + [c_void_p] * 5 + [c_void_p]),
     "sapcu_patch_knn": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sapcu_model_create": (c_int, [c_int, POINTER(c_int32), c_int, c_void_p, c_int64, POINTER(c_int64), c_int,
                                    POINTER(c_void_p)]),
@@ -103,8 +105,8 @@ def load(path=None):
             raise SapcuLibraryError("%s does not export %s" % (p, name)) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.sapcu_abi_version() != 1:
-        raise SapcuLibraryError("ABI version mismatch: library %d, binding 1" % lib.sapcu_abi_version())
+    if lib.sapcu_abi_version() != ABI_VERSION:
+        raise SapcuLibraryError("ABI version mismatch: library %d, binding %d" % (lib.sapcu_abi_version(), ABI_VERSION))
     if path is None:
         _lib = lib
     return lib

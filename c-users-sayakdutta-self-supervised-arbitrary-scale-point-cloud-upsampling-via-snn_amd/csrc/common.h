@@ -143,8 +143,10 @@ __device__ __forceinline__ float neuron_step(float x, NeuronS& s, const NeuronP&
 // neuron loop (GEMM epilogues, pos-enc kernel, stem).  State lives in registers for all T steps, and the loop is
 // peeled around two exact facts about neuron_step<false>:
 //   * step 0 starts from m = 0, r = 0:  m = x,  r = s0;
-//   * for t >= 1 the gate `x * (r <= 0)` is closed — the spike surrogate is > 0, so r > 0 — and the fed-back input
-//     contributes exactly +0;  the state updates after the last spike are dead.
+//   * for t >= 1 the gate `x * (r <= 0)` is closed — the reference's clamped spike surrogate is >= 3.85e-23 > 0, so its r > 0
+//     for every finite input — and the fed-back input contributes exactly +0 (the peel follows the reference's gate, not the
+//     sign of this build's own r, which may underflow to 0 without the clamp: see soft_spike2);  the state updates after the
+//     last spike are dead.
 // Chains are processed as 2-vectors (v_pk_mul/add/fma_f32: one instruction, two chains); H pairs are advanced together
 // (independent chains = VALU ILP).
 //
@@ -177,6 +179,14 @@ __device__ __forceinline__ f32x2 pk_clamp10(f32x2 d) { return f32x2{clampf(d.x, 
 // either way (exp2(+-144) is inf / below 2^-126 next to 1), and the Gaussian term is 0.1995 exp(-50) = 3.9e-23 clamped
 // against something smaller un-clamped: the spike moves by < 4e-23 absolute, the split-f16 operand made from it not at all
 // (below half the smallest f16 subnormal).  x = +-inf gives 0 / 1 + 0 without the clamp as well (x*x = inf -> exp2(-inf) = 0).
+//
+// What the clamp also guaranteed: spike >= 0.1995 exp(-50) = 3.85e-23 > 0, hence refractory r > 0 from step 0 on — the closed gate
+// that the peeled loops and fd's dead-stage elimination rest on.  Un-clamped, both exponentials underflow for x below about -13.2
+// and the spike is exactly 0.  The VALUE path does not notice (1 - r and m * (1 - r) are the same f32 for r = 0 and r = 3.85e-23),
+// but a refractory state built from it would read "gate open" where the reference's gate is closed.  The stepping forms that
+// carry r and count gate violations (NeuronStep2 / NeuronStep2V) therefore floor the step-0 refractory at SPIKE_FLOOR, the
+// reference's own minimum: r is then >= the reference's r up to rounding, and gate_open() tests what the reference's gate tests.
+constexpr float SPIKE_FLOOR = 3.8e-23f;      // just below 0.5 exp(-50) / sqrt(2 pi) + 0.5 sigmoid(-100) = 3.847e-23 (fn:135-146 at x = -10)
 __device__ __forceinline__ f32x2 soft_spike2(f32x2 d) {
 #if defined(SAPCU_LIF_EXACT_ORDER) || defined(SAPCU_SPIKE_CLAMP)     // (the second macro: same-box A/B builds, profiles/step_ab.py)
     const f32x2 x = pk_clamp10(d);
@@ -357,7 +367,7 @@ struct NeuronStep2 {
         }
         const f32x2 sp = soft_spike2(mm - s.th);
         s.m = pk_fma(-mm, sp, mm);
-        s.r = first ? sp : pk_fma(s.r, rdecay, sp);
+        s.r = first ? f32x2{fmaxf(sp.x, SPIKE_FLOOR), fmaxf(sp.y, SPIKE_FLOOR)} : pk_fma(s.r, rdecay, sp);   // (floor: see soft_spike2)
         s.th = pk_fma(s.th, f32x2{0.95f, 0.95f}, pk_fma(sp, a95, thc));
         return sp;
 #endif
@@ -417,7 +427,7 @@ struct NeuronStep2V {
         }
         const f32x2 sp = soft_spike2(mm - s.th);
         s.m = pk_fma(-mm, sp, mm);
-        s.r = first ? sp : pk_fma(s.r, rdecay, sp);
+        s.r = first ? f32x2{fmaxf(sp.x, SPIKE_FLOOR), fmaxf(sp.y, SPIKE_FLOOR)} : pk_fma(s.r, rdecay, sp);   // (floor: see soft_spike2)
         s.th = pk_fma(s.th, f32x2{0.95f, 0.95f}, pk_fma(sp, a95, thc));
         return sp;
 #endif

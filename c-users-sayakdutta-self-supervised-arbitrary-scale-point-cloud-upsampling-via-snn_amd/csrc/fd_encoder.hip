@@ -26,8 +26,8 @@
 //
 // Bit-identical to the per-stage path (tests/test_gpu_parity.py::test_fused_fd_encoder_equals_the_per_stage_path_bit_for_bit):
 // same score chains and tie rule in the neighbour searches, same split-f16 products in the same k order, same neuron arithmetic
-// (block 0: neuron_step<true>, blocks 1-3: NeuronStep2), same max.  Taken for patches of <= 48 points, <= 4 scales, emb % 256 == 0;
-// anything else runs the per-stage kernels.
+// (block 0: neuron_step<true>, blocks 1-3: NeuronStep2), same max.  Taken for patches of <= 48 points, <= 4 scales, emb % 32 == 0 and
+// emb >= 96 (fd_encoder_ok); anything else runs the per-stage kernels.
 #include <type_traits>
 
 #include "common.h"
@@ -881,7 +881,10 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
             third(std::integral_constant<int, 0>{});
             third(std::integral_constant<int, 1>{});
             third(std::integral_constant<int, 2>{});
-            if (cbw + 2 < ncb || sweep == 0) {                          // (a clamped tail wave of a later sweep stores nothing new)
+            // a wave stores whenever it owns at least one column block of this sweep: a tail wave (cbw < ncb <= cbw + 2) was clamped to
+            // the LAST three blocks, of which ncb - cbw are its own and the others are re-stored with the values their owners write
+            // (same rows, same K order: identical bits).  emb = 800 / 896 / 1024 have such tails in the second sweep.
+            if (cbw < ncb) {
 #pragma unroll
                 for (int j = 0; j < 6; ++j)
 #pragma unroll

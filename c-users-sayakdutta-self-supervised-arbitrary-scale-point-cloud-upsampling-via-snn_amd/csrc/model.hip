@@ -708,6 +708,18 @@ int sapcu_neuron_selfloop(const float* x, int64_t rows, int channels, int steps,
                                   refractory_out, (hipStream_t)stream);
 }
 
+int sapcu_neuron_drive(const float* x, int64_t rows, int channels, int steps, const float* membrane_decay,
+                       const float* threshold_adapt, const float* refractory_decay, const float* threshold_base,
+                       const float* delta_T, const float* theta_rh, int channel_pairs, float* spikes_out, float* membrane_out,
+                       float* threshold_out, float* refractory_out, int* gate_open_out, void* stream) {
+    SAPCU_CHECK_ARG(x && membrane_decay && threshold_adapt && refractory_decay && threshold_base, "neuron_drive: null pointer");
+    SAPCU_CHECK_ARG((delta_T == nullptr) == (theta_rh == nullptr), "neuron_drive: delta_T and theta_rh go together");
+    SAPCU_CHECK_ARG(rows >= 0 && channels >= 1 && steps >= 1, "neuron_drive: bad sizes");
+    return launch_neuron_drive(x, rows, channels, steps, membrane_decay, threshold_adapt, refractory_decay, threshold_base, delta_T,
+                               theta_rh, channel_pairs, spikes_out, membrane_out, threshold_out, refractory_out, gate_open_out,
+                               (hipStream_t)stream);
+}
+
 int sapcu_patch_knn(const float* feat, int64_t b, int m, int c, int ld, int k, int32_t* idx_out, void* stream) {
     SAPCU_CHECK_ARG(feat && idx_out && b >= 0 && ld >= c, "patch_knn: bad argument");
     return launch_patch_knn(feat, b, m, c, ld, k, idx_out, (hipStream_t)stream);

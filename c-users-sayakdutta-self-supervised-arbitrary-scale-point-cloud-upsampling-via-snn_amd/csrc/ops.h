@@ -12,6 +12,8 @@ int launch_patch_knn(const float* feat, int64_t b, int m, int c, int ld, int k, 
 int launch_neuron_selfloop(const float* x, int64_t rows, int ch, int T, const float* md, const float* ta,
                            const float* rd, const float* tb, const float* dT, const float* rh, float* so, float* mo,
                            float* to, float* ro, hipStream_t st);
+int launch_neuron_drive(const float* x, int64_t rows, int ch, int T, const float* md, const float* ta, const float* rd, const float* tb,
+                        const float* dT, const float* rh, int pairv, float* so, float* mo, float* to, float* ro, int* gate, hipStream_t st);
 int launch_fn_stem(const float* patch, int64_t rows, const float* w, const float* bias, const float* lif, int T,
                    float* out, hipStream_t st);
 int launch_fn_pe1(const float* patch, const int32_t* idx, int64_t rows, int m, int kk, int d, const float* w,

@@ -218,6 +218,91 @@ int launch_patch_knn(const float* feat, int64_t b, int m, int c, int ld, int k, 
 }
 
 // =============================================================================================
+// Neuron unit kernel for the STEPPING form fd's encoder runs (NeuronStep2 / NeuronStep2V: fd_encoder.hip, fd_edge_neuron_kernel):
+// the input enters at step 0 only (closed gate), every step's spikes are kept, and the refractory state the gate would test is
+// examined before each later step exactly as those kernels do.  A thread steps the pair (row 2i, row 2i + 1) of one channel
+// (PAIRV: rows i of channels 2c, 2c + 1 — the NeuronStep2V form).  spikes [T, rows, ch]; gate: events with an open gate.
+// =============================================================================================
+template <bool EIF, bool PAIRV>
+__global__ __launch_bounds__(256) void neuron_drive_kernel(const float* __restrict__ x, int64_t rows, int ch, int T, const float* md,
+                                                           const float* ta, const float* rd, const float* tb, const float* dT,
+                                                           const float* rh, float* __restrict__ so, float* mo, float* to, float* ro,
+                                                           int* __restrict__ gate) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t npair = PAIRV ? rows * ((ch + 1) / 2) : ((rows + 1) / 2) * ch;
+    if (t >= npair) return;
+    int64_t ea, eb;                                   // the pair's two elements (eb == ea: an odd tail, stepped twice)
+    int ca, cb;
+    if (PAIRV) {
+        const int hc = (ch + 1) / 2;
+        const int64_t r = t / hc;
+        ca = 2 * (int)(t % hc);
+        cb = ca + 1 < ch ? ca + 1 : ca;
+        ea = r * ch + ca;
+        eb = r * ch + cb;
+    } else {
+        ca = cb = (int)(t % ch);
+        const int64_t r = 2 * (t / ch), r1 = r + 1 < rows ? r + 1 : r;
+        ea = r * ch + ca;
+        eb = r1 * ch + cb;
+    }
+    auto prm = [&](int c) {
+        NeuronP p;
+        p.decay = clampf(md[c], 0.1f, 0.99f);
+        p.adapt = clampf(ta[c], 0.001f, 0.1f);
+        p.rdecay = clampf(rd[c], 0.1f, 0.95f);
+        p.theta0 = tb[c];
+        p.dT = EIF ? clampf(dT[c], 0.1f, 5.0f) : 0.f;
+        p.rh = EIF ? clampf(rh[c], 0.1f, 2.0f) : 0.f;
+        return p;
+    };
+    const f32x2 xin = f32x2{x[ea], x[eb]}, z = f32x2{0.f, 0.f};
+    int open = 0;
+    f32x2 m2, th2, r2;
+    auto run = [&](auto& n) {
+        for (int step = 0; step < T; ++step) {
+            if (step > 0 && n.gate_open()) ++open;
+            const f32x2 sp = n.step(step == 0 ? xin : z, step == 0);
+            if (so) {
+                so[(int64_t)step * rows * ch + ea] = sp.x;
+                so[(int64_t)step * rows * ch + eb] = sp.y;
+            }
+        }
+#ifdef SAPCU_LIF_EXACT_ORDER
+        m2 = f32x2{n.sx.m, n.sy.m}; th2 = f32x2{n.sx.th, n.sy.th}; r2 = f32x2{n.sx.r, n.sy.r};
+#else
+        m2 = n.s.m; th2 = n.s.th; r2 = n.s.r;
+#endif
+    };
+    if (PAIRV) {
+        NeuronStep2V<EIF> n(prm(ca), prm(cb));
+        run(n);
+    } else {
+        NeuronStep2<EIF> n(prm(ca));
+        run(n);
+    }
+    if (mo) { mo[ea] = m2.x; mo[eb] = m2.y; }
+    if (to) { to[ea] = th2.x; to[eb] = th2.y; }
+    if (ro) { ro[ea] = r2.x; ro[eb] = r2.y; }
+    if (open && gate) atomicAdd(gate, open);
+}
+
+int launch_neuron_drive(const float* x, int64_t rows, int ch, int T, const float* md, const float* ta, const float* rd, const float* tb,
+                        const float* dT, const float* rh, int pairv, float* so, float* mo, float* to, float* ro, int* gate, hipStream_t st) {
+    const int64_t npair = pairv ? rows * ((ch + 1) / 2) : ((rows + 1) / 2) * ch;
+    if (npair == 0) return SAPCU_OK;
+    const dim3 grid((unsigned)((npair + 255) / 256)), blk(256);
+#define SAPCU_ND(E, V) hipLaunchKernelGGL((neuron_drive_kernel<E, V>), grid, blk, 0, st, x, rows, ch, T, md, ta, rd, tb, dT, rh, so, mo, to, ro, gate)
+    if (dT && pairv) SAPCU_ND(true, true);
+    else if (dT) SAPCU_ND(true, false);
+    else if (pairv) SAPCU_ND(false, true);
+    else SAPCU_ND(false, false);
+#undef SAPCU_ND
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+// =============================================================================================
 // Neuron unit kernel (parity tests of the step arithmetic; fn:87-153, fd:198-275)
 // =============================================================================================
 template <bool EIF>
@@ -1027,14 +1112,23 @@ int launch_fd_neuron(bool eif, int mode, const float* in, int ldi, const int32_t
         (((uintptr_t)in | (uintptr_t)spk | (uintptr_t)shift) & 15) == 0) {
         const dim3 g2((unsigned)(pts / m), (unsigned)((C + FDE_CH - 1) / FDE_CH));
         const size_t lds = (size_t)m * FDE_CH * sizeof(float) + (((size_t)m * kk + 15) & ~(size_t)15);
-        if (eif)
-            hipLaunchKernelGGL(fd_edge_neuron_kernel<true>, g2, dim3(256), lds, st, in, ldi, idx, kk, m, shift, pts, C, prm,
-                               T, spk, ldo, coff, gate_violations, spk_split);
-        else
-            hipLaunchKernelGGL(fd_edge_neuron_kernel<false>, g2, dim3(256), lds, st, in, ldi, idx, kk, m, shift, pts, C,
-                               prm, T, spk, ldo, coff, gate_violations, spk_split);
-        SAPCU_CHECK_LAUNCH();
-        return SAPCU_OK;
+        // patches of 121..256 points: the tile + the byte table pass the default 64 KiB dynamic-LDS limit (m = 128, kk = 32: 68 KiB;
+        // m = 256, kk = 256: 192 KiB does not fit a CU at all and takes the scalar kernel below)
+        if (lds <= 160 * 1024) {
+            if (eif) {
+                static DeviceOnce once;
+                if (lds > 65536) SAPCU_SET_MAX_LDS(once, (&fd_edge_neuron_kernel<true>), 160 * 1024);
+                hipLaunchKernelGGL(fd_edge_neuron_kernel<true>, g2, dim3(256), lds, st, in, ldi, idx, kk, m, shift, pts, C, prm,
+                                   T, spk, ldo, coff, gate_violations, spk_split);
+            } else {
+                static DeviceOnce once;
+                if (lds > 65536) SAPCU_SET_MAX_LDS(once, (&fd_edge_neuron_kernel<false>), 160 * 1024);
+                hipLaunchKernelGGL(fd_edge_neuron_kernel<false>, g2, dim3(256), lds, st, in, ldi, idx, kk, m, shift, pts, C,
+                                   prm, T, spk, ldo, coff, gate_violations, spk_split);
+            }
+            SAPCU_CHECK_LAUNCH();
+            return SAPCU_OK;
+        }
     }
     const dim3 grid((unsigned)((pts * C + 255) / 256)), blk(256);
 #define SAPCU_FDN(E, M)                                                                                            \

@@ -12,8 +12,59 @@ fn's shape-keyed neighbour cache (fn/snn_coder.py:47-59) makes reference-mode re
 which batch a process sees first, so a sharded run cannot reproduce a single-process reference run
 bit for bit; sharded runs therefore use ``knn_cache_mode='fresh'`` (stated in DESIGN.md).
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def visible_gpu_count(sysfs_root="/sys/class/kfd/kfd/topology/nodes", dev_root="/dev/dri", environ=None):
+    """Number of GPUs a process started from here would see — WITHOUT loading the HIP runtime (a launcher parent must stay
+    GPU-free so that it may start ranks; touching HIP and then exec'ing / forking rank processes is what takes boxes down).
+    Counts the KFD topology nodes that are GPUs (``simd_count`` > 0; CPU nodes have 0) and whose render node
+    ``/dev/dri/renderD<drm_render_minor>`` this process can open (a container sees every node of the host in sysfs but only its
+    own device files), then applies the runtime's visibility lists the way ROCm does: ROCR_VISIBLE_DEVICES filters the
+    physical list, HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES index into the result (an empty string hides everything; an
+    entry the list cannot resolve ends it, as in the runtime).  Returns None when there is no KFD topology to read (not a ROCm
+    box) — the caller decides what that means."""
+    env = os.environ if environ is None else environ
+    try:
+        nodes = sorted(os.listdir(sysfs_root), key=lambda s: (len(s), s))
+    except OSError:
+        return None
+    gpus = []
+    for nd in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(os.path.join(sysfs_root, nd, "properties")) if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) <= 0:
+            continue
+        minor = int(props.get("drm_render_minor", "-1"))
+        node = os.path.join(dev_root, "renderD%d" % minor)
+        if minor < 0 or not os.access(node, os.R_OK | os.W_OK):
+            continue
+        gpus.append(nd)
+    count = len(gpus)
+
+    def apply(var, n):
+        if var not in env:
+            return n
+        entries = [e.strip() for e in env[var].split(",")] if env[var].strip() else []
+        k = 0
+        for e in entries:
+            if e.isdigit():
+                if int(e) >= n:
+                    break
+            elif not e.upper().startswith("GPU-"):          # neither an index nor a UUID: the runtime stops here
+                break
+            k += 1
+        return min(k, n)
+
+    count = apply("ROCR_VISIBLE_DEVICES", count)
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        count = apply(var, count)
+    return count
 
 
 def shard_range(n, rank, world):

@@ -25,7 +25,11 @@
 extern "C" {
 #endif
 
-#define SAPCU_ABI_VERSION 1
+/* The ABI version changes whenever a caller built against the previous header could misbehave with this library:
+ *   1 -> 2: SAPCU_FD_TAP_COUNT grew from 5 to 6 (SAPCU_FD_TAP_X0 appended) and sapcu_fd_forward reads all SAPCU_FD_TAP_COUNT
+ *           entries of a non-NULL `taps_host` array — a version-1 caller's 5-entry array would be read one pointer past its end.
+ * A binding must refuse to run unless sapcu_abi_version() == the SAPCU_ABI_VERSION it was built against (sapcu_amd/_lib.py does). */
+#define SAPCU_ABI_VERSION 2
 
 typedef enum {
     SAPCU_OK = 0,
@@ -96,6 +100,19 @@ int sapcu_neuron_selfloop(const float* x, int64_t rows, int channels, int steps,
                           const float* delta_T, const float* theta_rh,
                           float* spikes_out, float* membrane_out, float* threshold_out,
                           float* refractory_out, void* stream);
+
+/* The STEPPING form of the same neurons as fd's encoder runs them (fd/snn_coder.py:432-474 in eval mode): x enters at step 0
+ * only — from step 1 on the refractory gate `x * (r <= 0)` is closed, fd:133,249 — and every step's spikes are kept:
+ * spikes_out [steps, rows, channels].  The packed two-chain arithmetic of csrc/fd_encoder.hip / fd_edge_neuron_kernel
+ * (channel_pairs = 0: two rows of one channel per chain pair; 1: two channels of one row).  *gate_open_out (device int, the
+ * caller zeroes it) += number of (pair, step >= 1) events at which the kernels' gate test found r <= 0 — the same test that feeds
+ * sapcu_model_gate_violations; 0 for every finite input, as in the reference (its clamped spike is >= 3.85e-23). */
+int sapcu_neuron_drive(const float* x, int64_t rows, int channels, int steps,
+                       const float* membrane_decay, const float* threshold_adapt,
+                       const float* refractory_decay, const float* threshold_base,
+                       const float* delta_T, const float* theta_rh, int channel_pairs,
+                       float* spikes_out, float* membrane_out, float* threshold_out,
+                       float* refractory_out, int* gate_open_out, void* stream);
 
 /* Training-mode neuron loop (first piece) — fn/snn_coder.py:87-151 with `self.training`, driven
  * as `for t: x, *st = snn(x, *st)` (:318-320): forward value = hard spikes (m - theta > 0), derivative = the soft

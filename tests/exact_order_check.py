@@ -40,6 +40,21 @@ def main():
             ref = g["%s_T%d_spikes" % (kind, Tn)]
             worst = max(worst, float(np.abs(outs[0].cpu().numpy() - ref).max()))
     assert worst <= 1e-6, worst
+    # the stepping form fd runs, far outside the +-10 clamp (neuron_wide.npz): the exact-order build keeps the clamp, the gate stays closed
+    gw = golden("neuron_wide.npz")
+    xw = torch.from_numpy(gw["x"]).to(dev)
+    raww = [torch.from_numpy(r).to(dev) for r in gw["raw_params"]]
+    rw, cw = gw["x"].shape
+    for kind in ("lif", "eif"):
+        Tn = gw[kind + "_spikes"].shape[0]
+        for pairv in (0, 1):
+            spk = torch.empty((Tn, rw, cw), device=dev)
+            gate = torch.zeros(1, dtype=torch.int32, device=dev)
+            dT, rh = (raww[4], raww[5]) if kind == "eif" else (None, None)
+            _lib.check(lib.sapcu_neuron_drive(_lib.ptr(xw), rw, cw, Tn, _lib.ptr(raww[0]), _lib.ptr(raww[1]), _lib.ptr(raww[2]), _lib.ptr(raww[3]),
+                                              _lib.ptr(dT), _lib.ptr(rh), pairv, _lib.ptr(spk), None, None, None, _lib.ptr(gate), _lib.current_stream()))
+            np.testing.assert_allclose(spk.cpu().numpy(), gw[kind + "_spikes"], rtol=2e-5, atol=1e-6)
+            assert int(gate.item()) == 0
 
     class W:
         def __call__(self, kind, **over):

@@ -585,6 +585,41 @@ def ref_vs_ref_fixture():
     save("ref_vs_ref.npz", threads=np.array([1, 8]), **{k: np.array(v) for k, v in dict(fd_stats, **e2e).items()})
 
 
+def neuron_wide_fixture():
+    """neuron_wide.npz (round 4): the reference's LIF / EIF neurons (fd classes, fd/snn_coder.py:94-155,198-275) far outside the
+    spike function's +-10 clamp — pre-activations out to |x| = 40 and a few at +-100 / +-1e4 — driven the way fd's encoder drives
+    them: the SAME input at every step (the refractory gate decides what enters), every step's spikes and the state after the last
+    step.  This is the input class where an un-clamped spike surrogate underflows to exactly 0 (x - theta below about -13.2) while
+    the reference's clamped one stays at 3.85e-23, i.e. where its gate is closed with r > 0."""
+    C, T = 8, 7
+    rng = np.random.default_rng(11)
+    x = np.concatenate([np.linspace(-40, 40, 321), [-10.0, 10.0, -12.0, 12.0, -13.2, -13.3, -14.3, -14.4, -15.0, 15.0, -20.0, 20.0,
+                                                    -100.0, 100.0, -1e4, 1e4, 0.0, 1.0]])
+    x = np.tile(x[:, None], (1, C)).astype(np.float32)
+    x[:321] += rng.normal(0, 0.05, (321, C)).astype(np.float32)
+    raw = np.stack([rng.uniform(0.05, 1.05, C), rng.uniform(0.0, 0.12, C), rng.uniform(0.05, 1.0, C),
+                    rng.uniform(0.6, 1.4, C), rng.uniform(0.05, 5.5, C), rng.uniform(0.05, 2.2, C)]).astype(np.float32)
+    out = {"x": x, "raw_params": raw}
+    for kind, cls in (("lif", ref_fd.MultiTimeConstantLIFNeuron), ("eif", ref_fd.MultiTimeConstantEIFNeuron)):
+        neu = cls(C).eval()
+        with torch.no_grad():
+            neu.membrane_decay.copy_(torch.from_numpy(raw[0])); neu.threshold_adapt.copy_(torch.from_numpy(raw[1]))
+            neu.refractory_decay.copy_(torch.from_numpy(raw[2])); neu.threshold_base.copy_(torch.from_numpy(raw[3]))
+            if kind == "eif":
+                neu.delta_T.copy_(torch.from_numpy(raw[4])); neu.theta_rh.copy_(torch.from_numpy(raw[5]))
+            st, spikes, gate_open = [None, None, None], [], 0
+            for step in range(T):
+                if step > 0:
+                    gate_open += int((st[2] <= 0).sum())            # what the reference's own gate sees (fd:133,249)
+                v, *st = neu(torch.from_numpy(x), *st)
+                spikes.append(npy(v))
+        out["%s_spikes" % kind] = np.stack(spikes)                  # [T, rows, C]
+        out["%s_membrane" % kind], out["%s_threshold" % kind], out["%s_refractory" % kind] = npy(st[0]), npy(st[1]), npy(st[2])
+        out["%s_gate_open" % kind] = np.int64(gate_open)
+        print(kind, "reference gate-open events at t >= 1:", gate_open, " min spike", float(np.stack(spikes).min()))
+    save("neuron_wide.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only-ref-vs-ref", action="store_true", help="only (re)generate ref_vs_ref.npz (reference 1 thread vs 8 threads)")
@@ -597,7 +632,11 @@ def main():
     ap.add_argument("--suite-shape", default=None, help="(re)generate ONE shape of shape_suite.npz")
     ap.add_argument("--only-suite", action="store_true", help="only (re)generate shape_suite.npz (BASELINE config 3 stand-in)")
     ap.add_argument("--only-scale16", action="store_true", help="only (re)generate scale16.npz (BASELINE config 4 stand-in)")
+    ap.add_argument("--only-neuron-wide", action="store_true", help="only (re)generate neuron_wide.npz (neurons out to |x| = 1e4)")
     args = ap.parse_args()
+    if args.only_neuron_wide:
+        neuron_wide_fixture()
+        return
     if args.only_ref_vs_ref:
         ref_vs_ref_fixture()
         return

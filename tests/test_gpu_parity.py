@@ -139,6 +139,45 @@ def test_neuron_unit_against_reference_vectors():
                                            err_msg="%s T=%d %s" % (kind, T, key))
 
 
+def test_neuron_stepping_form_far_outside_the_spike_clamp():
+    """neuron_wide.npz (the reference's fd neurons out to |x| = 1e4, every step's spikes): the packed stepping form that fd's
+    kernels run (NeuronStep2: two rows of a channel; NeuronStep2V: two channels of a row), input at step 0 only.  The default
+    build leaves the +-10 clamp of the spike function out, so below x - theta = -13.2 its spike is exactly 0 where the
+    reference's is 3.85e-23; the refractory state is floored at that minimum (common.h SPIKE_FLOOR), so the kernels' gate test
+    must report 0 open gates — as the reference's own gate does on these inputs — and r must stay > 0.  Also the self-loop
+    form (fn's production loop) at T = 7 against the last step."""
+    from sapcu_amd import _lib
+    g = golden("neuron_wide.npz")
+    lib = _lib.load()
+    x, raw = _dev(g["x"]), [_dev(r) for r in g["raw_params"]]
+    rows, ch = g["x"].shape
+    assert int(g["lif_gate_open"]) == 0 and int(g["eif_gate_open"]) == 0
+    for kind in ("lif", "eif"):
+        ref = g[kind + "_spikes"]
+        T = ref.shape[0]
+        dT, rh = (raw[4], raw[5]) if kind == "eif" else (None, None)
+        for pairv in (0, 1):
+            spk = torch.full((T, rows, ch), float("nan"), device=U.dev())
+            st = [torch.full((rows, ch), float("nan"), device=U.dev()) for _ in range(3)]
+            gate = torch.zeros(1, dtype=torch.int32, device=U.dev())
+            _lib.check(lib.sapcu_neuron_drive(_lib.ptr(x), rows, ch, T, _lib.ptr(raw[0]), _lib.ptr(raw[1]), _lib.ptr(raw[2]), _lib.ptr(raw[3]),
+                                              _lib.ptr(dT), _lib.ptr(rh), pairv, _lib.ptr(spk), *[_lib.ptr(s) for s in st], _lib.ptr(gate),
+                                              _lib.current_stream()))
+            tag = "%s pairv=%d" % (kind, pairv)
+            np.testing.assert_allclose(spk.cpu().numpy(), ref, rtol=2e-5, atol=1e-6, err_msg=tag)
+            assert int(gate.item()) == 0, tag + ": %d open gates on inputs where the reference's gate is closed" % int(gate.item())
+            r = st[2].cpu().numpy()
+            assert (r > 0).all(), tag
+            # the floor keeps r at or above the reference's own value wherever the reference sits at its minimum
+            np.testing.assert_allclose(r, g[kind + "_refractory"], rtol=2e-5, atol=1e-6, err_msg=tag)
+            np.testing.assert_allclose(st[0].cpu().numpy(), g[kind + "_membrane"], rtol=2e-5, atol=1e-6, err_msg=tag)
+            np.testing.assert_allclose(st[1].cpu().numpy(), g[kind + "_threshold"], rtol=2e-5, atol=1e-6, err_msg=tag)
+        out = torch.empty_like(x)
+        _lib.check(lib.sapcu_neuron_selfloop(_lib.ptr(x), rows, ch, T, _lib.ptr(raw[0]), _lib.ptr(raw[1]), _lib.ptr(raw[2]), _lib.ptr(raw[3]),
+                                             _lib.ptr(dT), _lib.ptr(rh), _lib.ptr(out), None, None, None, _lib.current_stream()))
+        np.testing.assert_allclose(out.cpu().numpy(), ref[T - 1], rtol=2e-5, atol=1e-6, err_msg=kind + " self-loop")
+
+
 # ------------------------------------------------------------------------------- in-patch kNN
 def test_patch_knn_xyz_exact_and_feature_space_flips():
     """In-patch kNN against the reference's own knn() run (indices AND the score matrix it ranked, patch_knn.npz).  xyz
@@ -456,6 +495,64 @@ def test_fd_forward_256_patches_forced_neighbour_protocol(models):
     assert d_free.std() > 1e-2
 
 
+def _far_from_threshold_fd_weights(weights):
+    """The conditioned fd weights with BatchNorm biases moved so that every neuron stage sees pre-activations far outside the
+    spike function's +-10 clamp on both sides: channels 0, 7, 14, .. of scale_fusion and of the three EdgeConv blocks get
+    beta = -110 (LeakyReLU: x0 ~ -22, x0 - theta ~ -23) and channels 3, 10, .. beta = +22."""
+    sd = {k: v.clone() for k, v in weights("fd").items()}
+    for name in ["encoder.scale_fusion.1.bias"] + ["encoder.conv_blocks.%d.1.bias" % i for i in range(3)]:
+        sd[name][0::7] = -110.0
+        sd[name][3::7] = 22.0
+    return sd
+
+
+def test_fd_preactivations_far_outside_the_spike_clamp(weights, monkeypatch):
+    """the default build's packed spike function has no +-10 clamp, so for x0 - theta below about -13.2 its
+    spike is exactly 0 where the reference's is 3.85e-23.  The reference's refractory gate is closed there (r > 0) and it runs
+    normally; so must this build: distances equal to the oracle's under forced neighbour tables (1e-4), NO gate violation
+    reported by either path (fused encoder, per-stage kernels), and Generator3D6.upsample_seeds does not raise."""
+    import sapcu_amd
+    from conftest import FD_KW
+    from sapcu_amd import generation as gen, testing as T
+    sdd = _far_from_threshold_fd_weights(weights)
+    fds = []
+    for env in ({"SAPCU_FD_FUSED": "1"}, {"SAPCU_FD_FUSED": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        fd = sapcu_amd.EnhancedSNNDistanceEstimation(**FD_KW)
+        fd.load_state_dict(sdd, strict=True)
+        fd = fd.to(U.dev())
+        fd._engine()
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+        fds.append(fd)
+    assert fds[0].fused_blocks(48) == 1 and fds[1].fused_blocks(48) == 0
+    patch = U.sphere_patches(24, 48, skip=2100)
+    x0 = torch.full((24, 48, 960), float("nan"), device=U.dev())
+    fds[0](patch.to(U.dev()), taps={"x0": x0})
+    x0 = x0.cpu()
+    theta = torch.cat([sdd["encoder.snn_blocks.%d.threshold_base" % i] for i in range(4)])
+    dlt = x0 - theta
+    for lo, hi in ((0, 64), (64, 192), (192, 448), (448, 960)):          # every block reaches both tails
+        assert float(dlt[..., lo:hi].min()) < -15 and float(dlt[..., lo:hi].max()) > 15, (lo, float(dlt[..., lo:hi].min()), float(dlt[..., lo:hi].max()))
+    outs = []
+    for fd in fds:
+        d_gpu, d_forced, _, flips, _ = U.fd_forward_forced(fd, sdd, patch)
+        assert float((d_gpu - d_forced).abs().max()) <= TOL, float((d_gpu - d_forced).abs().max())
+        assert fd.gate_violations() == 0, "gate counter fired on inputs where the reference's gate is closed"
+        outs.append(d_gpu)
+    assert float(outs[0].std()) > 1e-3
+    knn = torch.empty((3, 24, 48, 32), dtype=torch.int32, device=U.dev())
+    a = fds[0](patch.to(U.dev()), taps={"knn": knn})
+    assert torch.equal(a, fds[1](patch.to(U.dev()), knn_force=knn))     # fused == per-stage, bit for bit, on this input class too
+    # the reference-facing entry point: the numeric guards run at the end of upsample_seeds and must stay silent
+    fn_ok = U.build_gpu_models(weights)[0]
+    g3 = gen.Generator3D6(fn_ok, fds[0], U.dev(), k_neighbors=48, batch_size=64)
+    cloud = T.sphere_cloud(1024, 0)
+    out = g3.upsample_seeds(cloud, T.grid_queries(96, 4))
+    assert out.shape[1] == 3 and np.isfinite(out).all() and fds[0].gate_violations() == 0
+
+
 def test_gemm_modes_agree_and_stay_in_range(weights, monkeypatch):
     """The default split-f16 GEMMs against the exact-f32 MFMA kernels (SAPCU_GEMM=f32) on the same patches."""
     fn16, fd16, sdn, sdd = U.build_gpu_models(weights)
@@ -697,6 +794,49 @@ def test_full_batch_4096_properties(models):
     assert (fd(rot[500:600]) - d1[500:600]).abs().max() <= 1e-6
     out = gen.displace(q, gen.l2_normalize3(n1), d1)
     assert torch.isfinite(out).all()
+    assert fd.gate_violations() == 0
+
+
+def test_headline_batch_rows_against_the_oracle(models):
+    """BASELINE config 2 — the batch bench.py reports (sphere N = 5000 seed 0, the 4096 grid queries, M = 48, T = 4) — run as ONE
+    device pass, then 48 of its rows (fixed seed) checked against the oracle stage by stage: outer-kNN indices and gathered
+    patches exact, normals 1e-4, rotated patches to the last f32 digit, distances 1e-4 under the neighbour tables the device
+    chose for those rows (forced-neighbour protocol), displaced points exact.  (the headline batch's parity no
+    longer rests on sub-batch == full-batch transitivity.)"""
+    from sapcu_amd import testing as T
+    from sapcu_amd import generation as gen
+    fn, fd, sdn, sdd = models
+    fn.knn_cache_mode = "fresh"
+    cloud_h, q_h = T.sphere_cloud(5000, 0), T.grid_queries(4096, 0)
+    cloud, q = _dev(cloud_h), _dev(q_h)
+    idx, _, patch = gen.knn_gather(cloud, q, 48)
+    nrm = gen.l2_normalize3(fn(patch))
+    rot = gen.gather_rotate(cloud, q, idx, nrm)
+    knn = torch.empty((3, 4096, 48, 32), dtype=torch.int32, device=U.dev())
+    dist = fd(rot, taps={"knn": knn})
+    out = gen.displace(q, nrm, dist)
+    torch.cuda.synchronize()
+    rows = np.sort(np.random.default_rng(2024).choice(4096, 48, replace=False))
+    rt = torch.as_tensor(rows, device=U.dev())
+    ref_idx = G.knn_bruteforce(cloud_h, q_h[rows], 48)
+    assert np.array_equal(idx[rt].cpu().numpy(), ref_idx)
+    ref_patch = G.gather_centre(cloud_h, q_h[rows], ref_idx)
+    assert np.array_equal(patch[rt].cpu().numpy(), ref_patch.astype(np.float32))
+    with torch.no_grad():
+        n_ref = torch.nn.functional.normalize(O.fn_forward(sdn, torch.from_numpy(ref_patch).float(), U.FN_HP), dim=-1)
+    n_gpu = nrm[rt].cpu()
+    e_n = float((n_gpu - n_ref).abs().max())
+    ref_rot = G.rotate_patches(ref_patch, n_gpu.numpy()).astype(np.float32)
+    rot_rows = rot[rt].cpu()
+    assert float((rot_rows - torch.from_numpy(ref_rot)).abs().max()) <= 1e-9
+    force = knn[:, rt].cpu().long()
+    with torch.no_grad():
+        d_ref = O.fd_forward(sdd, rot_rows, U.FD_HP, force_idx=[force[0], force[1], force[2]])
+    d_gpu = dist[rt].cpu()
+    e_d = float((d_gpu - d_ref).abs().max())
+    print("headline batch, 48 sampled rows: normals max err %.2e, distances max err %.2e (forced tables)" % (e_n, e_d))
+    assert e_n <= TOL and e_d <= TOL
+    assert np.array_equal(out[rt].cpu().numpy(), G.displace(q_h[rows], n_gpu.numpy(), d_gpu.numpy()))
     assert fd.gate_violations() == 0
 
 
@@ -1622,6 +1762,60 @@ def test_fused_fd_encoder_equals_the_per_stage_path_bit_for_bit(weights, monkeyp
         assert torch.equal(fd(patch), da), tag + ": tap-free call"
         assert torch.equal(fd(patch, knn_force=tb["knn"]), db), tag + ": forced tables"
     assert fd.gate_violations() == 0 and fd_stage.gate_violations() == 0 and fd.gemm_mode() == (True, 0)
+
+
+@pytest.mark.parametrize("emb", [800, 896, 1024])
+def test_fused_fd_encoder_with_a_ragged_last_column_sweep(monkeypatch, emb):
+    """emb_dims above 768 whose second sweep of 24 column blocks ends in a partly owned wave (emb / 32 - 24
+    not a multiple of 3: 800 -> block 24, 896 -> block 27, 1024 -> blocks 30, 31) — those pooled columns were never stored.
+    Fused encoder against the per-stage kernels, bit for bit, with the outputs pre-filled with NaN."""
+    import sapcu_amd
+    from conftest import FD_KW
+    from sapcu_amd import testing as T
+    kw = dict(FD_KW, emb_dims=emb)
+    tmpl = sapcu_amd.EnhancedSNNDistanceEstimation(**kw).state_dict()
+    bn = {k: v for k, v in dict(golden("bn_calib_fd.npz")).items() if tuple(v.shape) == tuple(tmpl[k].shape)}
+    sdd = T.conditioned_state_dict(tmpl, 0, bn_stats=bn)
+    fds = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SAPCU_FD_FUSED", flag)
+        fd = sapcu_amd.EnhancedSNNDistanceEstimation(**kw)
+        fd.load_state_dict(sdd, strict=True)
+        fd = fd.to(U.dev())
+        fd._engine()
+        monkeypatch.delenv("SAPCU_FD_FUSED")
+        fds.append(fd)
+    assert fds[0].fused_blocks(48) == 1 and fds[1].fused_blocks(48) == 0
+    for nq, mpts in ((37, 48), (5, 12)):
+        patch = U.sphere_patches(nq, mpts, skip=1900).to(U.dev())
+        kk = min(32, mpts)
+        ta, tb = _fd_taps(nq, mpts, 4, kk, emb), _fd_taps(nq, mpts, 4, kk, emb)
+        del ta["spikes"], tb["spikes"], ta["fused0"], tb["fused0"]
+        da = fds[0](patch, taps=ta)
+        db = fds[1](patch, taps=tb, knn_force=ta["knn"])
+        torch.cuda.synchronize()
+        assert not bool(torch.isnan(ta["pooled"]).any()), "emb=%d: %d pooled columns never written" % (emb, int(torch.isnan(ta["pooled"][0, 0]).sum()))
+        assert torch.equal(ta["pooled"], tb["pooled"]) and torch.equal(ta["enc"], tb["enc"]) and torch.equal(da, db), (emb, nq, mpts)
+    assert fds[0].gate_violations() == 0 and fds[1].gate_violations() == 0
+
+
+def test_fd_forward_on_patches_of_128_points(models):
+    """the largest patch the entry points accept.  fd's EdgeConv + neuron kernel stages the patch's [m][128]
+    tile AND its byte-sized neighbour table in LDS: 69 632 B at m = 128, k = 32 — above the default 64 KiB dynamic-LDS limit,
+    which the launcher has to raise.  Distances against the oracle on the device's own neighbour tables (1e-4); fn on the same
+    patches against the oracle."""
+    fn, fd, sdn, sdd = models
+    patch = U.sphere_patches(3, 128, skip=2300)
+    d_gpu, d_forced, _, _, _ = U.fd_forward_forced(fd, sdd, patch)
+    assert float((d_gpu - d_forced).abs().max()) <= TOL and fd.gate_violations() == 0
+    mode = fn.knn_cache_mode
+    fn.knn_cache_mode = "fresh"
+    try:
+        with torch.no_grad():
+            n_ref = O.fn_forward(sdn, patch, U.FN_HP)
+        assert float((fn(patch.to(U.dev())).cpu() - n_ref).abs().max()) <= TOL
+    finally:
+        fn.knn_cache_mode = mode
 
 
 def test_exact_operation_order_build():

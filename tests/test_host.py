@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libsapcu_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert _lib.load().sapcu_abi_version() == 1
+    assert _lib.load().sapcu_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_argument_errors_come_back_as_codes_not_crashes():
@@ -154,6 +154,59 @@ def test_sharded_upsample_all_gather_gloo_world2(n):
         p.join(60)
     assert all(ok for _, ok, _ in res)
     assert res[0][2][0] == 0 and res[1][2][1] == n and res[0][2][1] == res[1][2][0]
+
+
+def test_visible_gpu_count_reads_the_kfd_topology_not_the_runtime(tmp_path):
+    """sapcu_amd.dist.visible_gpu_count on a fake sysfs / dev tree: CPU nodes (simd_count 0) are not GPUs, a GPU whose render node
+    this process cannot open does not count (containers see the host's whole topology), and the visibility variables apply the
+    way the runtime applies them.  No torch.cuda / HIP call is involved (bench.py's launcher parent relies on that)."""
+    import inspect
+    nodes, dri = tmp_path / "nodes", tmp_path / "dri"
+    dri.mkdir()
+    for i, (simd, minor) in enumerate([(0, -1), (0, -1), (1024, 128), (1024, 129), (1024, 130), (1024, 131)]):
+        d = nodes / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\ndrm_render_minor %d\n" % (0 if simd else 64, simd, minor))
+    for minor in (128, 129, 130):                    # renderD131 is missing: that GPU belongs to another container
+        (dri / ("renderD%d" % minor)).write_text("")
+    cnt = lambda env: sdist.visible_gpu_count(str(nodes), str(dri), env)
+    assert cnt({}) == 3
+    assert cnt({"HIP_VISIBLE_DEVICES": "0,2"}) == 2
+    assert cnt({"HIP_VISIBLE_DEVICES": ""}) == 0
+    assert cnt({"ROCR_VISIBLE_DEVICES": "1,2", "HIP_VISIBLE_DEVICES": "0,1,2"}) == 2     # HIP indices beyond the ROCR list end it
+    assert cnt({"CUDA_VISIBLE_DEVICES": "0,7,1"}) == 1                                    # an unresolvable entry ends the list
+    assert cnt({"ROCR_VISIBLE_DEVICES": "GPU-abcdef0123456789"}) == 1
+    assert sdist.visible_gpu_count(str(tmp_path / "absent"), str(dri), {}) is None
+    import ast
+    tree = ast.parse(inspect.getsource(sdist.visible_gpu_count))
+    names = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name)} | {n.attr for n in ast.walk(tree) if isinstance(n, ast.Attribute)}
+    assert not names & {"torch", "cuda", "device_count", "is_available", "ctypes", "CDLL"}, names
+
+
+@pytest.mark.parametrize("n", [385, 13, 5, 1])
+def test_sharded_upsample_all_gather_gloo_world8(n):
+    """world_size 8 (the driver's node): n not divisible by 8 — the last slabs short, and for n < 8 whole ranks EMPTY
+    (n = 5: ceil = 1, ranks 5..7 refine nothing and still join the all-gather; n = 13: ceil = 2, rank 6 has one seed, rank 7 none)."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 8, port, n, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _ in res), res
+    ranges = [r[2] for r in res]
+    assert ranges[0][0] == 0 and ranges[-1][1] == n and all(ranges[i][1] == ranges[i + 1][0] for i in range(7))
+    per = -(-n // 8)
+    assert all(e - s0 == max(0, min(per, n - i * per)) for i, (s0, e) in enumerate(ranges))
+    if n < 8:
+        assert sum(1 for s0, e in ranges if e == s0) == 8 - n
 
 
 def test_inprocess_seed_generator_matches_reference_dense_bit_for_bit():
@@ -287,9 +340,10 @@ def test_bench_spawns_its_own_ranks_before_touching_the_gpu():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     src = inspect.getsource(bench.spawn_ranks)
-    assert "torch.distributed.run" in src and "subprocess.call" in src and "device_count" in src
-    for forbidden in ("is_available", "set_device", "os.exec", "execv"):
+    assert "torch.distributed.run" in src and "subprocess.call" in src and "visible_gpu_count" in src
+    for forbidden in ("is_available", "set_device", "os.exec", "execv", "device_count", "torch.cuda"):     # no HIP runtime in the parent
         assert forbidden not in src, forbidden
+    assert "subprocess.run" in inspect.getsource(bench._count_gpus_in_child)                                # the fallback asks a child
     tree = ast.parse(inspect.getsource(bench.main))
     calls = [n.lineno for n in ast.walk(tree) if isinstance(n, ast.Call) and getattr(n.func, "id", "") == "spawn_ranks"]
     sets = [n.lineno for n in ast.walk(tree) if isinstance(n, ast.Attribute) and n.attr == "set_device"]

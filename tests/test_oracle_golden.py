@@ -31,6 +31,29 @@ def test_neuron_unit_lif_eif():
                 np.testing.assert_allclose(val.numpy(), ref, rtol=0, atol=1e-7, err_msg="%s T=%d %s" % (kind, T, key))
 
 
+def test_neuron_far_outside_the_spike_clamp():
+    """neuron_wide.npz: the reference's fd neurons out to |x| = 1e4, driven fd's way (same input every step, the gate decides).
+    The oracle reproduces every step's spikes and the final state; the reference's gate is closed for t >= 1 on ALL of these
+    inputs — its clamped spike surrogate bottoms out at 3.85e-23 > 0, so r > 0 (the invariant the HIP kernels' dead-stage
+    elimination and gate counter rest on)."""
+    g = golden("neuron_wide.npz")
+    x, raw = t(g["x"]), g["raw_params"]
+    names = ["membrane_decay", "threshold_adapt", "refractory_decay", "threshold_base", "delta_T", "theta_rh"]
+    assert float(np.abs(g["x"]).max()) == 1e4 and int(g["lif_gate_open"]) == 0 and int(g["eif_gate_open"]) == 0
+    for kind, n in (("lif", 4), ("eif", 6)):
+        sd = {"n." + names[i]: t(raw[i]) for i in range(n)}
+        p = O.neuron_params(sd, "n")
+        st = None
+        for step in range(g[kind + "_spikes"].shape[0]):
+            if step:
+                assert bool((st[2] > 0).all())
+            v, st = O.neuron_step(x, st, p)
+            np.testing.assert_allclose(v.numpy(), g[kind + "_spikes"][step], rtol=1e-6, atol=1e-7, err_msg="%s step %d" % (kind, step))
+        for key, val in (("membrane", st[0]), ("threshold", st[1]), ("refractory", st[2])):
+            np.testing.assert_allclose(val.numpy(), g["%s_%s" % (kind, key)], rtol=1e-6, atol=1e-7, err_msg=kind + " " + key)
+        assert g[kind + "_spikes"].min() >= 3.8e-23 and g[kind + "_refractory"].min() > 0
+
+
 def test_closed_gate_identity():
     """eval-mode spikes are > 0, so the input gate is closed for t >= 1."""
     g = golden("neuron_unit.npz")
