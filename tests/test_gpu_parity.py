@@ -170,7 +170,9 @@ def test_neuron_stepping_form_far_outside_the_spike_clamp():
             assert (r > 0).all(), tag
             # the floor keeps r at or above the reference's own value wherever the reference sits at its minimum
             np.testing.assert_allclose(r, g[kind + "_refractory"], rtol=2e-5, atol=1e-6, err_msg=tag)
-            np.testing.assert_allclose(st[0].cpu().numpy(), g[kind + "_membrane"], rtol=2e-5, atol=1e-6, err_msg=tag)
+            # (the EIF membrane is m * (1 - s) of values up to dT e^5 ~ 700 with s near 1: the product keeps the ABSOLUTE error of
+            #  a 1-2 ulp hardware exp, ~1e-5, on a small result)
+            np.testing.assert_allclose(st[0].cpu().numpy(), g[kind + "_membrane"], rtol=2e-5, atol=5e-5 if kind == "eif" else 1e-6, err_msg=tag)
             np.testing.assert_allclose(st[1].cpu().numpy(), g[kind + "_threshold"], rtol=2e-5, atol=1e-6, err_msg=tag)
         out = torch.empty_like(x)
         _lib.check(lib.sapcu_neuron_selfloop(_lib.ptr(x), rows, ch, T, _lib.ptr(raw[0]), _lib.ptr(raw[1]), _lib.ptr(raw[2]), _lib.ptr(raw[3]),
