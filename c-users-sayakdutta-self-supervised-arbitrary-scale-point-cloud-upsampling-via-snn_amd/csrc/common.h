@@ -318,14 +318,24 @@ struct NeuronS2 {
 
 template <bool EIF>
 struct NeuronStep2 {
+    // (the scalar parameters the packed form needs are plain members: with the whole NeuronP embedded, the compiler's scalar
+    //  replacement of the object sliced dT | rh as one 8-byte piece overlapping other pieces and rebuilt it through a stack slot)
+#ifdef SAPCU_LIF_EXACT_ORDER
     NeuronP p;
-    f32x2 decay, rdecay, a95, thc, theta0;
+#endif
+    f32x2 decay, rdecay, a95, thc, theta0, dT2, rh2;
     float inv_dT;
     NeuronS2 s;
 #ifdef SAPCU_LIF_EXACT_ORDER
     NeuronS sx, sy;
 #endif
-    __device__ __forceinline__ explicit NeuronStep2(const NeuronP& pp) : p(pp) {
+    __device__ __forceinline__ explicit NeuronStep2(const NeuronP& pp) {
+#ifdef SAPCU_LIF_EXACT_ORDER
+        p = pp;
+#endif
+        const NeuronP& p = pp;
+        dT2 = f32x2{p.dT, p.dT};
+        rh2 = f32x2{p.rh, p.rh};
         decay = f32x2{p.decay, p.decay};
         rdecay = f32x2{p.rdecay, p.rdecay};
         a95 = f32x2{p.adapt * 0.95f, p.adapt * 0.95f};
@@ -360,10 +370,10 @@ struct NeuronStep2 {
             mm = pk_fma(-md, s.r, md);
         }
         if (EIF) {
-            f32x2 a = (s.m - p.rh) * inv_dT;
+            f32x2 a = (s.m - rh2) * inv_dT;
             a = f32x2{clampf(a.x, -5.0f, 5.0f), clampf(a.y, -5.0f, 5.0f)} * 1.4426950408889634074f;
             const f32x2 e = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
-            mm = pk_fma(e, f32x2{p.dT, p.dT}, mm);
+            mm = pk_fma(e, dT2, mm);
         }
         const f32x2 sp = soft_spike2(mm - s.th);
         s.m = pk_fma(-mm, sp, mm);
@@ -378,13 +388,19 @@ struct NeuronStep2 {
 // parameters as 2-vectors.  (fd's per-stage EdgeConv + neuron kernel walks four consecutive channels per thread.)
 template <bool EIF>
 struct NeuronStep2V {
+#ifdef SAPCU_LIF_EXACT_ORDER
     NeuronP pa, pb;
+#endif
     f32x2 decay, rdecay, a95, thc, theta0, dT, rh, inv_dT;
     NeuronS2 s;
 #ifdef SAPCU_LIF_EXACT_ORDER
     NeuronS sx, sy;
 #endif
-    __device__ __forceinline__ NeuronStep2V(const NeuronP& a, const NeuronP& b) : pa(a), pb(b) {
+    __device__ __forceinline__ NeuronStep2V(const NeuronP& a, const NeuronP& b) {
+#ifdef SAPCU_LIF_EXACT_ORDER
+        pa = a;
+        pb = b;
+#endif
         decay = f32x2{a.decay, b.decay};
         rdecay = f32x2{a.rdecay, b.rdecay};
         a95 = f32x2{a.adapt * 0.95f, b.adapt * 0.95f};

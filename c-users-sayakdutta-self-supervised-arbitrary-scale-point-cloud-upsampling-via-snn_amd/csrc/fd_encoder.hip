@@ -58,13 +58,18 @@ constexpr int FE_OFF_XYZ = FE_OFF_R2 + FE_R2_BYTES;        // float4[48]
 constexpr int FE_OFF_IDX0 = FE_OFF_XYZ + FE_M * 16;        // u8[48][48]: xyz neighbours, ascending distance
 constexpr int FE_OFF_IDXL = FE_OFF_IDX0 + FE_M * FE_M;     // u8[48][48]: feature-space neighbours of the current block
 constexpr int FE_OFF_XX = FE_OFF_IDXL + FE_M * FE_M;       // float[64]
-constexpr int FE_LDS = FE_OFF_XX + 256;                    // 157 184 B
+constexpr int FE_LDS = 163840;                             // all of it: the per-patch tables end at FE_OFF_XX + 256 = 157 184 B, and
+                                                           // multi_scale_conv re-uses [FE_OFF_XYZ, 163 840) as FE_OFF_BEST
+// multi_scale_conv's view of the LDS (the per-patch tables and the upper half of the phase buffer are dead by then):
+constexpr int FE_OFF_X3L = FE_OFF_R2 + 32768;              // f32[16 values][512 threads]: block 3's x0 of the CURRENT third of the patch
+constexpr int FE_OFF_BEST = FE_OFF_XYZ;                    // u32[6 column sub-blocks][4 steps][8 waves][16 lanes]: running maxima (keys)
+static_assert(FE_OFF_BEST + 6 * 4 * 8 * 16 * 4 <= FE_LDS && FE_OFF_X3L + 16 * 512 * 4 <= FE_OFF_XYZ, "fd encoder: multi_scale_conv areas");
 constexpr int FE_F_LD = 36;                                // score staging 2 x [64][36] f32 at R2 + 0, keys [m][m+1] behind them
 constexpr int FE_KEYS_OFF = 2 * 64 * FE_F_LD * 4;         // (two staging buffers)
 constexpr int FE_TLD = 36;                                 // EdgeConv staging tile of a wave: [48][36] f32 (32 channels + 4 pad)
 constexpr int FE_TILE = FE_M * FE_TLD;
 static_assert(8 * FE_TILE * 4 <= FE_R2_BYTES, "fd encoder: staging tiles");
-static_assert(FE_LDS <= 163840, "fd encoder: LDS budget");
+static_assert(FE_OFF_XX + 256 <= FE_LDS && FE_LDS <= 163840, "fd encoder: LDS budget");
 static_assert(FE_KEYS_OFF + FE_M * (FE_M + 1) * 4 <= FE_R2_BYTES, "fd encoder: score keys");
 
 // ---- split-f16 operand panel: [k32 step][plane hi | lo][ROWS][32 halves], 16-byte chunks XOR-swizzled by (row >> 2) & 3 (the
@@ -85,15 +90,28 @@ __device__ __forceinline__ void fe_put(unsigned char* X, int row, int k, float v
     *reinterpret_cast<_Float16*>(p + ROWS * 64) = (_Float16)(v - (float)hi);
 }
 
-__device__ __forceinline__ NeuronP fe_load_np(const float* __restrict__ nprm, int col) {   // clamped at model build (pack kernel)
-    const float* q = nprm + (int64_t)col * 8;      // (scalar loads: a float4-built struct made the compiler shuffle it through scratch)
+// Clamped neuron parameters of a channel (8 floats per channel, pack_fd_neuron_kernel): carried from one chunk / round to the next as
+// the two VECTORS they are loaded as — a carried struct of six scalars gets its loads merged by the load vectoriser into pieces that
+// overlap the fields, and the compiler then rebuilds the fields through stack slots (scratch) — and taken apart only where used.
+struct FeNP {
+    f32x4 a;       // decay, adapt, rdecay, theta0
+    f32x2 b;       // dT, rh
+};
+__device__ __forceinline__ FeNP fe_load_np(const float* __restrict__ nprm, int col) {
+    const float* q = nprm + (int64_t)col * 8;
+    FeNP v;
+    v.a = *reinterpret_cast<const f32x4*>(q);
+    v.b = *reinterpret_cast<const f32x2*>(q + 4);
+    return v;
+}
+__device__ __forceinline__ NeuronP fe_np(const FeNP& v) {
     NeuronP p;
-    p.decay = q[0];
-    p.adapt = q[1];
-    p.rdecay = q[2];
-    p.theta0 = q[3];
-    p.dT = q[4];
-    p.rh = q[5];
+    p.decay = v.a.x;
+    p.adapt = v.a.y;
+    p.rdecay = v.a.z;
+    p.theta0 = v.a.w;
+    p.dT = v.b.x;
+    p.rh = v.b.y;
     return p;
 }
 
@@ -122,21 +140,23 @@ __device__ __forceinline__ half8 fe_wfrag(const half8* __restrict__ wp, int nk32
 // 4) + e, column 16 cs[j] + (lane & 15).  One k32 step of weight fragments in registers; the column sub-blocks go in two halves whose
 // fragments are refilled in place behind their MFMAs (NCS = 1: behind the step).  RH > 0: the operand fragments of RH row sub-blocks
 // at a time (registers), re-read for the second column half.
-template <int NCS, int NRS, int RH = 0>
+template <int NCS, int NRS, int RH = 0, bool CARRY_HALF = false>
 __device__ __forceinline__ void fe_gemm16(const unsigned char* X, int plane_bytes, const half8* __restrict__ wp, int nk32, const int (&cs)[NCS],
                                           int lane, f32x4 (&acc)[NRS][NCS], int rs0 = 0, int s_first = 0, int nsteps = -1, int nk32_total = -1,
-                                          half8 (*Wh)[NCS] = nullptr, half8 (*Wl)[NCS] = nullptr) {
-    // (Wh / Wl: the caller keeps the fragment registers across calls — multi_scale_conv's rounds; nullptr: local, fresh accumulators)
+                                          half8 (*Wh)[NCS > 1 && CARRY_HALF ? NCS / 2 : NCS] = nullptr,
+                                          half8 (*Wl)[NCS > 1 && CARRY_HALF ? NCS / 2 : NCS] = nullptr) {
+    // (Wh / Wl: the caller keeps fragment registers across calls — multi_scale_conv's rounds; nullptr: local, fresh accumulators.
+    //  CARRY_HALF: only the FIRST column half's fragments are the caller's (24 registers that stay live through the caller's
+    //  emission phase instead of 48); the second half's first fragments are loaded on entry and land under the first half's MFMAs)
     const int c16 = lane & 15, g = lane >> 4;
     const unsigned char* xa = X + (16 * rs0 + c16) * 64 + ((g ^ ((c16 >> 2) & 3)) * 16);      // A operand: row 16 rs + c16, k chunk g
     const int kstep = 2 * plane_bytes;
     constexpr int HC = NCS > 1 ? NCS / 2 : 1, NH = NCS > 1 ? 2 : 1;
     constexpr int RC = RH > 0 ? RH : NRS, NRC = NRS / RC;
+    constexpr int NCARRY = NCS > 1 && CARRY_HALF ? NCS / 2 : NCS;
     const int nk_all = nk32_total < 0 ? nk32 : nk32_total;
     if (nsteps < 0) nsteps = nk32;
-    half8 whl[NCS], wll[NCS];
-    half8(&wh)[NCS] = Wh ? *Wh : whl;
-    half8(&wl)[NCS] = Wl ? *Wl : wll;
+    half8 wh[NCS], wl[NCS];
     if (!Wh) {
 #pragma unroll
         for (int i = 0; i < NRS; ++i)
@@ -146,6 +166,17 @@ __device__ __forceinline__ void fe_gemm16(const unsigned char* X, int plane_byte
         for (int j = 0; j < NCS; ++j) {
             wh[j] = fe_wfrag(wp, nk_all, cs[j], s_first, 0, lane);
             wl[j] = fe_wfrag(wp, nk_all, cs[j], s_first, 1, lane);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NCS; ++j) {
+            if (j < NCARRY) {
+                wh[j] = (*Wh)[j];
+                wl[j] = (*Wl)[j];
+            } else {
+                wh[j] = fe_wfrag(wp, nk_all, cs[j], s_first, 0, lane);
+                wl[j] = fe_wfrag(wp, nk_all, cs[j], s_first, 1, lane);
+            }
         }
     }
 #pragma unroll 1
@@ -184,6 +215,13 @@ __device__ __forceinline__ void fe_gemm16(const unsigned char* X, int plane_byte
                 wh[j] = fe_wfrag(wp, nk_all, cs[j], sn, 0, lane);
                 wl[j] = fe_wfrag(wp, nk_all, cs[j], sn, 1, lane);
             }
+        }
+    }
+    if (Wh) {
+#pragma unroll
+        for (int j = 0; j < NCARRY; ++j) {
+            (*Wh)[j] = wh[j];
+            (*Wl)[j] = wl[j];
         }
     }
 }
@@ -444,10 +482,10 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
         }
     } else {
         // thread (256 of them) -> channel c0 + (ftid & 31), rows (ftid >> 5) + 8 n; a chunk's parameters are loaded one chunk ahead
-        NeuronP pn = fe_load_np(a.nprm, COFF_IN + (tid & 31));
+        FeNP pn = fe_load_np(a.nprm, COFF_IN + (tid & 31));
         auto fill = [&](float* F, int c0, int cw, int ftid) {
             const int cc = ftid & 31;
-            const NeuronP p = pn;
+            const NeuronP p = fe_np(pn);
             pn = fe_load_np(a.nprm, COFF_IN + (c0 + 32 < CIN ? c0 + 32 : c0) + cc);
 #pragma unroll
             for (int n = 0; n < 8; n += 2) {
@@ -472,9 +510,9 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
     //     GEMM's rows are independent and those outputs are never used)
     {
         const int cc = tid & 63;
-        NeuronP pn2 = fe_load_np(a.nprm, COFF_IN + cc);
+        FeNP pn2 = fe_load_np(a.nprm, COFF_IN + cc);
         for (int c0 = 0; c0 < CIN; c0 += 64) {
-            const NeuronP p = pn2;
+            const NeuronP p = fe_np(pn2);
             pn2 = fe_load_np(a.nprm, COFF_IN + (c0 + 64 < CIN ? c0 + 64 : c0) + cc);
 #pragma unroll
             for (int n = 0; n < 6; n += 2) {
@@ -644,8 +682,10 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
         auto fill = [&](float* F, int c0, int cw, int ftid) {
             {                                                          // 64 rows x (x, y, z, 0)
                 const int i = ftid >> 2, cc = ftid & 3;
-                const float4 v = XYZ[i < FE_M ? i : 0];
-                F[i * FE_F_LD + cc] = (i < m && cc < 3) ? (cc == 0 ? v.x : (cc == 1 ? v.y : v.z)) : 0.f;
+                // (one LDS dword at a computed address: a select chain over a float4's components becomes a dynamic vector
+                //  extract, which the compiler lowers through a stack slot)
+                const float v = reinterpret_cast<const float*>(XYZ)[4 * (i < FE_M ? i : 0) + cc];      // XYZ[.].w == 0
+                F[i * FE_F_LD + cc] = i < m ? v : 0.f;
             }
             (void)c0; (void)cw;
         };
@@ -772,6 +812,15 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
     unsigned char* pe[4];                                   // panel addresses: point 4 rg + e of the third (row 4 point), column 64 cw + lane
 #pragma unroll
     for (int e = 0; e < 4; ++e) pe[e] = R2 + fe_panel_off<FE_PR>(4 * (4 * rg + e), 64 * cw + lane);
+    // Registers.  The sweep below holds 96 accumulators, 48 of weight fragments and 16 of operand fragments per lane next to the
+    // neuron loops of the emission; block 3's x0 (48 values per thread) and the 24 running maxima do not fit beside them (round 3:
+    // the compiler indexed x3 dynamically, i.e. kept it in scratch, and spilled 37 more).  So: the x0 values of the CURRENT third sit
+    // in LDS — 16 dwords per thread in the idle upper half of the phase buffer, slots only their owner touches: no barrier —, copied
+    // from the registers when a third starts (static indices; the other thirds' 32 / 16 values stay in registers until then), and
+    // the running maxima live in LDS too (the dead per-patch tables: one dword per (column, step), updated once per third by the
+    // lane that owns it).
+    float* X3L = reinterpret_cast<float*>(smem + FE_OFF_X3L) + tid;                    // value v of this thread: X3L[512 v]
+    unsigned* BESTL = reinterpret_cast<unsigned*>(smem + FE_OFF_BEST) + w * 16 + (lane & 15);   // (j, tt): BESTL[(4 j + tt) * 128]
     FE_STAMP(16);
 #ifdef FE_STAMPS
     unsigned long long fe_t_emit = 0, fe_t_mfma = 0, fe_tp = 0;
@@ -788,9 +837,6 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
         const int cb0 = cbw + 2 < ncb ? cbw : (ncb >= 3 ? ncb - 3 : 0);
         // this wave's six 16-column sub-blocks: column 16 css[j] + (lane & 15)
         const int css[6] = {2 * cb0, 2 * cb0 + 1, 2 * cb0 + 2, 2 * cb0 + 3, 2 * cb0 + 4, 2 * cb0 + 5};
-        float bias[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) bias[j] = a.msc_b[16 * css[j] + (lane & 15)];
         for (int t0 = 0; t0 < a.T; t0 += 4) {
             const int nemit = a.T - t0 < 4 ? a.T - t0 : 4;
             const bool count = sweep == 0 && t0 + nemit == a.T;        // the gate check runs once, over all T steps
@@ -800,35 +846,39 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
             float* tap = (a.tap_spikes && sweep == 0) ? a.tap_spikes + (a.s0 + patch_i) * (int64_t)m * 960 : nullptr;
 #endif
             const bool fast = t0 == 0 && nemit == 4 && tap == nullptr;         // (workgroup-uniform)
-            // running maxima of the RAW accumulators per (column sub-block, step): x -> LeakyReLU(x / 16 + bias) -> integer key is
-            // monotone, so the max over the points commutes with it bit for bit — bias, LeakyReLU and the key once per result
-            float best[6][4];
+            // running maxima of the RAW accumulators per (column sub-block, step), as order-preserving keys (0 = below every key):
+            // x -> LeakyReLU(x / 16 + bias) -> integer key is monotone, so the max over the points commutes with it bit for bit —
+            // bias, LeakyReLU and the final key once per result
+            if (lane < 16) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j)
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) best[j][tt] = -__builtin_huge_valf();
-            // one third of the patch; TH is compile-time (a generic lambda called with integral constants: x3 must be indexed
-            // statically to stay in registers), the rounds are a rolled loop
+                for (int q = 0; q < 24; ++q) BESTL[q * 128] = 0u;
+            }
+            // one third of the patch; TH is compile-time (a generic lambda called with integral constants: x3 is indexed
+            // statically and stays in registers), the rounds are a rolled loop
             auto third = [&](auto th_c) {
                 constexpr int TH = decltype(th_c)::value;
                 const int pt0 = FE_TP * TH + 4 * rg;                    // this thread's first point
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl)                          // this third's block-3 x0: registers -> this thread's LDS slots
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) X3L[512 * (4 * sl + e)] = x3[TH][sl][e];
                 f32x4 acc[4][6];                                        // [row sub-block: points 4 rs + (lane >> 4), step e][column sub-block]
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                half8 Wh[6], Wl[6];                                     // one k32 step of weight fragments, carried from round to round
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
+                half8 Wh[3], Wl[3];                                     // the first column half's weight fragments of the next k32 step,
+#pragma unroll                                                          // carried from round to round (the second half: loaded on entry)
+                for (int j = 0; j < 3; ++j) {
                     Wh[j] = fe_wfrag(mscw, 30, css[j], 0, 0, lane);
                     Wl[j] = fe_wfrag(mscw, 30, css[j], 0, 1, lane);
                 }
-                NeuronP pnext = fe_load_np(a.nprm, 64 * cw + lane);      // a chunk's neuron parameters are loaded one round ahead
+                FeNP pnext = fe_load_np(a.nprm, 64 * cw + lane);         // a chunk's neuron parameters are loaded one round ahead
 #pragma unroll 1
                 for (int R = 0; R < 8; ++R) {
                     const int ch = 2 * R + cw;                          // this wave's chunk (15 = none: round 7, odd waves)
                     const int c = 64 * ch + lane;
-                    const NeuronP p = pnext;
+                    const NeuronP p = fe_np(pnext);
                     pnext = fe_load_np(a.nprm, c + 128 < 960 ? c + 128 : (c < 960 ? c : 959));
                     FE_T0();
                     float* tp = tap ? tap + c : nullptr;
@@ -837,16 +887,10 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
                         if (ch < 7) {                                   // blocks 0-2: x0 from LDS
 #pragma unroll
                             for (int e = 0; e < 4; ++e) x[e] = XS[(pt0 + e) * FE_XLD + c];
-                        } else {                                        // block 3: x0 from registers, slot R - 3 (wave-uniform selects:
-#pragma unroll                                                          // the loop stays rolled and x3 stays in registers)
-                            for (int e = 0; e < 4; ++e) {
-                                const int slot = R - 4 + cw;
-                                float v = x3[TH][0][e];
-                                v = slot == 1 ? x3[TH][1][e] : v;
-                                v = slot == 2 ? x3[TH][2][e] : v;
-                                v = slot == 3 ? x3[TH][3][e] : v;
-                                x[e] = v;
-                            }
+                        } else {                                        // block 3: this thread's own slots; odd waves emit the block's
+                            const float* xs = X3L + 2048 * (R - 4 + cw);    // chunks in rounds 3..6, even waves in rounds 4..7
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) x[e] = xs[512 * e];
                         }
                         if (ch == 0) {                                  // block 0 (wave-uniform branches)
                             if (fast) fe_emit4<0, true>(x, p, 0, 4, pe, pt0, m, count, a.gate, nullptr, 0);
@@ -861,22 +905,26 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
                     }
                     lds_barrier();
                     FE_TACC(fe_t_emit);
-                    fe_gemm16<6, 4, 2>(R2, FE_PR * 64, mscw, 30, css, lane, acc, 0, 4 * R, R < 7 ? 4 : 2, 30, &Wh, &Wl);
+                    fe_gemm16<6, 4, 2, true>(R2, FE_PR * 64, mscw, 30, css, lane, acc, 0, 4 * R, R < 7 ? 4 : 2, 30, &Wh, &Wl);
                     lds_barrier();
                     FE_TACC(fe_t_mfma);
                 }
-                // epilogue of this third: + bias, LeakyReLU, running max per step over the third's points (row = 4 point + step:
-                // register u of a quad is step u), integer keys
+                // epilogue of this third: maximum per step over the third's points (row = 4 point + step: register u of a quad is
+                // step u) — first over this lane's own points, then over the four lane groups —, folded into the running maxima
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int pl = 4 * i + (lane >> 4);                 // point inside the third
-                    if (FE_TP * TH + pl < m) {
+                for (int j = 0; j < 6; ++j)
 #pragma unroll
-                        for (int j = 0; j < 6; ++j)
+                    for (int e = 0; e < 4; ++e) {
+                        float v = -__builtin_huge_valf();               // (a lane group none of whose points exist: below every real value)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) best[j][e] = fmaxf(best[j][e], acc[i][j][e]);
+                        for (int i = 0; i < 4; ++i)
+                            if (FE_TP * TH + 4 * i + (lane >> 4) < m) v = fmaxf(v, acc[i][j][e]);
+                        const unsigned k2 = fe_group_max(float_max_key(v));
+                        if (lane < 16) {
+                            const unsigned old = BESTL[(4 * j + e) * 128];
+                            BESTL[(4 * j + e) * 128] = k2 > old ? k2 : old;
+                        }
                     }
-                }
             };
             third(std::integral_constant<int, 0>{});
             third(std::integral_constant<int, 1>{});
@@ -884,16 +932,22 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
             // a wave stores whenever it owns at least one column block of this sweep: a tail wave (cbw < ncb <= cbw + 2) was clamped to
             // the LAST three blocks, of which ncb - cbw are its own and the others are re-stored with the values their owners write
             // (same rows, same K order: identical bits).  emb = 800 / 896 / 1024 have such tails in the second sweep.
-            if (cbw < ncb) {
+            if (cbw < ncb && lane < 16) {
+                int lane_e = lane;                                      // (opaque: or the compiler forms the twelve store / bias addresses
+                asm volatile("" : "+v"(lane_e));                        //  before the sweep and keeps them — spilled — across it)
+                const unsigned* bl = BESTL;
+                asm volatile("" : "+v"(bl));
 #pragma unroll
-                for (int j = 0; j < 6; ++j)
+                for (int j = 0; j < 6; ++j) {
+                    const float bias = a.msc_b[16 * css[j] + lane_e];
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
-                        // (a lane group none of whose points exist contributes -inf: key below every real one)
-                        const unsigned k2 = fe_group_max(float_max_key(lrelu02(__fadd_rn(__fmul_rn(best[j][tt], 0.0625f), bias[j]))));
-                        if (lane < 16 && tt < nemit)
-                            a.pooled[((int64_t)(t0 + tt) * a.b + patch_i) * a.emb + 16 * css[j] + lane] = float_from_max_key(k2);
+                        const float raw = float_from_max_key(bl[(4 * j + tt) * 128]);
+                        if (tt < nemit)
+                            a.pooled[((int64_t)(t0 + tt) * a.b + patch_i) * a.emb + 16 * css[j] + lane_e] =
+                                float_from_max_key(float_max_key(lrelu02(__fadd_rn(__fmul_rn(raw, 0.0625f), bias))));
                     }
+                }
             }
         }
     }

@@ -13,7 +13,7 @@ tail -3 $R/gpurun_out/gpu_tests.log
 fi
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/trace $R/gpurun_out/pmc_f $R/gpurun_out/pmc_w $R/gpurun_out/pmc_m
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-strong-leg --no-m100"
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-strong-leg --no-m100 --no-ref-default"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trace -- $BENCH --steps 3 --warmup 1 > $R/gpurun_out/trace.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_f -- $BENCH --steps 2 --warmup 1 --no-roofline > $R/gpurun_out/pmc_f.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_w -- $BENCH --steps 2 --warmup 1 --no-roofline > $R/gpurun_out/pmc_w.log 2>&1

@@ -12,7 +12,7 @@ CODE = (
     "from sapcu_amd import _lib\n"
     "p = os.environ.get('SAPCU_AB_LIB')\n"
     "if p: _lib.LIB_PATH = p\n"
-    "sys.argv = ['bench.py', '--steps', '8', '--warmup', '2', '--no-cpu-baseline', '--no-strong-leg', '--no-m100', '--no-roofline']\n"
+    "sys.argv = ['bench.py', '--steps', '8', '--warmup', '2', '--no-cpu-baseline', '--no-strong-leg', '--no-m100', '--no-ref-default', '--no-roofline']\n"
     "runpy.run_path(%r, run_name='__main__')\n" % (ROOT, os.path.join(ROOT, "bench.py")))
 
 
