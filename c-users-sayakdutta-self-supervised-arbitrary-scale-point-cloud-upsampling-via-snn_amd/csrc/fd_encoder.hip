@@ -52,9 +52,12 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int FE_M = 48;                 // points per patch (rows of every per-patch table)
 constexpr int FE_NT = 512;               // threads: 8 waves, 256 registers each
 constexpr int FE_XLD = 448;              // x0 of blocks 0..2: [48][448] f32
-constexpr int FE_OFF_R2 = FE_M * FE_XLD * 4;               // 86016: 64 KiB phase buffer (score keys / GEMM panels / staging)
+// (the phase buffer comes FIRST: its addresses — panel rows, planes, steps, staging tiles — then fit the 16-bit offset field of the
+//  LDS instructions and need no second base register per variant)
+constexpr int FE_OFF_R2 = 0;                               // 64 KiB phase buffer (score keys / GEMM panels / staging)
 constexpr int FE_R2_BYTES = 65536;
-constexpr int FE_OFF_XYZ = FE_OFF_R2 + FE_R2_BYTES;        // float4[48]
+constexpr int FE_OFF_XS = FE_R2_BYTES;                     // x0 of blocks 0..2: [48][448] f32 = 86 016 B
+constexpr int FE_OFF_XYZ = FE_OFF_XS + FE_M * FE_XLD * 4;  // float4[48]
 constexpr int FE_OFF_IDX0 = FE_OFF_XYZ + FE_M * 16;        // u8[48][48]: xyz neighbours, ascending distance
 constexpr int FE_OFF_IDXL = FE_OFF_IDX0 + FE_M * FE_M;     // u8[48][48]: feature-space neighbours of the current block
 constexpr int FE_OFF_XX = FE_OFF_IDXL + FE_M * FE_M;       // float[64]
@@ -464,7 +467,7 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
     constexpr int COFF_IN = L == 1 ? 0 : (L == 2 ? 64 : 192), COFF_OUT = L == 1 ? 64 : (L == 2 ? 192 : 448);
     constexpr int KIND_IN = L == 1 ? 0 : (L == 2 ? 1 : 2);
     constexpr int NPW = L == 3 ? 2 : 1;                    // column-block pairs (W1 + W2 | W1) per wave
-    float* XS = reinterpret_cast<float*>(smem);
+    float* XS = reinterpret_cast<float*>(smem + FE_OFF_XS);
     unsigned char* R2 = smem + FE_OFF_R2;
     unsigned char* IDXL = smem + FE_OFF_IDXL;
     float* xx = reinterpret_cast<float*>(smem + FE_OFF_XX);
@@ -658,9 +661,14 @@ __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char*
     FE_STAMP(4 * L + 3);
 }
 
+// GENERAL = false: the production shape — T = 4 and no spike tap, so every emission is the fully unrolled four-step form — compiled
+// WITHOUT the general emission path (any T, taps): with both in one kernel the general path's extra live values pushed the
+// allocation over 256 registers everywhere (37 spilled registers + block 3's x0 indexed in scratch, round 3); alone the kernel
+// needs 241 registers and no scratch at all.  GENERAL = true: everything else (T != 4, stage taps), may spill.
+template <bool GENERAL>
 __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    float* XS = reinterpret_cast<float*>(smem);
+    float* XS = reinterpret_cast<float*>(smem + FE_OFF_XS);
     unsigned char* R2 = smem + FE_OFF_R2;
     float4* XYZ = reinterpret_cast<float4*>(smem + FE_OFF_XYZ);
     unsigned char* IDX0 = smem + FE_OFF_IDX0;
@@ -845,7 +853,7 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
 #else
             float* tap = (a.tap_spikes && sweep == 0) ? a.tap_spikes + (a.s0 + patch_i) * (int64_t)m * 960 : nullptr;
 #endif
-            const bool fast = t0 == 0 && nemit == 4 && tap == nullptr;         // (workgroup-uniform)
+            const bool fast = !GENERAL || (t0 == 0 && nemit == 4 && tap == nullptr);         // (workgroup-uniform)
             // running maxima of the RAW accumulators per (column sub-block, step), as order-preserving keys (0 = below every key):
             // x -> LeakyReLU(x / 16 + bias) -> integer key is monotone, so the max over the points commutes with it bit for bit —
             // bias, LeakyReLU and the final key once per result
@@ -894,13 +902,13 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
                         }
                         if (ch == 0) {                                  // block 0 (wave-uniform branches)
                             if (fast) fe_emit4<0, true>(x, p, 0, 4, pe, pt0, m, count, a.gate, nullptr, 0);
-                            else fe_emit4<0, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
+                            else if (GENERAL) fe_emit4<0, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
                         } else if (ch < 3) {                            // block 1
                             if (fast) fe_emit4<1, true>(x, p, 0, 4, pe, pt0, m, count, a.gate, nullptr, 0);
-                            else fe_emit4<1, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
+                            else if (GENERAL) fe_emit4<1, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
                         } else {                                        // blocks 2, 3
                             if (fast) fe_emit4<2, true>(x, p, 0, 4, pe, pt0, m, count, a.gate, nullptr, 0);
-                            else fe_emit4<2, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
+                            else if (GENERAL) fe_emit4<2, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
                         }
                     }
                     lds_barrier();
@@ -1009,9 +1017,20 @@ int launch_fd_encoder(const FdEncArgs& a, hipStream_t st) {
     if (a.b == 0) return SAPCU_OK;
     SAPCU_CHECK_ARG(fd_encoder_ok(a.m, a.nscale, a.emb, a.T), "fd_encoder: unsupported shape m=%d scales=%d emb=%d", a.m, a.nscale, a.emb);
     SAPCU_CHECK_ARG(a.kk >= 1 && a.kk <= a.m && a.kmax0 >= 1 && a.kmax0 <= a.m && a.b < 0x7fffffffLL, "fd_encoder: bad neighbour counts");
-    static DeviceOnce lds_once;
-    SAPCU_SET_MAX_LDS(lds_once, (&fd_encoder_kernel), FE_LDS);
-    hipLaunchKernelGGL(fd_encoder_kernel, dim3((unsigned)a.b), dim3(FE_NT), FE_LDS, st, a);
+#ifdef FE_STAMPS
+    const bool production = a.T == 4;                        // (diagnostic build: the spikes tap carries the stamps)
+#else
+    const bool production = a.T == 4 && a.tap_spikes == nullptr;
+#endif
+    if (production) {                                        // the scratch-free kernel
+        static DeviceOnce lds_once;
+        SAPCU_SET_MAX_LDS(lds_once, (&fd_encoder_kernel<false>), FE_LDS);
+        hipLaunchKernelGGL(fd_encoder_kernel<false>, dim3((unsigned)a.b), dim3(FE_NT), FE_LDS, st, a);
+    } else {
+        static DeviceOnce lds_once;
+        SAPCU_SET_MAX_LDS(lds_once, (&fd_encoder_kernel<true>), FE_LDS);
+        hipLaunchKernelGGL(fd_encoder_kernel<true>, dim3((unsigned)a.b), dim3(FE_NT), FE_LDS, st, a);
+    }
     SAPCU_CHECK_LAUNCH();
     return SAPCU_OK;
 }
