@@ -26,7 +26,7 @@
 //
 // Bit-identical to the per-stage path (tests/test_gpu_parity.py::test_fused_fd_encoder_equals_the_per_stage_path_bit_for_bit):
 // same score chains and tie rule in the neighbour searches, same split-f16 products in the same k order, same neuron arithmetic
-// (block 0: neuron_step<true>, blocks 1-3: NeuronStep2), same max.  Taken for patches of <= 48 points, <= 4 scales, emb % 32 == 0 and
+// (NeuronStep2 in every block), same max.  Taken for patches of <= 48 points, <= 4 scales, emb % 32 == 0 and
 // emb >= 96 (fd_encoder_ok); anything else runs the per-stage kernels.
 #include <type_traits>
 
@@ -118,16 +118,13 @@ __device__ __forceinline__ NeuronP fe_np(const FeNP& v) {
     return p;
 }
 
-// neuron kinds: 0 = block 0 (EIF in neuron_step's operation order, as fd_neuron_kernel<true, 0>), 1 = EIF / 2 = LIF in
-// NeuronStep2's arithmetic (as fd_edge_neuron_kernel)
-// step-0 spikes of TWO elements of one channel (always real pairs: with one element per call the compiler re-vectorised the
-// scalarised half of the packed arithmetic and assembled its operand pairs through scratch memory)
+// neuron kinds: 1 = EIF (blocks 0 and 1), 2 = LIF (blocks 2 and 3), both in NeuronStep2's packed arithmetic — the arithmetic of the
+// per-stage kernels fd_neuron_kernel / fd_edge_neuron_kernel.  (Until round 4 block 0 ran neuron_step<true>, the scalar form with
+// its IEEE division per step: four times the instructions of the packed form, and — one 64-channel chunk per patch third, emitted
+// by half the waves while the others waited at the barrier — a third of multi_scale_conv's whole emission time.)
+// step-0 spikes of TWO elements of one channel
 template <int KIND>
 __device__ __forceinline__ f32x2 fe_spike0(f32x2 x, const NeuronP& p) {
-    if (KIND == 0) {
-        NeuronS sa = neuron_init(p), sb = neuron_init(p);
-        return f32x2{neuron_step<true>(x.x, sa, p), neuron_step<true>(x.y, sb, p)};
-    }
     NeuronStep2<KIND == 1> ns(p);
     return ns.step(x, true);
 }
@@ -383,30 +380,7 @@ template <int KIND, bool FAST>
 __device__ __forceinline__ void fe_emit4(const float (&x)[4], const NeuronP& p, int t0, int nemit, unsigned char* const (&pe)[4], int pt0,
                                          int m, bool count, int* __restrict__ gate, float* __restrict__ tap, int64_t tap_tstride) {
     const int total = FAST ? 4 : t0 + nemit;
-    if (KIND == 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            NeuronS s = neuron_init(p);
-            bool open = false;
-            if (FAST) {
-#pragma unroll
-                for (int step = 0; step < 4; ++step) {
-                    open = open || (step > 0 && s.r <= 0.f);
-                    fe_put_at(pe[e] + step * 64, neuron_step<true>(step == 0 ? x[e] : 0.f, s, p));
-                }
-            } else {
-                for (int step = 0; step < total; ++step) {
-                    open = open || (step > 0 && s.r <= 0.f);
-                    const float sp = neuron_step<true>(step == 0 ? x[e] : 0.f, s, p);
-                    if (step >= t0) {
-                        fe_put_at(pe[e] + (step - t0) * 64, sp);
-                        if (tap && pt0 + e < m) tap[(int64_t)step * tap_tstride + (int64_t)(pt0 + e) * 960] = sp;
-                    }
-                }
-            }
-            if (count && open && pt0 + e < m) atomicAdd(gate, 1);
-        }
-    } else {
+    {
         NeuronStep2<KIND == 1> n0(p), n1(p);
         const f32x2 z = f32x2{0.f, 0.f};
         bool o0 = false, o1 = false;
@@ -465,7 +439,7 @@ template <int L>
 __device__ __forceinline__ void fe_edge_block(const FdEncArgs& a, unsigned char* smem, int64_t patch_i, int tid, float (&x3)[3][4][4]) {
     constexpr int CIN = 64 << (L - 1), COUT = 128 << (L - 1);
     constexpr int COFF_IN = L == 1 ? 0 : (L == 2 ? 64 : 192), COFF_OUT = L == 1 ? 64 : (L == 2 ? 192 : 448);
-    constexpr int KIND_IN = L == 1 ? 0 : (L == 2 ? 1 : 2);
+    constexpr int KIND_IN = L <= 2 ? 1 : 2;                  // block L-1: EIF (blocks 0, 1) | LIF
     constexpr int NPW = L == 3 ? 2 : 1;                    // column-block pairs (W1 + W2 | W1) per wave
     float* XS = reinterpret_cast<float*>(smem + FE_OFF_XS);
     unsigned char* R2 = smem + FE_OFF_R2;
@@ -900,10 +874,7 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) x[e] = xs[512 * e];
                         }
-                        if (ch == 0) {                                  // block 0 (wave-uniform branches)
-                            if (fast) fe_emit4<0, true>(x, p, 0, 4, pe, pt0, m, count, a.gate, nullptr, 0);
-                            else if (GENERAL) fe_emit4<0, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
-                        } else if (ch < 3) {                            // block 1
+                        if (ch < 3) {                                   // blocks 0, 1: EIF (wave-uniform branches)
                             if (fast) fe_emit4<1, true>(x, p, 0, 4, pe, pt0, m, count, a.gate, nullptr, 0);
                             else if (GENERAL) fe_emit4<1, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
                         } else {                                        // blocks 2, 3

@@ -983,12 +983,13 @@ __global__ __launch_bounds__(256) void fd_neuron_kernel(const float* __restrict_
     }
     if (pre_out) pre_out[t] = pre;
     const NeuronP p = EIF ? load_eif(prm, C, c) : load_lif(prm, C, c);
-    NeuronS s = neuron_init(p);
+    // NeuronStep2's packed arithmetic, one element in both halves of the pair: element for element the arithmetic of
+    // fd_edge_neuron_kernel and of the fused encoder (fd_encoder.hip) — the three must agree bit for bit.  (Round 4: until then
+    // this kernel — block 0's stage — ran neuron_step<EIF>, the scalar form with an IEEE division per EIF step.)
+    NeuronStep2<EIF> n(p);
     for (int step = 0; step < T; ++step) {
-        float x = 0.f;
-        if (step == 0) x = pre;
-        else if (s.r <= 0.f) atomicAdd(gate_violations, 1);
-        const float sp = neuron_step<EIF>(x, s, p);
+        if (step > 0 && n.gate_open()) atomicAdd(gate_violations, 1);
+        const float sp = n.step(step == 0 ? f32x2{pre, pre} : f32x2{0.f, 0.f}, step == 0).x;
         // spk_split: every step as split rows (the operand of the multi_scale_conv GEMM), f32 only for step 0 (the features
         // the next blocks' neighbour search and EdgeConv read) — spk is then the [pts, ldo] slab of step 0 alone
         if (spk_split) {
