@@ -53,6 +53,7 @@ _SIGNATURES = {
                                           c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "sapcu_gather_rows": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "sapcu_scatter_add_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "sapcu_scatter_add_rows_grouped": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "sapcu_group_max_forward": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sapcu_group_max_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "sapcu_neuron_selfloop": (c_int, [c_void_p, c_int64, c_int, c_int] + [c_void_p] * 6 + [c_void_p] * 4 + [c_void_p]),

@@ -376,15 +376,14 @@ static int wgrad_slabs(int64_t rows) {                       // ~1024 rows per s
 // ---- backward of the per-channel softmax over the k neighbours + weighted aggregation (fn/snn_coder.py:379-389):
 //   forward (fn_softmax_agg_kernel): w = softmax_j(a_j / sqrt(hd)), u_j = v[nbr_j] + pe_j, res = sum_j w_j u_j
 //   backward, g = d res:  d pe_j = w_j g;  d v[nbr_j] += w_j g (scatter-add);  d a_j = w_j g (u_j - res) / sqrt(hd)
-// thread per (point, channel); the softmax is recomputed from `a` with the forward kernel's arithmetic.  grad_v is
-// accumulated with float atomics (a neighbour row receives contributions from several points: summation order, and so
-// the last bits of grad_v, may differ between runs).
+// thread per (point, channel); the softmax is recomputed from `a` with the forward kernel's arithmetic.  grad_v is NOT written
+// here: its contributions are exactly the d pe_j values, which scatter_sum_grouped_kernel sums per neighbour row in a fixed
+// order afterwards (round 4; float atomics until then — the one run-to-run difference of a training step).
 __global__ __launch_bounds__(256) void softmax_agg_bwd_kernel(const float* __restrict__ a, const float* __restrict__ pe,
                                                               const float* __restrict__ v, int ldv, const int32_t* __restrict__ idx,
                                                               const float* __restrict__ gres, int64_t pts, int m, int kk, int d,
                                                               float sqrt_hd, const float* __restrict__ keep,
-                                                              float* __restrict__ ga, float* __restrict__ gpe,
-                                                              float* __restrict__ gv, int ldgv) {
+                                                              float* __restrict__ ga, float* __restrict__ gpe) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= pts * d) return;
     const int c = (int)(t % d);
@@ -414,7 +413,6 @@ __global__ __launch_bounds__(256) void softmax_agg_bwd_kernel(const float* __res
         const float u = __fadd_rn(v[nb * ldv + c], pr[(int64_t)j * d]);
         const float wg = wj * kj * g;
         gpe[(pt * kk + j) * d + c] = wg;
-        atomicAdd(gv + nb * ldgv + c, wg);
         ga[(pt * kk + j) * d + c] = wj * g * (kj * u - res) * inv_sqrt_hd;
     }
 }
@@ -481,6 +479,75 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
     const int64_t r = t / d;
     const int c = (int)(t - r * d);
     atomicAdd(gsrc + index[r] * ldg + c, gout[t]);
+}
+
+// ---- deterministic scatter-add for the patch-structured indices of the training step (round 4).  Every index tensor the step
+// scatters through is grouped: the gr source rows of group g (the m k edge rows of a patch) point into the gs destination rows
+// of the SAME group (the patch's m points).  One workgroup per group: the group's destinations (as local ids) go to LDS, the
+// INVERSE table is built there — destination t's sources in ascending source order, by one thread per destination scanning the
+// gr entries twice (count, then fill behind an exclusive prefix of the counts) — and every (destination, channel) is then summed
+// by one thread over its sources in that order and STORED: no atomics, no zeroing, the same bits every run.  (The float
+// atomicAdd form summed in arrival order: the last bits of the gradients, and with hard spikes whole trajectories, differed
+// from run to run.)  LOCAL = true: index32 holds in-patch ids (softmax-aggregate's neighbour table); false: index64 holds global
+// rows, local id = index - g gs.  Entries outside [0, gs) are skipped and counted in *bad (may be null).
+// =============================================================================================
+template <bool LOCAL>
+__global__ __launch_bounds__(256) void scatter_sum_grouped_kernel(const float* __restrict__ gout, const int32_t* __restrict__ index32,
+                                                                  const int64_t* __restrict__ index64, int gs, int gr, int d,
+                                                                  float* __restrict__ gsrc, int ldg, int* __restrict__ bad) {
+    extern __shared__ unsigned char sg_smem[];
+    int* dst = reinterpret_cast<int*>(sg_smem);                 // [gr] local destination of each source row (-1: none)
+    int* lst = dst + gr;                                        // [gr] source rows ordered by (destination, source)
+    int* off = lst + gr;                                        // [gs + 1] start of each destination's list
+    const int64_t g = blockIdx.x;
+    const int tid = threadIdx.x;
+    int nbad = 0;
+    for (int e = tid; e < gr; e += 256) {
+        const int64_t v = LOCAL ? (int64_t)index32[g * gr + e] : index64[g * gr + e] - g * gs;
+        const bool ok = v >= 0 && v < gs;
+        dst[e] = ok ? (int)v : -1;
+        nbad += ok ? 0 : 1;
+    }
+    if (nbad && bad) atomicAdd(bad, nbad);
+    __syncthreads();
+    for (int t = tid; t < gs; t += 256) {                       // count
+        int c = 0;
+        for (int e = 0; e < gr; ++e) c += dst[e] == t;
+        off[t + 1] = c;
+    }
+    __syncthreads();
+    if (tid == 0) {                                             // exclusive prefix (gs <= a few hundred)
+        off[0] = 0;
+        for (int t = 0; t < gs; ++t) off[t + 1] += off[t];
+    }
+    __syncthreads();
+    for (int t = tid; t < gs; t += 256) {                       // fill, ascending source order
+        int w = off[t];
+        for (int e = 0; e < gr; ++e)
+            if (dst[e] == t) lst[w++] = e;
+    }
+    __syncthreads();
+    const float* gb = gout + g * gr * (int64_t)d;
+    float* ob = gsrc + g * gs * (int64_t)ldg;
+    for (int64_t q = tid; q < (int64_t)gs * d; q += 256) {
+        const int t = (int)(q / d), c = (int)(q - (int64_t)t * d);
+        float s = 0.f;
+        for (int w = off[t]; w < off[t + 1]; ++w) s = __fadd_rn(s, gb[(int64_t)lst[w] * d + c]);
+        ob[(int64_t)t * ldg + c] = s;
+    }
+}
+
+static int launch_scatter_sum_grouped(const float* gout, const int32_t* i32, const int64_t* i64, int64_t groups, int gs, int gr, int d,
+                                      float* gsrc, int ldg, int* bad, hipStream_t st) {
+    if (groups == 0) return SAPCU_OK;
+    const size_t lds = ((size_t)2 * gr + gs + 1) * sizeof(int);
+    SAPCU_CHECK_ARG(lds <= 64 * 1024 && groups < 0x7fffffffLL, "scatter_sum_grouped: group too large (%d sources, %d destinations)", gr, gs);
+    if (i32)
+        hipLaunchKernelGGL(scatter_sum_grouped_kernel<true>, dim3((unsigned)groups), dim3(256), lds, st, gout, i32, i64, gs, gr, d, gsrc, ldg, bad);
+    else
+        hipLaunchKernelGGL(scatter_sum_grouped_kernel<false>, dim3((unsigned)groups), dim3(256), lds, st, gout, i32, i64, gs, gr, d, gsrc, ldg, bad);
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
 }
 
 // ---- max over the points of a patch (adaptive_max_pool1d(., 1), fn/snn_coder.py:472) with the arg-max kept for the backward;
@@ -693,11 +760,11 @@ int sapcu_softmax_agg_backward(const float* a, const float* pe, const float* v, 
     if (pts == 0) return SAPCU_OK;
     SAPCU_CHECK_ARG(pts % m == 0, "softmax_agg_backward: points must come in whole patches of m");
     hipStream_t st = (hipStream_t)stream;
-    { const int rc = launch_zero_rows(grad_v, pts, ldgv, d, st); if (rc != SAPCU_OK) return rc; }
     hipLaunchKernelGGL(softmax_agg_bwd_kernel, dim3((unsigned)((pts * d + 255) / 256)), dim3(256), 0, st, a, pe, v, ldv, idx, grad_res,
-                       pts, m, kk, d, sqrt_hd, keep, grad_a, grad_pe, grad_v, ldgv);
+                       pts, m, kk, d, sqrt_hd, keep, grad_a, grad_pe);
     SAPCU_CHECK_LAUNCH();
-    return SAPCU_OK;
+    // grad_v[nbr] = sum over the (point, j) edges that list nbr of d pe_j, in ascending edge order (deterministic)
+    return launch_scatter_sum_grouped(grad_pe, idx, nullptr, pts / m, m, m * kk, d, grad_v, ldgv, nullptr, st);
 }
 
 
@@ -722,6 +789,17 @@ int sapcu_scatter_add_rows(const float* grad_out, const int64_t* index, int64_t 
     return SAPCU_OK;
 }
 
+
+int sapcu_scatter_add_rows_grouped(const float* grad_out, const int64_t* index, int64_t rows, int d, float* grad_src, int ld_grad,
+                                   int64_t src_rows, int group_src_rows, int group_rows, int* bad_count, void* stream) {
+    SAPCU_CHECK_ARG(grad_out && index && grad_src && rows >= 0 && d >= 1 && ld_grad >= d && src_rows >= 0 && group_src_rows >= 1 &&
+                        group_rows >= 1, "scatter_add_rows_grouped: bad argument");
+    SAPCU_CHECK_ARG(rows % group_rows == 0 && src_rows % group_src_rows == 0 && rows / group_rows == src_rows / group_src_rows,
+                    "scatter_add_rows_grouped: %lld rows / %d and %lld destination rows / %d are not the same number of whole groups",
+                    (long long)rows, group_rows, (long long)src_rows, group_src_rows);
+    return launch_scatter_sum_grouped(grad_out, nullptr, index, rows / group_rows, group_src_rows, group_rows, d, grad_src, ld_grad,
+                                      bad_count, (hipStream_t)stream);
+}
 
 int sapcu_group_max_forward(const float* x, int64_t groups, int m, int c, float* out, int32_t* argmax_out, void* stream) {
     SAPCU_CHECK_ARG(x && out && argmax_out && groups >= 0 && m >= 1 && c >= 1, "group_max_forward: bad argument");

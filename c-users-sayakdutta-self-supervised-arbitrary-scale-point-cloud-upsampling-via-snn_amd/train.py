@@ -252,7 +252,7 @@ def conv_bn_train(x, weight, bias, gamma, beta, eps=1e-5, running=None):
 
 class _GatherRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src, index):
+    def forward(ctx, src, index, group=None):
         lib = _lib.load()
         src = src.contiguous()
         index = index.contiguous().to(torch.int64)
@@ -262,6 +262,7 @@ class _GatherRows(torch.autograd.Function):
             _lib.check(lib.sapcu_gather_rows(_lib.ptr(src), d, _lib.ptr(index), rows, d, _lib.ptr(out), _lib.current_stream()))
         ctx.save_for_backward(index)
         ctx.src_rows = src.shape[0]
+        ctx.group = group
         return out
 
     @staticmethod
@@ -272,14 +273,22 @@ class _GatherRows(torch.autograd.Function):
         rows, d = g.shape
         gsrc = torch.empty((ctx.src_rows, d), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
-            _lib.check(lib.sapcu_scatter_add_rows(_lib.ptr(g), _lib.ptr(index), rows, d, _lib.ptr(gsrc), d, ctx.src_rows,
-                                                  _lib.current_stream()))
-        return gsrc, None
+            if ctx.group is not None:           # patch-structured index: the deterministic segmented sum
+                gs, gr = ctx.group
+                _lib.check(lib.sapcu_scatter_add_rows_grouped(_lib.ptr(g), _lib.ptr(index), rows, d, _lib.ptr(gsrc), d, ctx.src_rows,
+                                                              int(gs), int(gr), None, _lib.current_stream()))
+            else:                               # arbitrary index: float atomics (summation order not fixed)
+                _lib.check(lib.sapcu_scatter_add_rows(_lib.ptr(g), _lib.ptr(index), rows, d, _lib.ptr(gsrc), d, ctx.src_rows,
+                                                      _lib.current_stream()))
+        return gsrc, None, None
 
 
-def gather_rows(src, index):
-    """out[r] = src[index[r]] on [rows, d] tensors (index_points, fn/snn_coder.py:19-29); backward = scatter-add."""
-    return _GatherRows.apply(src, index)
+def gather_rows(src, index, group=None):
+    """out[r] = src[index[r]] on [rows, d] tensors (index_points, fn/snn_coder.py:19-29); backward = scatter-add.
+    group = (destination rows per group, index rows per group) when the index is patch-structured — rows r of group g (a
+    patch's m*k edge rows) only point into source rows [g*gs, (g+1)*gs) (the patch's m points): the backward is then the
+    deterministic segmented sum (sapcu_scatter_add_rows_grouped) instead of float atomics."""
+    return _GatherRows.apply(src, index, group)
 
 
 def _pad_channels(t, mult=32):
@@ -327,10 +336,11 @@ def transformer_block_train(p, xyz, features, knn_idx, time_steps=4, num_heads=8
     q = layer(x, "w_qs.0", "w_qs.1", "snn_q")
     kf = layer(x, "w_ks.0", "w_ks.1", "snn_k")
     v = layer(x, "w_vs.0", "w_vs.1", "snn_v")
-    pos_diff = gather_rows(xyzr, ptr) - gather_rows(xyzr, nbr)            # [P*k, 3]
+    grp = (N, N * k)                                                      # every index below stays inside its patch
+    pos_diff = gather_rows(xyzr, ptr, grp) - gather_rows(xyzr, nbr, grp)  # [P*k, 3]
     pe = layer(pos_diff, "fc_delta.0", "fc_delta.1", "snn_delta")
     pe = layer(pe, "fc_delta2.0", "fc_delta2.1", "snn_delta2")
-    attn_in = gather_rows(q, ptr) - gather_rows(kf, nbr) + pe
+    attn_in = gather_rows(q, ptr, grp) - gather_rows(kf, nbr, grp) + pe
     a = layer(attn_in, "fc_gamma.0", "fc_gamma.1", "snn_gamma")
     a = layer(a, "fc_gamma2.0", "fc_gamma2.1")
     d_model = a.shape[1]

@@ -180,6 +180,14 @@ int sapcu_softmax_agg_backward(const float* a, const float* pe, const float* v, 
 int sapcu_gather_rows(const float* src, int ld_src, const int64_t* index, int64_t rows, int d, float* out, void* stream);
 int sapcu_scatter_add_rows(const float* grad_out, const int64_t* index, int64_t rows, int d, float* grad_src, int ld_grad,
                            int64_t src_rows, void* stream);
+/* The same sum for GROUPED indices, deterministic (no atomics, no zeroing pass): rows come in groups of group_rows consecutive
+ * rows (a patch's m k edge rows) whose indices all point into the group_src_rows destination rows of the same group (the
+ * patch's m points: index[r] / group_src_rows == r / group_rows).  One workgroup per group builds the inverse table in LDS and
+ * sums every destination's sources in ascending source order — bit-identical from run to run, which the float-atomic form is
+ * not.  This is what the training step uses (index_points' backward, and inside sapcu_softmax_agg_backward for grad_v).
+ * bad_count: NULL or a device int that receives the number of entries pointing outside their group (skipped). */
+int sapcu_scatter_add_rows_grouped(const float* grad_out, const int64_t* index, int64_t rows, int d, float* grad_src, int ld_grad,
+                                   int64_t src_rows, int group_src_rows, int group_rows, int* bad_count, void* stream);
 
 /* Max over the m points of each patch, x [groups*m, c] -> out [groups, c] (adaptive_max_pool1d, fn/snn_coder.py:472), with
  * the arg-max (ties -> first point) for the backward, which routes grad_out to that point. */
