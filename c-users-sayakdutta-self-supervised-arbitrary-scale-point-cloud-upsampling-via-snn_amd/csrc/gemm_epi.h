@@ -7,6 +7,24 @@ namespace sapcu {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// The split-f16 product instruction of the ring / f32-A kernels.  -DSAPCU_TIMING_MFMA16 (diagnostic, WRONG results): the same
+// flops issued as two v_mfma_f32_16x16x32_f16 on quarters of the accumulator — the timing-only prototype that bounds what moving
+// these two kernels to the small MFMA shape could gain (profiles/r04_ab_mfma16_ring.txt).
+typedef _Float16 epi_half8 __attribute__((ext_vector_type(8)));
+typedef float epi_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 mfma_32x32x16_f16(epi_half8 a, epi_half8 b, f32x16 c) {
+#ifdef SAPCU_TIMING_MFMA16
+    epi_f32x4 q0 = {c[0], c[1], c[2], c[3]}, q1 = {c[8], c[9], c[10], c[11]};
+    q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q0, 0, 0, 0);
+    q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q1, 0, 0, 0);
+    c[0] = q0[0]; c[1] = q0[1]; c[2] = q0[2]; c[3] = q0[3];
+    c[8] = q1[0]; c[9] = q1[1]; c[10] = q1[2]; c[11] = q1[3];
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits vmcnt(0), i.e. for the

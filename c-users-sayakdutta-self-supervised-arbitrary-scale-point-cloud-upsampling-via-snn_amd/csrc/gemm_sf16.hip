@@ -200,7 +200,7 @@ __global__ __launch_bounds__(1024) void gemm_sf16_kernel(const GemmArgs g) {
 #pragma unroll
                             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[t], w2[t][j], acc[j], 0, 0, 0);
+                                for (int j = 0; j < 2; ++j) acc[j] = mfma_32x32x16_f16(a2[t], w2[t][j], acc[j]);
                             __builtin_amdgcn_sched_barrier(0);
                         };
                         product(1, 0);      // a_lo . w_hi

@@ -213,12 +213,12 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
         f32x16 acc[2];
         auto mfma6 = [&](const Frags& f) {
             // alternate the two accumulators so consecutive MFMAs never depend on each other
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.wh[0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.wh[1], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wl[0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wl[1], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wh[0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.wh[1], acc[1], 0, 0, 0);
+            acc[0] = mfma_32x32x16_f16(f.al, f.wh[0], acc[0]);
+            acc[1] = mfma_32x32x16_f16(f.al, f.wh[1], acc[1]);
+            acc[0] = mfma_32x32x16_f16(f.ah, f.wl[0], acc[0]);
+            acc[1] = mfma_32x32x16_f16(f.ah, f.wl[1], acc[1]);
+            acc[0] = mfma_32x32x16_f16(f.ah, f.wh[0], acc[0]);
+            acc[1] = mfma_32x32x16_f16(f.ah, f.wh[1], acc[1]);
         };
         auto wait_landed = [&](int64_t step) {     // this wave's DMAs of `step` have landed (4 DMAs per step, in order)
             const int64_t ahead = issued - step - 1;
@@ -250,18 +250,18 @@ __global__ __launch_bounds__(1024) void gemm_ring_kernel(const GemmArgs g) {
                     // the accumulation order of a kernel that issues one v_mfma_f32_16x16x32_f16 per product (fn_edge_chain.hip,
                     // fd_encoder.hip): two chained 32x32x16 over the same 32 k values equal one 16x16x32 bit for bit
                     // (profiles/micro/mfma_f16_shapes_bits.hip)
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.al, f0.wh[0], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.al, f0.wh[1], acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.al, f1.wh[0], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.al, f1.wh[1], acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.ah, f0.wl[0], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.ah, f0.wl[1], acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.ah, f1.wl[0], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.ah, f1.wl[1], acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.ah, f0.wh[0], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.ah, f0.wh[1], acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.ah, f1.wh[0], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.ah, f1.wh[1], acc[1], 0, 0, 0);
+                    acc[0] = mfma_32x32x16_f16(f0.al, f0.wh[0], acc[0]);
+                    acc[1] = mfma_32x32x16_f16(f0.al, f0.wh[1], acc[1]);
+                    acc[0] = mfma_32x32x16_f16(f1.al, f1.wh[0], acc[0]);
+                    acc[1] = mfma_32x32x16_f16(f1.al, f1.wh[1], acc[1]);
+                    acc[0] = mfma_32x32x16_f16(f0.ah, f0.wl[0], acc[0]);
+                    acc[1] = mfma_32x32x16_f16(f0.ah, f0.wl[1], acc[1]);
+                    acc[0] = mfma_32x32x16_f16(f1.ah, f1.wl[0], acc[0]);
+                    acc[1] = mfma_32x32x16_f16(f1.ah, f1.wl[1], acc[1]);
+                    acc[0] = mfma_32x32x16_f16(f0.ah, f0.wh[0], acc[0]);
+                    acc[1] = mfma_32x32x16_f16(f0.ah, f0.wh[1], acc[1]);
+                    acc[0] = mfma_32x32x16_f16(f1.ah, f1.wh[0], acc[0]);
+                    acc[1] = mfma_32x32x16_f16(f1.ah, f1.wh[1], acc[1]);
                     if (gstep + 1 < total_steps) {
                         wait_landed(gstep + 1);
                         lds_barrier();
