@@ -424,6 +424,24 @@ __device__ __forceinline__ void fe_emit4(const float (&x)[4], const NeuronP& p, 
     }
 }
 
+// max(a, b) for finite values and -inf as v_med3_f32(a, b, FLT_MAX): one instruction.  fmaxf costs two more — the compiler quiets
+// each operand it cannot prove non-signalling (MFMA results) with v_max_f32 x, x first — and med3(a, b, +inf) is folded back into
+// that fmaxf.  (NOT inline asm: the hazard recogniser does not see into it, and a VALU read of a matrix-pipe result needs software
+// wait states.)  No NaN and no +inf reaches these maxima.
+__device__ __forceinline__ float fe_max2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, 3.40282346638528859812e38f); }
+__device__ __forceinline__ float fe_max3(float a, float b, float c) { return fe_max2(fe_max2(a, b), c); }
+// Four per-lane values v[0..3], each to be maximised over the four 16-lane rows of the wave: a reduce-scatter in three swaps and
+// three maxima — row g ends up with the full maximum of v[g] (v_permlane32_swap exchanges the upper half of its first operand
+// with the lower half of its second, v_permlane16_swap the odd rows of the first with the even rows of the second).
+__device__ __forceinline__ float fe_rows_max4(float v0, float v1, float v2, float v3) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v2), false, false);
+    const float x = fe_max2(__uint_as_float(a[0]), __uint_as_float(a[1]));          // rows 0, 1: v0 over the halves | rows 2, 3: v2
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v1), __float_as_uint(v3), false, false);
+    const float y = fe_max2(__uint_as_float(b[0]), __uint_as_float(b[1]));          // rows 0, 1: v1 | rows 2, 3: v3
+    const auto c = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return fe_max2(__uint_as_float(c[0]), __uint_as_float(c[1]));                   // row g: v[g] over all four rows
+}
+
 __device__ __forceinline__ unsigned fe_group_max(unsigned x) {    // max over the four lane groups' values, in all of them
     const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);       // [g0,g0,g2,g2], [g1,g1,g3,g3]
     const unsigned m1 = r[0] > r[1] ? r[0] : r[1];
@@ -676,76 +694,79 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
     __syncthreads();
     FE_STAMP(1);
     // ---- block 0: EdgeConv(6 -> 64) per scale, max over the ks nearest, + bias, LeakyReLU -> split panel [64][64 S]   fd:413-420
+    // Round 4: on the matrix pipe.  An edge's value for (scale, channel) is the 6-term dot product w . (xj - xi, xj), which the
+    // per-stage kernel (fd_edge0_scalar_kernel) evaluates as a k-ascending chain w0 dx, fma(w1, dy, .), ... fma(w5, zj, .) — and a
+    // k-ascending chain of IEEE f32 FMAs is exactly what v_mfma_f32_16x16x4_f32 computes (fe_knn; profiles/micro/mfma_f32_exact.hip;
+    // fma(w0, dx, +0) = w0 dx up to the sign of a zero, which neither the max nor the + bias that follow can see).  So a 16 x 16
+    // block of (edge, channel) pairs is two MFMAs (k = dx dy dz xj | yj zj 0 0): rows = 16 consecutive neighbours of the point's
+    // sorted list, columns = 16 channels.  A point needs its 6 edge operands once — they serve all scales and channel blocks —
+    // and 8 MFMAs per (scale, 16-neighbour tile): 56 per point at the reference's scales (8, 16, 32, 48), against 624 packed FMAs
+    // + 208 maxima per lane pair before (2.7 x their issue floor: index -> coordinate chains of two LDS latencies per edge).
     {
-        float wt[4][6], bb[4];
+        const float* XYZf = reinterpret_cast<const float*>(XYZ);
+        const int r16 = lane & 15, g4 = lane >> 4;
+        float wb[4][4][2], bb[4];                              // B operands: W_s[channel 16 ct + r16][k = 4 kstep + g4] (k >= 6: 0)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int sc = 0; sc < 4; ++sc) {
 #pragma unroll
-            for (int t = 0; t < 6; ++t) wt[s][t] = s < a.nscale ? a.e0_w[((int64_t)s * 64 + lane) * 6 + t] : 0.f;
-            bb[s] = s < a.nscale ? a.e0_b[s * 64 + lane] : 0.f;
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int kstep = 0; kstep < 2; ++kstep) {
+                    const int k = 4 * kstep + g4;
+                    wb[sc][ct][kstep] = (sc < a.nscale && k < 6) ? a.e0_w[((int64_t)sc * 64 + 16 * ct + r16) * 6 + k] : 0.f;
+                }
+            bb[sc] = sc < a.nscale ? a.e0_b[sc * 64 + lane] : 0.f;       // the channel this lane STORES: 16 g4 + r16 = lane
         }
         int ksv[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) ksv[s] = s < a.nscale ? a.ks[s] : 0;
+        for (int sc = 0; sc < 4; ++sc) ksv[sc] = sc < a.nscale ? a.ks[sc] : 0;
         float big = 0.f;
-        for (int i = 2 * w; i < m; i += 16) {
-            const int i1 = (i + 1 < m) ? i + 1 : i;
-            const float4 pa = XYZ[i], pb = XYZ[i1];
-            const f32x2 xi = f32x2{pa.x, pb.x}, yi = f32x2{pa.y, pb.y}, zi = f32x2{pa.z, pb.z};
-            f32x2 mx[4];
+        for (int i = w; i < m; i += FE_NT / 64) {
+            // edge operands of point i: A[row = neighbour 16 jt + r16][k = 4 kstep + g4]
+            const float xi_c = g4 < 3 ? XYZf[4 * i + g4] : 0.f;                      // kstep 0: (xj - xi, yj - yi, zj - zi, xj)
+            float ea[3][2];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) mx[s] = f32x2{-__builtin_huge_valf(), -__builtin_huge_valf()};
-            // the coordinates of four edges per point are read one batch AHEAD of the arithmetic that uses them (index -> coordinate
-            // is a chain of two LDS latencies); the batch loop is rolled, two batches per iteration (static double-buffer slots) —
-            // fully unrolled, the compiler hoists the 192 (edge, scale) activity conditions out of the point loop and spills them
-            const unsigned char* ia_ = IDX0 + i * FE_M;
-            const unsigned char* ib_ = IDX0 + i1 * FE_M;
-            float4 qa[2][4], qb[2][4];
-            auto issue = [&](int d, float4 (&da)[4], float4 (&db)[4]) {
-                const int dd = d < 12 ? d : 11;                          // (row pitch 48 bytes = 12 batches; entries beyond kmax0: "point 0")
-                const unsigned na = *reinterpret_cast<const unsigned*>(ia_ + 4 * dd);
-                const unsigned nb = *reinterpret_cast<const unsigned*>(ib_ + 4 * dd);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    da[u] = XYZ[(na >> (8 * u)) & 255u];
-                    db[u] = XYZ[(nb >> (8 * u)) & 255u];
-                }
-            };
-            auto edges = [&](int j0, const float4 (&da)[4], const float4 (&db)[4]) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = j0 + u;
-                    const f32x2 xj = f32x2{da[u].x, db[u].x}, yj = f32x2{da[u].y, db[u].y}, zj = f32x2{da[u].z, db[u].z};
-                    const f32x2 dx = xj - xi, dy = yj - yi, dz = zj - zi;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        if (j < ksv[s]) {                                   // (ksv[s] = 0 for s >= nscale)
-                            f32x2 v = f32x2{wt[s][0], wt[s][0]} * dx;
-                            v = pk_fma(f32x2{wt[s][1], wt[s][1]}, dy, v);
-                            v = pk_fma(f32x2{wt[s][2], wt[s][2]}, dz, v);
-                            v = pk_fma(f32x2{wt[s][3], wt[s][3]}, xj, v);
-                            v = pk_fma(f32x2{wt[s][4], wt[s][4]}, yj, v);
-                            v = pk_fma(f32x2{wt[s][5], wt[s][5]}, zj, v);
-                            mx[s] = f32x2{fmaxf(mx[s].x, v.x), fmaxf(mx[s].y, v.y)};
-                        }
-                    }
-                }
-            };
-            issue(0, qa[0], qb[0]);
-#pragma unroll 1
-            for (int d0 = 0; 4 * d0 < a.kmax0; d0 += 2) {
-                issue(d0 + 1, qa[1], qb[1]);
-                edges(4 * d0, qa[0], qb[0]);
-                issue(d0 + 2, qa[0], qb[0]);
-                if (4 * (d0 + 1) < a.kmax0) edges(4 * (d0 + 1), qa[1], qb[1]);
+            for (int jt = 0; jt < 3; ++jt) {
+                const int nb = IDX0[i * FE_M + 16 * jt + r16];                       // (entries beyond kmax0: "point 0", masked below)
+                ea[jt][0] = XYZf[4 * nb + (g4 < 3 ? g4 : 0)] - xi_c;                // (xj - 0 for g4 == 3: exact)
+                ea[jt][1] = g4 < 2 ? XYZf[4 * nb + 1 + g4] : 0.f;                    // kstep 1: (yj, zj, 0, 0)
             }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (s < a.nscale) {
-                    const float va = lrelu02(__fadd_rn(mx[s].x, bb[s])), vb = lrelu02(__fadd_rn(mx[s].y, bb[s]));
-                    fe_put<64>(R2, i, s * 64 + lane, va);
-                    if (i1 != i) fe_put<64>(R2, i1, s * 64 + lane, vb);
-                    big = fmaxf(big, fmaxf(fabsf(va), fabsf(vb)));
+            for (int sc = 0; sc < 4; ++sc) {
+                if (sc < a.nscale) {                                                 // (wave-uniform)
+                    const int nfull = ksv[sc] >> 4, rem = ksv[sc] & 15;               // whole 16-neighbour tiles + the edges of a last one
+                    const int lim = rem - 4 * g4;                                     // ... of which this lane's quad holds e < lim
+                    float mx[4];
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) mx[ct] = -__builtin_huge_valf();
+#pragma unroll
+                    for (int jt = 0; jt < 3; ++jt) {
+                        const bool full = jt < nfull, part = jt == nfull && rem > 0;  // (wave-uniform)
+                        if (full || part) {
+                            f32x4 acc[4];
+#pragma unroll
+                            for (int ct = 0; ct < 4; ++ct)
+                                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[jt][0], wb[sc][ct][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                            for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[jt][1], wb[sc][ct][1], acc[ct], 0, 0, 0);
+                            if (full) {                                              // acc[ct][e]: edge 16 jt + 4 g4 + e, channel 16 ct + r16
+#pragma unroll
+                                for (int ct = 0; ct < 4; ++ct)
+                                    mx[ct] = fe_max3(fe_max3(mx[ct], acc[ct][0], acc[ct][1]), acc[ct][2], acc[ct][3]);
+                            } else {
+#pragma unroll
+                                for (int ct = 0; ct < 4; ++ct) {
+                                    const float ninf = -__builtin_huge_valf();
+                                    mx[ct] = fe_max3(fe_max3(mx[ct], 0 < lim ? acc[ct][0] : ninf, 1 < lim ? acc[ct][1] : ninf),
+                                                     2 < lim ? acc[ct][2] : ninf, 3 < lim ? acc[ct][3] : ninf);
+                                }
+                            }
+                        }
+                    }
+                    // over the four lane groups' edges; lane group g4 keeps channel block ct = g4, i.e. channel 16 g4 + r16 = lane
+                    const float va = lrelu02(__fadd_rn(fe_rows_max4(mx[0], mx[1], mx[2], mx[3]), bb[sc]));
+                    fe_put<64>(R2, i, sc * 64 + lane, va);
+                    big = fmaxf(big, fabsf(va));
                 }
             }
         }
