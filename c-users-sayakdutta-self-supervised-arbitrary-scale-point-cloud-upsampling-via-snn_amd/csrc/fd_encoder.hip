@@ -823,10 +823,10 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
     // the running maxima live in LDS too (the dead per-patch tables: one dword per (column, step), updated once per third by the
     // lane that owns it).
     float* X3L = reinterpret_cast<float*>(smem + FE_OFF_X3L) + tid;                    // value v of this thread: X3L[512 v]
-    unsigned* BESTL = reinterpret_cast<unsigned*>(smem + FE_OFF_BEST) + w * 16 + (lane & 15);   // (j, tt): BESTL[(4 j + tt) * 128]
+    float* BESTL = reinterpret_cast<float*>(smem + FE_OFF_BEST) + (lane >> 4) * 128 + w * 16 + (lane & 15);   // (j, step = this lane's row): BESTL[512 j]
     FE_STAMP(16);
 #ifdef FE_STAMPS
-    unsigned long long fe_t_emit = 0, fe_t_mfma = 0, fe_tp = 0;
+    unsigned long long fe_t_emit = 0, fe_t_mfma = 0, fe_t_start = 0, fe_t_epi = 0, fe_tp = 0;
 #define FE_T0() fe_tp = __builtin_amdgcn_s_memtime()
 #define FE_TACC(V) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (V) += now_ - fe_tp; fe_tp = now_; } while (0)
 #else
@@ -852,15 +852,14 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
             // running maxima of the RAW accumulators per (column sub-block, step), as order-preserving keys (0 = below every key):
             // x -> LeakyReLU(x / 16 + bias) -> integer key is monotone, so the max over the points commutes with it bit for bit —
             // bias, LeakyReLU and the final key once per result
-            if (lane < 16) {
 #pragma unroll
-                for (int q = 0; q < 24; ++q) BESTL[q * 128] = 0u;
-            }
+            for (int j = 0; j < 6; ++j) BESTL[512 * j] = -__builtin_huge_valf();
             // one third of the patch; TH is compile-time (a generic lambda called with integral constants: x3 is indexed
             // statically and stays in registers), the rounds are a rolled loop
             auto third = [&](auto th_c) {
                 constexpr int TH = decltype(th_c)::value;
                 const int pt0 = FE_TP * TH + 4 * rg;                    // this thread's first point
+                FE_T0();
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl)                          // this third's block-3 x0: registers -> this thread's LDS slots
 #pragma unroll
@@ -877,6 +876,7 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
                     Wl[j] = fe_wfrag(mscw, 30, css[j], 0, 1, lane);
                 }
                 FeNP pnext = fe_load_np(a.nprm, 64 * cw + lane);         // a chunk's neuron parameters are loaded one round ahead
+                FE_TACC(fe_t_start);
 #pragma unroll 1
                 for (int R = 0; R < 8; ++R) {
                     const int ch = 2 * R + cw;                          // this wave's chunk (15 = none: round 7, odd waves)
@@ -909,22 +909,23 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
                     lds_barrier();
                     FE_TACC(fe_t_mfma);
                 }
-                // epilogue of this third: maximum per step over the third's points (row = 4 point + step: register u of a quad is
-                // step u) — first over this lane's own points, then over the four lane groups —, folded into the running maxima
+                // epilogue of this third: maximum per step over the third's points (row = 4 point + step: register e of a quad is
+                // step e) — first over this lane's own points, then over the four lane groups by a reduce-scatter that leaves step g
+                // in lane group g (fe_rows_max4: 3 swaps + 3 maxima for the four steps) —, folded into the running maxima
+                const bool allv = FE_TP * (TH + 1) <= m;                // (workgroup-uniform: every point of this third exists)
 #pragma unroll
-                for (int j = 0; j < 6; ++j)
+                for (int j = 0; j < 6; ++j) {
+                    float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float v = -__builtin_huge_valf();               // (a lane group none of whose points exist: below every real value)
+                        v[e] = -__builtin_huge_valf();                  // (a lane group none of whose points exist: below every real value)
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            if (FE_TP * TH + 4 * i + (lane >> 4) < m) v = fmaxf(v, acc[i][j][e]);
-                        const unsigned k2 = fe_group_max(float_max_key(v));
-                        if (lane < 16) {
-                            const unsigned old = BESTL[(4 * j + e) * 128];
-                            BESTL[(4 * j + e) * 128] = k2 > old ? k2 : old;
-                        }
+                            if (allv || FE_TP * TH + 4 * i + (lane >> 4) < m) v[e] = fe_max2(v[e], acc[i][j][e]);
                     }
+                    BESTL[512 * j] = fe_max2(BESTL[512 * j], fe_rows_max4(v[0], v[1], v[2], v[3]));
+                }
+                FE_TACC(fe_t_epi);
             };
             third(std::integral_constant<int, 0>{});
             third(std::integral_constant<int, 1>{});
@@ -932,21 +933,18 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
             // a wave stores whenever it owns at least one column block of this sweep: a tail wave (cbw < ncb <= cbw + 2) was clamped to
             // the LAST three blocks, of which ncb - cbw are its own and the others are re-stored with the values their owners write
             // (same rows, same K order: identical bits).  emb = 800 / 896 / 1024 have such tails in the second sweep.
-            if (cbw < ncb && lane < 16) {
-                int lane_e = lane;                                      // (opaque: or the compiler forms the twelve store / bias addresses
+            if (cbw < ncb) {
+                int lane_e = lane;                                      // (opaque: or the compiler forms the store / bias addresses
                 asm volatile("" : "+v"(lane_e));                        //  before the sweep and keeps them — spilled — across it)
-                const unsigned* bl = BESTL;
+                const float* bl = BESTL;
                 asm volatile("" : "+v"(bl));
+                const int tt = lane_e >> 4, r16e = lane_e & 15;         // this lane's step and column inside a sub-block
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    const float bias = a.msc_b[16 * css[j] + lane_e];
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) {
-                        const float raw = float_from_max_key(bl[(4 * j + tt) * 128]);
-                        if (tt < nemit)
-                            a.pooled[((int64_t)(t0 + tt) * a.b + patch_i) * a.emb + 16 * css[j] + lane_e] =
-                                float_from_max_key(float_max_key(lrelu02(__fadd_rn(__fmul_rn(raw, 0.0625f), bias))));
-                    }
+                    const float bias = a.msc_b[16 * css[j] + r16e];
+                    const float raw = bl[512 * j];
+                    if (tt < nemit)
+                        a.pooled[((int64_t)(t0 + tt) * a.b + patch_i) * a.emb + 16 * css[j] + r16e] = lrelu02(__fadd_rn(__fmul_rn(raw, 0.0625f), bias));
                 }
             }
         }
@@ -956,6 +954,8 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
         unsigned long long* st = reinterpret_cast<unsigned long long*>(a.tap_spikes) + (int64_t)blockIdx.x * 32;
         st[17] = fe_t_emit;
         st[18] = fe_t_mfma;
+        st[28] = fe_t_start;
+        st[29] = fe_t_epi;
         st[19] = __builtin_amdgcn_s_memtime();
     }
 #endif

@@ -48,6 +48,9 @@ def main():
     print("  %-26s %8.0f  (%.1f %%)  = emission %.0f + MFMA rounds %.0f + epilogues etc. %.0f" % (
         "multi_scale_conv", np.median(msc), 100 * np.median(msc) / np.median(total), np.median(s[:, 17]), np.median(s[:, 18]),
         np.median(msc - s[:, 17] - s[:, 18])))
+    if s[:, 28].any() or s[:, 29].any():
+        print("  multi_scale_conv, per patch: starts of the thirds (x0 dump, accumulators, first fragments) %.0f, epilogues of the thirds %.0f"
+              % (np.median(s[:, 28]), np.median(s[:, 29])))
     if s[:, 20].any():      # finer stamps inside fe_knn (ad-hoc diagnostic builds): xyz search at 20.., block-3 search at 24..
         for base, name in ((20, "xyz search"), (24, "L3 search")):
             print("  %s: to end of chunk loop %.0f, keys %.0f" % (name, np.median(s[:, base + 1] - s[:, base]), np.median(s[:, base + 2] - s[:, base + 1])))
