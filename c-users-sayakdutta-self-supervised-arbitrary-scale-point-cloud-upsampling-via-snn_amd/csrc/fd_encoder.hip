@@ -14,15 +14,17 @@
 //
 // What makes that fit.  In eval mode a neuron's input gate is closed from step 1 on (violations are counted),
 // so ALL T spikes of a (point, channel) are a function of its ONE pre-activation x0 at t = 0.  The kernel therefore keeps x0 —
-// 48 x 960 floats: blocks 0-2 in LDS (84 KiB), block 3 in registers (48 per lane) — and regenerates the spikes where they are
+// 48 x 960 floats: blocks 0-2 in LDS (84 KiB), block 3 in registers (the current third of the patch parked in LDS, round 4) — and regenerates the spikes where they are
 // consumed: step-0 spikes as the f32 features of the next block's neighbour search and as the split-f16 operand of its EdgeConv
 // GEMM; all steps as the operand of multi_scale_conv.  That contraction takes the patch in thirds of 16 points with the T steps
 // stacked as ROWS (row = 4 point + step: 64 rows, no padded row at T = 4), every wave 96 of ALL emb columns (96 accumulator
 // registers: one sweep over K per third), K in rounds of 128 columns: per round every thread runs the T-step neuron loop of four
 // (point, channel) elements with the state in registers, writes the spikes into a 32 KiB split-f16 panel and the waves multiply the
 // panel with weight fragments streamed L2 -> registers in fragment order (the fn_edge_chain.hip recipe; v_mfma_f32_16x16x32_f16,
-// pass-major, since round 3).  The max over the points is a running maximum of the raw accumulators in the accumulator layout
-// (bias, LeakyReLU and the order-preserving integer key are monotone: once per result), like the GEMM epilogue it replaces.
+// pass-major, since round 3).  The max over the points is a running maximum of the raw accumulators (bias and LeakyReLU are
+// monotone: once per result), kept in LDS between the thirds, like the GEMM epilogue it replaces.  Round 4: the
+// production instantiation fd_encoder_kernel<false> (T = 4, no spike tap) needs 241 registers and no scratch; block 0's EdgeConv
+// runs on the exact-f32 MFMA.
 //
 // Bit-identical to the per-stage path (tests/test_gpu_parity.py::test_fused_fd_encoder_equals_the_per_stage_path_bit_for_bit):
 // same score chains and tie rule in the neighbour searches, same split-f16 products in the same k order, same neuron arithmetic
@@ -442,12 +444,6 @@ __device__ __forceinline__ float fe_rows_max4(float v0, float v1, float v2, floa
     return fe_max2(__uint_as_float(c[0]), __uint_as_float(c[1]));                   // row g: v[g] over all four rows
 }
 
-__device__ __forceinline__ unsigned fe_group_max(unsigned x) {    // max over the four lane groups' values, in all of them
-    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);       // [g0,g0,g2,g2], [g1,g1,g3,g3]
-    const unsigned m1 = r[0] > r[1] ? r[0] : r[1];
-    const auto q = __builtin_amdgcn_permlane32_swap(m1, m1, false, false);
-    return q[0] > q[1] ? q[0] : q[1];
-}
 
 // ---------------------------------------------------------------------------------------------
 // EdgeConv block L = 1..3 (fd:447-474 at t = 0): neighbour search on the step-0 spikes of block L-1, factored EdgeConv GEMM,
