@@ -958,6 +958,145 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_encoder_kernel(const FdEncArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// multi_scale_conv + max over the points for patches of ANY size (round 4): the second half of fd_encoder_kernel as a kernel of
+// its own, for the per-stage path (patches of more than 48 points — the reference's default is 100, generation.py:68).  Until
+// round 4 that path's neuron kernels wrote the spikes of all T steps as split rows ([T, points, 960]: 6.3 GB at 4000 x 100 points,
+// T = 4; 11 GB at the reference's T = 7) for the big-tile GEMM to read back.  All T spikes of a (point, channel) are a function of
+// its pre-activation x0 (closed gate), so the neuron kernels now write x0 [points, 960] and the step-0 spikes only, and this
+// kernel regenerates every step where it is consumed: one workgroup per patch, the patch in tiles of 16 points with the 4 steps of
+// a group stacked as rows (64 rows), every wave 96 of all emb columns, K in rounds of 128 columns — fd_encoder_kernel's scheme,
+// with x0 read from global memory (L2: the neuron kernels have just written it) one round ahead instead of from LDS.  Same
+// split-f16 products in the same order, same neuron arithmetic, same maximum: bit-identical to the T-slab path
+// (tests: test_fd_x0_path_equals_the_spike_slab_path_bit_for_bit).  LDS: the 32 KiB panel + 12 KiB of running maxima.
+// ---------------------------------------------------------------------------------------------
+constexpr int FM_OFF_BEST = 32768;
+constexpr int FM_LDS = FM_OFF_BEST + 6 * 4 * 8 * 16 * 4;
+
+template <bool GENERAL>
+__global__ __launch_bounds__(FE_NT, 1) void fd_msc_kernel(const FdMscArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char* R2 = smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = a.m;
+    const int64_t patch_i = blockIdx.x;
+    const float* __restrict__ xp = a.x0 + patch_i * m * 960;
+    const int cw = w & 1, rg = w >> 1;
+    const int nsweep = a.emb / 768 + (a.emb % 768 ? 1 : 0);
+    const int ntile = (m + 15) >> 4;
+    const half8* __restrict__ mscw = reinterpret_cast<const half8*>(a.msc_wp);
+    const int64_t tap_tstride = a.b_total * (int64_t)m * 960;
+    unsigned char* pe[4];                                   // panel addresses: point 4 rg + e of the tile (row 4 point), column 64 cw + lane
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pe[e] = R2 + fe_panel_off<FE_PR>(4 * (4 * rg + e), 64 * cw + lane);
+    float* BESTL = reinterpret_cast<float*>(smem + FM_OFF_BEST) + (lane >> 4) * 128 + w * 16 + (lane & 15);   // (j, step = this lane's row): BESTL[512 j]
+    for (int sweep = 0; sweep < nsweep; ++sweep) {
+        const int ncb = a.emb / 32;
+        const int cbw = sweep * 24 + 3 * w;
+        const int cb0 = cbw + 2 < ncb ? cbw : (ncb >= 3 ? ncb - 3 : 0);
+        const int css[6] = {2 * cb0, 2 * cb0 + 1, 2 * cb0 + 2, 2 * cb0 + 3, 2 * cb0 + 4, 2 * cb0 + 5};
+        for (int t0 = 0; t0 < a.T; t0 += 4) {
+            const int nemit = a.T - t0 < 4 ? a.T - t0 : 4;
+            const bool count = sweep == 0 && t0 + nemit == a.T;        // the gate check runs once, over all T steps
+            float* tap = (GENERAL && a.tap_spikes && sweep == 0) ? a.tap_spikes + (a.s0 + patch_i) * (int64_t)m * 960 : nullptr;
+            const bool fast = !GENERAL || (t0 == 0 && nemit == 4 && tap == nullptr);         // (workgroup-uniform)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) BESTL[512 * j] = -__builtin_huge_valf();
+#pragma unroll 1
+            for (int tile = 0; tile < ntile; ++tile) {
+                const int pt0 = 16 * tile + 4 * rg;                     // this thread's first point; rows beyond the patch: the last point
+                const float* xr[4];                                     // (emitted like any other, never looked at: masked in the maximum)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xr[e] = xp + (int64_t)(pt0 + e < m ? pt0 + e : m - 1) * 960 + lane;
+                f32x4 acc[4][6];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                half8 Wh[6], Wl[6];                                     // (203 registers without x0 in them: room for the whole k32 step)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    Wh[j] = fe_wfrag(mscw, 30, css[j], 0, 0, lane);
+                    Wl[j] = fe_wfrag(mscw, 30, css[j], 0, 1, lane);
+                }
+                FeNP pnext = fe_load_np(a.nprm, 64 * cw + lane);         // a chunk's neuron parameters and x0 values: one round ahead
+                float xn[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xn[e] = xr[e][64 * cw];
+#pragma unroll 1
+                for (int R = 0; R < 8; ++R) {
+                    const int ch = 2 * R + cw;                          // this wave's chunk (15 = none: round 7, odd waves)
+                    const int c = 64 * ch + lane;
+                    const NeuronP p = fe_np(pnext);
+                    float x[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = xn[e];
+                    const int chn = ch + 2 < 15 ? ch + 2 : (ch < 15 ? ch : 14);     // (the last rounds re-load their own chunk: unconditional loads)
+                    pnext = fe_load_np(a.nprm, 64 * chn + lane);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xn[e] = xr[e][64 * chn];
+                    float* tp = tap ? tap + c : nullptr;
+                    if (ch < 15) {
+                        if (ch < 3) {                                   // blocks 0, 1: EIF (wave-uniform branches)
+                            if (fast) fe_emit4<1, true>(x, p, 0, 4, pe, pt0, m, count, a.gate, nullptr, 0);
+                            else if (GENERAL) fe_emit4<1, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
+                        } else {                                        // blocks 2, 3: LIF
+                            if (fast) fe_emit4<2, true>(x, p, 0, 4, pe, pt0, m, count, a.gate, nullptr, 0);
+                            else if (GENERAL) fe_emit4<2, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
+                        }
+                    }
+                    lds_barrier();
+                    fe_gemm16<6, 4, 2, false>(R2, FE_PR * 64, mscw, 30, css, lane, acc, 0, 4 * R, R < 7 ? 4 : 2, 30, &Wh, &Wl);
+                    lds_barrier();
+                }
+                const bool allv = 16 * (tile + 1) <= m;                 // (workgroup-uniform: every point of this tile exists)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = -__builtin_huge_valf();
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (allv || 16 * tile + 4 * i + (lane >> 4) < m) v[e] = fe_max2(v[e], acc[i][j][e]);
+                    }
+                    BESTL[512 * j] = fe_max2(BESTL[512 * j], fe_rows_max4(v[0], v[1], v[2], v[3]));
+                }
+            }
+            if (cbw < ncb) {
+                int lane_e = lane;
+                asm volatile("" : "+v"(lane_e));
+                const float* bl = BESTL;
+                asm volatile("" : "+v"(bl));
+                const int tt = lane_e >> 4, r16e = lane_e & 15;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const float bias = a.msc_b[16 * css[j] + r16e];
+                    const float raw = bl[512 * j];
+                    if (tt < nemit)
+                        a.pooled[((int64_t)(t0 + tt) * a.b + patch_i) * a.emb + 16 * css[j] + r16e] = lrelu02(__fadd_rn(__fmul_rn(raw, 0.0625f), bias));
+                }
+            }
+        }
+    }
+}
+
+bool fd_msc_ok(int m, int emb, int T) { return m >= 1 && emb % 32 == 0 && emb >= 96 && T >= 1; }
+
+int launch_fd_msc(const FdMscArgs& a, hipStream_t st) {
+    if (a.b == 0) return SAPCU_OK;
+    SAPCU_CHECK_ARG(fd_msc_ok(a.m, a.emb, a.T) && a.b < 0x7fffffffLL && a.x0 && a.msc_wp && a.msc_b && a.nprm && a.pooled && a.gate,
+                    "fd_msc: unsupported shape or null operand (m=%d emb=%d T=%d)", a.m, a.emb, a.T);
+    if (a.T == 4 && a.tap_spikes == nullptr) {
+        hipLaunchKernelGGL(fd_msc_kernel<false>, dim3((unsigned)a.b), dim3(FE_NT), FM_LDS, st, a);
+    } else {
+        hipLaunchKernelGGL(fd_msc_kernel<true>, dim3((unsigned)a.b), dim3(FE_NT), FM_LDS, st, a);
+    }
+    SAPCU_CHECK_LAUNCH();
+    return SAPCU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // model-build helpers: weights in fragment order, clamped neuron parameters
 // ---------------------------------------------------------------------------------------------
 // out[((cs * nk32 + s) * 2 + plane) * 64 + lane][j] = w16_plane[16 cs + (lane & 15)][32 s + 8 (lane >> 4) + j],  w [n, k] row-major

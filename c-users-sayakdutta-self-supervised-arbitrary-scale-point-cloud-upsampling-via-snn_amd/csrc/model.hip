@@ -98,6 +98,7 @@ struct sapcu_model {
     bool opt_fd_maxfuse;       // SAPCU_FD_MAXFUSE=0: multi_scale_conv GEMM + rowgroup_max
     bool opt_fd_split;         // SAPCU_FD_SPLIT=0: fd spikes as f32 rows for every step
     bool opt_fd_fused;         // SAPCU_FD_FUSED=0: fd encoder on the per-stage kernels (through HBM) instead of fd_encoder.hip
+    bool opt_fd_x0;            // SAPCU_FD_X0=0: the per-stage path writes T spike slabs for the big-tile GEMM instead of x0 for fd_msc_kernel
     // fd, fused encoder (fd_encoder.hip): scale_fusion | EdgeConv 1-3 | multi_scale_conv in MFMA-fragment order, clamped neuron
     // parameters of the 960 encoder channels
     void* fde_w;
@@ -423,6 +424,7 @@ struct FdPlan {
     int64_t cb;
     int kmax0, kk;
     bool fused;                // the whole encoder in fd_encoder.hip: no per-point intermediates in the workspace
+    bool x0path;               // per-stage front + fd_msc_kernel: x0 [P, 960] and ONE spike slab instead of T slabs (round 4)
     bool maxfuse;              // multi_scale_conv's max over points inside the GEMM: the [T*P, emb] aggregate is never written
     int64_t agg_rows(int mp) const { return maxfuse ? 1 : mp; }   // rows of the AGG area per (step, patch): keys only, or the aggregate
 };
@@ -432,9 +434,17 @@ static bool fd_encoder_fused(const sapcu_model* m, int mp) {
     return m->sf16 && m->opt_fd_fused && m->fde_w && m->fde_nprm && fd_encoder_ok(mp, m->nscale, m->emb, m->T);
 }
 
+// does the per-stage path hand x0 to fd_msc_kernel (multi_scale_conv with the spikes regenerated on the CU) instead of writing the
+// spikes of all T steps for the big-tile GEMM?  Patches of more than 48 points (the reference's default is 100), every T.
+static bool fd_x0_path(const sapcu_model* m, int mp) {
+    return !fd_encoder_fused(m, mp) && m->sf16 && m->opt_fd_fused && m->opt_fd_x0 && m->opt_fd_maxfuse && m->opt_fd_split && m->fde_w &&
+           m->fde_nprm && fd_msc_ok(mp, m->emb, m->T);
+}
+
 static FdPlan fd_plan(const sapcu_model* m, int64_t b, int mp) {
     FdPlan pl;
     pl.fused = fd_encoder_fused(m, mp);
+    pl.x0path = fd_x0_path(m, mp);
     pl.maxfuse = m->sf16 && m->opt_fd_maxfuse;
     if (pl.fused) {
         // the encoder's intermediates never leave the CU: per patch only pooled [T, emb], the encoding and the decoder's rows
@@ -450,7 +460,8 @@ static FdPlan fd_plan(const sapcu_model* m, int64_t b, int mp) {
     // 1024 + block-0 features per point, neighbour tables
     int kmax0 = 1;
     for (int i = 0; i < m->nscale; ++i) kmax0 = kmax0 > m->ks[i] ? kmax0 : m->ks[i];
-    const int64_t per_patch = (int64_t)mp * (((int64_t)m->T * 960 + 960 + 1024 + 64 * (m->nscale + 1)) * 4 +
+    const int64_t slabs = pl.x0path ? 2 : m->T;        // x0 path: the step-0 spike slab (split rows) + x0, whatever T
+    const int64_t per_patch = (int64_t)mp * ((slabs * 960 + 960 + 1024 + 64 * (m->nscale + 1)) * 4 +
                                             (int64_t)(imin(kmax0, mp) + 3 * imin(m->k, mp)) * 4) +
                               (int64_t)m->T * pl.agg_rows(mp) * m->emb * 4 +
                               ((int64_t)(m->T + 1) * m->emb + 256 + 3 * 128 + 3 * 64 + 192 + 64) * 4;
@@ -470,7 +481,8 @@ static int64_t fd_ws_bytes(const sapcu_model* m, int64_t b, int mp) {
     if (!pl.fused) {
         add(P * pl.kmax0, 4); add(3 * P * pl.kk, 4);
         add(P * 64 * m->nscale, 4); add(P * 64, 4);
-        add((int64_t)m->T * P * 960, 4); add(P * 960, 4); add(P * 1024, 4); add((int64_t)m->T * pl.cb * pl.agg_rows(mp) * m->emb, 4);
+        add((pl.x0path ? 1 : (int64_t)m->T) * P * 960, 4); add(P * 960, 4); add(P * 1024, 4); add((int64_t)m->T * pl.cb * pl.agg_rows(mp) * m->emb, 4);
+        if (pl.x0path) add(P * 960, 4);
     }
     add((int64_t)m->T * pl.cb * m->emb, 4); add(pl.cb * m->emb, 4);
     add(pl.cb * 256, 4);
@@ -499,10 +511,11 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
         int32_t* idxb = A.take<int32_t>(pp * 3 * pl.cb * mp * pl.kk);
         float* E0 = A.take<float>(pp * pl.cb * mp * 64 * m->nscale);
         float* FUSED = A.take<float>(pp * pl.cb * mp * 64);
-        float* SPK = A.take<float>(pp * (int64_t)T * pl.cb * mp * 960);
+        float* SPK = A.take<float>(pp * (pl.x0path ? 1 : (int64_t)T) * pl.cb * mp * 960);
         float* F0 = A.take<float>(pp * pl.cb * mp * 960);
         float* AB = A.take<float>(pp * pl.cb * mp * 1024);
         float* AGG = A.take<float>(pp * (int64_t)T * pl.cb * pl.agg_rows(mp) * emb);       // maxfuse: T*cb*emb keys only
+        float* X0 = A.take<float>(pl.x0path ? pl.cb * mp * 960 : 0);                       // x0 path: [P, 960] pre-activations
         float* POOLED = A.take<float>((int64_t)T * pl.cb * emb);
         float* ENC = A.take<float>(pl.cb * emb);
         float* D1 = A.take<float>(pl.cb * 256);
@@ -559,8 +572,8 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
         mg.a = SPK; mg.r = (int64_t)T * P; mg.k = 960; mg.lda = 960; mg.w = m->p(FD_MSC_W); mg.n = emb; mg.bias = m->p(FD_MSC_B);
         mg.c = nullptr; mg.ldc = emb; mg.epi = EPI_LRELU_MAX; mg.max_keys = reinterpret_cast<unsigned*>(AGG); mg.max_m = mp;
         const bool maxfuse = pl.maxfuse;
-        bool split_spikes = false;
-        if (maxfuse && m->opt_fd_split && !(taps && taps[SAPCU_FD_TAP_SPIKES])) {
+        bool split_spikes = pl.x0path;                          // x0 path: ONE slab of step-0 split rows (the EdgeConv GEMMs' operand)
+        if (!pl.x0path && maxfuse && m->opt_fd_split && !(taps && taps[SAPCU_FD_TAP_SPIKES])) {
             GemmArgs probe = mg;
             probe.a_split = 1;
             probe.w16_hi = (const _Float16*)m->w16_hi + (mg.w - m->blob);
@@ -569,8 +582,9 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
         }
         float* const SPKS = split_spikes ? SPK : nullptr;       // [T*P, 960] split rows (same buffer, other format)
         float* const SPK0 = split_spikes ? F0 : SPK;            // where the step-0 f32 spikes live ([P, 960] slab)
+        float* const X0P = pl.x0path ? X0 : nullptr;            // the neuron kernels then write x0 and run step 0 only
         SAPCU_TRY(launch_fd_neuron(true, 0, FUSED, 64, nullptr, 0, mp, nullptr, P, 64, m->p(FD_SNN0), T, SPK0, 960, 0,
-                                   nullptr, m->gate_dev, st, SPKS));
+                                   nullptr, m->gate_dev, st, SPKS, X0P));
         // blocks 1..3: feature-space kNN on the t=0 spikes, factored EdgeConv, neuron  fd:447-474
         for (int l = 1; l <= 3; ++l) {
             int32_t* idl = idxb + (int64_t)(l - 1) * pl.cb * mp * pl.kk;
@@ -593,9 +607,19 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
             else
                 SAPCU_TRY(gemm(m, F, P, cin[l], 960, m->p(ew), 2 * cout[l], nullptr, AB, 2 * cout[l], EPI_BIAS, st));
             SAPCU_TRY(launch_fd_neuron(l == 1, 1, AB, 2 * cout[l], idl, pl.kk, mp, m->p(ew + 1), P, cout[l], m->p(ew + 2),
-                                       T, SPK0, 960, coff[l], nullptr, m->gate_dev, st, SPKS));
-            if (X0T) SAPCU_TRY(launch_fd_pre(AB, 2 * cout[l], idl, pl.kk, mp, m->p(ew + 1), P, cout[l], X0T, 960, coff[l], st));
+                                       T, SPK0, 960, coff[l], nullptr, m->gate_dev, st, SPKS, X0P));
+            if (X0T && !pl.x0path) SAPCU_TRY(launch_fd_pre(AB, 2 * cout[l], idl, pl.kk, mp, m->p(ew + 1), P, cout[l], X0T, 960, coff[l], st));
         }
+        if (pl.x0path) {
+            // multi_scale_conv over all T steps + max over the points straight from x0: every spike regenerated on the CU (fd_msc_kernel)
+            if (X0T) SAPCU_CHECK_HIP(hipMemcpyAsync(X0T, X0, (size_t)P * 960 * 4, hipMemcpyDeviceToDevice, st));
+            FdMscArgs ma;
+            memset(&ma, 0, sizeof(ma));
+            ma.x0 = X0; ma.b = cb; ma.b_total = b; ma.s0 = s; ma.m = mp; ma.T = T; ma.emb = emb;
+            ma.msc_wp = (const _Float16*)m->fde_w + m->fde_off[4]; ma.msc_b = m->p(FD_MSC_B); ma.nprm = m->fde_nprm;
+            ma.pooled = POOLED; ma.tap_spikes = taps ? (float*)taps[SAPCU_FD_TAP_SPIKES] : nullptr; ma.gate = m->gate_dev;
+            SAPCU_TRY(launch_fd_msc(ma, st));
+        } else {
         if (taps && taps[SAPCU_FD_TAP_SPIKES]) {
             for (int t = 0; t < T; ++t)
                 SAPCU_CHECK_HIP(hipMemcpyAsync((float*)taps[SAPCU_FD_TAP_SPIKES] + ((int64_t)t * b + s) * mp * 960,
@@ -613,6 +637,7 @@ static int fd_forward(const sapcu_model* m, const float* patch, int64_t b, int m
             SAPCU_TRY(gemm(m, SPK, (int64_t)T * P, 960, 960, m->p(FD_MSC_W), emb, m->p(FD_MSC_B), AGG, emb, EPI_LRELU, st));
             SAPCU_TRY(launch_rowgroup_max(AGG, (int64_t)T * cb, mp, emb, POOLED, st));
         }
+        }   // T spike slabs + GEMM
         }   // per-stage encoder
         if (taps && taps[SAPCU_FD_TAP_POOLED]) {
             for (int t = 0; t < T; ++t)
@@ -869,6 +894,7 @@ int sapcu_model_create(int kind, const int32_t* hp, int n_hp, const float* blob,
     m->opt_fd_maxfuse = !env_off("SAPCU_FD_MAXFUSE");
     m->opt_fd_split = !env_off("SAPCU_FD_SPLIT");
     m->opt_fd_fused = !env_off("SAPCU_FD_FUSED");
+    m->opt_fd_x0 = !env_off("SAPCU_FD_X0");
     const char* ce = getenv("SAPCU_CHUNK");
     m->chunk = ce ? atoll(ce) : 0;
     if (m->chunk < 0) m->chunk = 0;
@@ -1049,8 +1075,9 @@ int sapcu_model_fused_blocks(sapcu_model_t m, int m_pts, int* mask_host) {
     if (m->kind == SAPCU_KIND_FN) {
         for (int l = 0; l < 3; ++l)
             if (fn_block_fused(m, l, m_pts)) mask |= 1 << l;
-    } else if (fd_encoder_fused(m, m_pts)) {
-        mask = 1;
+    } else {
+        if (fd_encoder_fused(m, m_pts)) mask = 1;
+        else if (fd_x0_path(m, m_pts)) mask = 2;
     }
     *mask_host = mask;
     return SAPCU_OK;

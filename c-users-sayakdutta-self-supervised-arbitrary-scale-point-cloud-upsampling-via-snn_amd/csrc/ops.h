@@ -60,7 +60,8 @@ int launch_fd_edge0(const float* patch, const int32_t* idx, int kmax, int64_t pt
                     const int32_t* ks_dev, const float* w, const float* bias, float* out, hipStream_t st);
 int launch_fd_neuron(bool eif, int mode, const float* in, int ldi, const int32_t* idx, int kk, int m,
                      const float* shift, int64_t pts, int C, const float* prm, int T, float* spk, int ldo, int coff,
-                     float* pre_out, int* gate_violations, hipStream_t st, float* spk_split = nullptr);   // spk_split: see fd_neuron_kernel
+                     float* pre_out, int* gate_violations, hipStream_t st, float* spk_split = nullptr,    // spk_split: see fd_neuron_kernel
+                     float* x0_out = nullptr);            // x0_out [pts, ldo]: pre-activations out, step 0 only (the x0 path, fd_msc_kernel)
 // fused fd encoder (fd_encoder.hip)
 typedef _Float16 fe_half8 __attribute__((ext_vector_type(8)));
 struct FdEncArgs {
@@ -87,6 +88,22 @@ struct FdEncArgs {
     int* gate;                   // refractory gate found open at t >= 1 (must stay 0)
     int* ovf;                    // a block-0 EdgeConv value beyond the f16 range of the split operand
 };
+// multi_scale_conv + max over the points from the pre-activations x0 [points, 960] (fd_msc_kernel, fd_encoder.hip): the per-stage
+// path's replacement for "T spike slabs through HBM + big-tile GEMM", any patch size
+struct FdMscArgs {
+    const float* x0;             // [b * m, 960] neuron inputs at t = 0 of the four blocks (what SAPCU_FD_TAP_X0 shows)
+    int64_t b;                   // patches of this launch (pooled is [T, b, emb])
+    int64_t b_total, s0;         // the forward's batch and this launch's first patch in it (spike tap indexing)
+    int m, T, emb;
+    const _Float16* msc_wp;      // multi_scale_conv [emb, 960] in fragment order
+    const float* msc_b;
+    const float* nprm;           // [960][8] clamped neuron parameters
+    float* pooled;               // [T, b, emb]
+    float* tap_spikes;           // [T, b_total, m, 960] or null
+    int* gate;
+};
+bool fd_msc_ok(int m, int emb, int T);
+int launch_fd_msc(const FdMscArgs& a, hipStream_t st);
 bool fd_encoder_ok(int m, int nscale, int emb, int T);
 int launch_fd_encoder(const FdEncArgs& a, hipStream_t st);
 int launch_pack_frag_weights(const void* w16_hi, const void* w16_lo, int n, int k, void* out, hipStream_t st);

@@ -966,7 +966,8 @@ __global__ __launch_bounds__(256) void fd_neuron_kernel(const float* __restrict_
                                                         const float* __restrict__ shift, int64_t pts, int C,
                                                         const float* __restrict__ prm, int T, float* __restrict__ spk,
                                                         int ldo, int coff, float* __restrict__ pre_out,
-                                                        int* __restrict__ gate_violations, float* __restrict__ spk_split) {
+                                                        int* __restrict__ gate_violations, float* __restrict__ spk_split,
+                                                        float* __restrict__ x0_out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= pts * C) return;
     const int c = (int)(t % C);
@@ -987,6 +988,12 @@ __global__ __launch_bounds__(256) void fd_neuron_kernel(const float* __restrict_
     // fd_edge_neuron_kernel and of the fused encoder (fd_encoder.hip) — the three must agree bit for bit.  (Round 4: until then
     // this kernel — block 0's stage — ran neuron_step<EIF>, the scalar form with an IEEE division per EIF step.)
     NeuronStep2<EIF> n(p);
+    // x0_out (round 4, the x0 path): the pre-activation goes out as x0 [pts, ldo] and only step 0 is run here — fd_msc_kernel
+    // regenerates every step from x0 (and checks the gate); spk / spk_split then hold the step-0 slab alone
+    if (x0_out) {
+        x0_out[row * ldo + coff + c] = pre;
+        T = 1;
+    }
     for (int step = 0; step < T; ++step) {
         if (step > 0 && n.gate_open()) atomicAdd(gate_violations, 1);
         const float sp = n.step(step == 0 ? f32x2{pre, pre} : f32x2{0.f, 0.f}, step == 0).x;
@@ -1016,7 +1023,8 @@ __global__ __launch_bounds__(256) void fd_edge_neuron_kernel(const float* __rest
                                                                 const float* __restrict__ shift, int64_t pts, int C,
                                                                 const float* __restrict__ prm, int T,
                                                                 float* __restrict__ spk, int ldo, int coff,
-                                                                int* __restrict__ gate_violations, float* __restrict__ spk_split) {
+                                                                int* __restrict__ gate_violations, float* __restrict__ spk_split,
+                                                                float* __restrict__ x0_out) {
     extern __shared__ float sA[];                       // [m][FDE_CH] f32, then the neighbour table [m][kk] as bytes
     unsigned char* sI = reinterpret_cast<unsigned char*>(sA + (size_t)m * FDE_CH);
     const int tid = threadIdx.x;
@@ -1065,7 +1073,12 @@ __global__ __launch_bounds__(256) void fd_edge_neuron_kernel(const float* __rest
         const f32x2 pre0 = f32x2{lrelu02(__fadd_rn(__fsub_rn(mx.x, xb.x), sh.x)), lrelu02(__fadd_rn(__fsub_rn(mx.y, xb.y), sh.y))};
         const f32x2 pre1 = f32x2{lrelu02(__fadd_rn(__fsub_rn(mx.z, xb.z), sh.z)), lrelu02(__fadd_rn(__fsub_rn(mx.w, xb.w), sh.w))};
         NeuronStep2V<EIF> n0(p[0], p[1]), n1(p[2], p[3]);
-        for (int step = 0; step < T; ++step) {
+        int nstep = T;
+        if (x0_out) {                                    // (see fd_neuron_kernel: x0 out, step 0 only)
+            *reinterpret_cast<float4*>(x0_out + r * ldo + coff + c) = make_float4(pre0.x, pre0.y, pre1.x, pre1.y);
+            nstep = 1;
+        }
+        for (int step = 0; step < nstep; ++step) {
             if (step > 0 && (n0.gate_open() || n1.gate_open())) atomicAdd(gate_violations, 1);
             const f32x2 z = f32x2{0.f, 0.f};
             const f32x2 s0 = n0.step(step == 0 ? pre0 : z, step == 0), s1 = n1.step(step == 0 ? pre1 : z, step == 0);
@@ -1106,11 +1119,11 @@ int launch_fd_pre(const float* in, int ldi, const int32_t* idx, int kk, int m, c
 
 int launch_fd_neuron(bool eif, int mode, const float* in, int ldi, const int32_t* idx, int kk, int m,
                      const float* shift, int64_t pts, int C, const float* prm, int T, float* spk, int ldo, int coff,
-                     float* pre_out, int* gate_violations, hipStream_t st, float* spk_split) {
+                     float* pre_out, int* gate_violations, hipStream_t st, float* spk_split, float* x0_out) {
     if (pts == 0) return SAPCU_OK;
     // the 16-byte form needs 4-aligned channel geometry (every tensor of the models has it) and byte-sized neighbour indices
     if (mode == 1 && pre_out == nullptr && pts % m == 0 && C % 4 == 0 && ldi % 4 == 0 && ldo % 32 == 0 && coff % 4 == 0 && m <= 256 &&
-        (((uintptr_t)in | (uintptr_t)spk | (uintptr_t)shift) & 15) == 0) {
+        (((uintptr_t)in | (uintptr_t)spk | (uintptr_t)shift | (uintptr_t)x0_out) & 15) == 0) {
         const dim3 g2((unsigned)(pts / m), (unsigned)((C + FDE_CH - 1) / FDE_CH));
         const size_t lds = (size_t)m * FDE_CH * sizeof(float) + (((size_t)m * kk + 15) & ~(size_t)15);
         // patches of 121..256 points: the tile + the byte table pass the default 64 KiB dynamic-LDS limit (m = 128, kk = 32: 68 KiB;
@@ -1120,12 +1133,12 @@ int launch_fd_neuron(bool eif, int mode, const float* in, int ldi, const int32_t
                 static DeviceOnce once;
                 if (lds > 65536) SAPCU_SET_MAX_LDS(once, (&fd_edge_neuron_kernel<true>), 160 * 1024);
                 hipLaunchKernelGGL(fd_edge_neuron_kernel<true>, g2, dim3(256), lds, st, in, ldi, idx, kk, m, shift, pts, C, prm,
-                                   T, spk, ldo, coff, gate_violations, spk_split);
+                                   T, spk, ldo, coff, gate_violations, spk_split, x0_out);
             } else {
                 static DeviceOnce once;
                 if (lds > 65536) SAPCU_SET_MAX_LDS(once, (&fd_edge_neuron_kernel<false>), 160 * 1024);
                 hipLaunchKernelGGL(fd_edge_neuron_kernel<false>, g2, dim3(256), lds, st, in, ldi, idx, kk, m, shift, pts, C,
-                                   prm, T, spk, ldo, coff, gate_violations, spk_split);
+                                   prm, T, spk, ldo, coff, gate_violations, spk_split, x0_out);
             }
             SAPCU_CHECK_LAUNCH();
             return SAPCU_OK;
@@ -1134,7 +1147,7 @@ int launch_fd_neuron(bool eif, int mode, const float* in, int ldi, const int32_t
     const dim3 grid((unsigned)((pts * C + 255) / 256)), blk(256);
 #define SAPCU_FDN(E, M)                                                                                            \
     hipLaunchKernelGGL((fd_neuron_kernel<E, M>), grid, blk, 0, st, in, ldi, idx, kk, m, shift, pts, C, prm, T, spk, \
-                       ldo, coff, pre_out, gate_violations, spk_split)
+                       ldo, coff, pre_out, gate_violations, spk_split, x0_out)
     if (eif && mode == 0) SAPCU_FDN(true, 0);
     else if (eif) SAPCU_FDN(true, 1);
     else if (mode == 0) SAPCU_FDN(false, 0);

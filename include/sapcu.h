@@ -278,9 +278,12 @@ int sapcu_model_gemm_mode(sapcu_model_t m, int* split_f16_host, int* range_overf
 
 /* Which stages of the handle run as fused LDS-resident kernels for patches of m_pts points (no device work):
  * fn: bit l (0..2) of *mask_host set = transformer block l+1 runs csrc/fn_edge_chain.hip (else the five-kernel chain);
- * fd: bit 0 set = the encoder (blocks 0-3 + multi_scale_conv) runs csrc/fd_encoder.hip (else the per-stage kernels through HBM).
+ * fd: bit 0 set = the encoder (blocks 0-3 + multi_scale_conv) runs csrc/fd_encoder.hip (patches of <= 48 points); bit 1 set = the
+ *     per-stage kernels hand the pre-activations x0 to fd_msc_kernel (multi_scale_conv with the spikes of all T steps regenerated
+ *     on the CU: larger patches, e.g. the reference's default of 100 points) instead of writing T spike slabs for a GEMM; neither:
+ *     the per-stage kernels through HBM.
  * The choice depends on the hyper-parameters, on m_pts and on the switches read at sapcu_model_create (SAPCU_CHAIN=0,
- * SAPCU_FD_FUSED=0, SAPCU_GEMM=f32 disable them); it changes speed and workspace size, not results. */
+ * SAPCU_FD_FUSED=0, SAPCU_FD_X0=0, SAPCU_GEMM=f32 disable them); it changes speed and workspace size, not results. */
 int sapcu_model_fused_blocks(sapcu_model_t m, int m_pts, int* mask_host);
 
 /* out = in / max(||in||_2, 1e-12) row-wise for [b,3] — the extra F.normalize of generation.py:139. */

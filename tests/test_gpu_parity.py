@@ -1820,7 +1820,7 @@ def test_fused_fd_encoder_equals_the_per_stage_path_bit_for_bit(weights, monkeyp
     over = {"time_steps_enc": T}
     _, fd, _, _ = U.build_gpu_models_under(weights, monkeypatch, {"SAPCU_FD_FUSED": "1"}, None, over)
     _, fd_stage, _, _ = U.build_gpu_models_under(weights, monkeypatch, {"SAPCU_FD_FUSED": "0"}, None, over)
-    assert fd.fused_blocks(48) == 1 and fd.fused_blocks(5) == 1 and fd.fused_blocks(100) == 0 and fd_stage.fused_blocks(48) == 0
+    assert fd.fused_blocks(48) == 1 and fd.fused_blocks(5) == 1 and fd.fused_blocks(100) == 2 and fd_stage.fused_blocks(48) == 0 and fd_stage.fused_blocks(100) == 0
     for nq, mpts in ((64, 48), (37, 48), (1, 48), (9, 20), (70, 5), (5, 12), (3, 33)):
         patch = U.sphere_patches(nq, mpts, skip=1700).to(U.dev())
         kk = min(32, mpts)
@@ -1897,6 +1897,47 @@ def test_fd_forward_on_patches_of_128_points(models):
         assert float((fn(patch.to(U.dev())).cpu() - n_ref).abs().max()) <= TOL
     finally:
         fn.knn_cache_mode = mode
+
+
+@pytest.mark.parametrize("T", [4, 7])
+def test_fd_x0_path_equals_the_spike_slab_path_bit_for_bit(weights, monkeypatch, T):
+    """Round 4, patches of more than 48 points (the reference's default is 100, generation.py:68; config/fd.yaml runs T = 7): the
+    per-stage kernels write the pre-activations x0 [points, 960] and the step-0 spikes only, and fd_msc_kernel (csrc/fd_encoder.hip)
+    regenerates the spikes of all T steps on the CU for multi_scale_conv + the max over the points — instead of T spike slabs
+    through HBM and the big-tile GEMM (handles created under SAPCU_FD_X0=0) or the whole old per-stage path (SAPCU_FD_FUSED=0).
+    Every tap — scale fusion, neighbour tables, x0, every spike of every step, pooled, encoding — and the distances must agree
+    BIT FOR BIT: 100, 128, 64, 49 and 77 points, one patch, T = 4 (two kernels: production / general) and the reference's T = 7
+    (two groups of steps), with and without taps, free-running and under forced tables."""
+    over = {"time_steps_enc": T}
+    _, fd, _, sdd = U.build_gpu_models_under(weights, monkeypatch, {}, None, over)
+    _, fd_slab, _, _ = U.build_gpu_models_under(weights, monkeypatch, {"SAPCU_FD_X0": "0"}, None, over)
+    _, fd_stage, _, _ = U.build_gpu_models_under(weights, monkeypatch, {"SAPCU_FD_FUSED": "0"}, None, over)
+    assert fd.fused_blocks(100) == 2 and fd.fused_blocks(49) == 2 and fd.fused_blocks(48) == 1
+    assert fd_slab.fused_blocks(100) == 0 and fd_slab.fused_blocks(48) == 1 and fd_stage.fused_blocks(100) == 0
+    for nq, mpts in ((9, 100), (3, 128), (5, 64), (1, 49), (4, 77)):
+        patch = U.sphere_patches(nq, mpts, skip=2500).to(U.dev())
+        kk = min(32, mpts)
+        ta, tb = _fd_taps(nq, mpts, T, kk), _fd_taps(nq, mpts, T, kk)
+        ta["x0"], tb["x0"] = torch.full((nq, mpts, 960), float("nan"), device=U.dev()), torch.full((nq, mpts, 960), float("nan"), device=U.dev())
+        da, db = fd(patch, taps=ta), fd_slab(patch, taps=tb)
+        torch.cuda.synchronize()
+        tag = "nq=%d m=%d T=%d" % (nq, mpts, T)
+        assert torch.equal(ta["fused0"], tb["fused0"]) and torch.equal(ta["knn"], tb["knn"]), tag
+        assert not bool(torch.isnan(ta["x0"]).any()) and torch.equal(ta["x0"], tb["x0"]), tag + ": x0"
+        for t in range(T):
+            assert not bool(torch.isnan(ta["spikes"][t]).any()), tag + ": step %d spikes not written" % t
+            assert torch.equal(ta["spikes"][t], tb["spikes"][t]), tag + ": step %d spikes (max diff %g)" % (t, float((ta["spikes"][t] - tb["spikes"][t]).abs().max()))
+        assert torch.equal(ta["pooled"], tb["pooled"]), tag + ": pooled (max diff %g)" % float((ta["pooled"] - tb["pooled"]).abs().max())
+        assert torch.equal(ta["enc"], tb["enc"]) and torch.equal(da, db), tag
+        assert torch.equal(fd(patch), da), tag + ": tap-free call (production kernel at T = 4)"
+        assert torch.equal(fd_slab(patch), da), tag + ": tap-free call, slab path"
+        assert torch.equal(fd_stage(patch, knn_force=ta["knn"]), da), tag + ": old per-stage path"
+        assert torch.equal(fd(patch, knn_force=ta["knn"]), da), tag + ": forced tables"
+    # against the oracle on the device's tables (1e-4), at the reference's default patch size
+    patch = U.sphere_patches(6, 100, skip=2600)
+    d_gpu, d_forced, _, _, _ = U.fd_forward_forced(fd, sdd, patch, dict(U.FD_HP, time_steps_enc=T))
+    assert float((d_gpu - d_forced).abs().max()) <= TOL
+    assert fd.gate_violations() == 0 and fd_slab.gate_violations() == 0 and fd_stage.gate_violations() == 0
 
 
 def test_exact_operation_order_build():
