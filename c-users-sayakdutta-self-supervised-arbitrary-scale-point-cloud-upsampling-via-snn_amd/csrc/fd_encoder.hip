@@ -146,7 +146,8 @@ template <int NCS, int NRS, int RH = 0, bool CARRY_HALF = false>
 __device__ __forceinline__ void fe_gemm16(const unsigned char* X, int plane_bytes, const half8* __restrict__ wp, int nk32, const int (&cs)[NCS],
                                           int lane, f32x4 (&acc)[NRS][NCS], int rs0 = 0, int s_first = 0, int nsteps = -1, int nk32_total = -1,
                                           half8 (*Wh)[NCS > 1 && CARRY_HALF ? NCS / 2 : NCS] = nullptr,
-                                          half8 (*Wl)[NCS > 1 && CARRY_HALF ? NCS / 2 : NCS] = nullptr) {
+                                          half8 (*Wl)[NCS > 1 && CARRY_HALF ? NCS / 2 : NCS] = nullptr, int nrc_used = 1 << 30) {
+    // (nrc_used, wave-uniform: only the first nrc_used chunks of RH row sub-blocks are multiplied — a partly filled last tile)
     // (Wh / Wl: the caller keeps fragment registers across calls — multi_scale_conv's rounds; nullptr: local, fresh accumulators.
     //  CARRY_HALF: only the FIRST column half's fragments are the caller's (24 registers that stay live through the caller's
     //  emission phase instead of 48); the second half's first fragments are loaded on entry and land under the first half's MFMAs)
@@ -189,6 +190,7 @@ __device__ __forceinline__ void fe_gemm16(const unsigned char* X, int plane_byte
         for (int hc = 0; hc < NH; ++hc) {
 #pragma unroll
             for (int rc = 0; rc < NRC; ++rc) {
+                if (rc >= nrc_used) continue;
                 half8 ah[RC], al[RC];
 #pragma unroll
                 for (int i = 0; i < RC; ++i) {
@@ -1004,6 +1006,10 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_msc_kernel(const FdMscArgs a) {
             for (int j = 0; j < 6; ++j) BESTL[512 * j] = -__builtin_huge_valf();
 #pragma unroll 1
             for (int tile = 0; tile < ntile; ++tile) {
+                // a last, partly filled tile (m = 100: 4 of 16 points) only multiplies the pairs of 16-row sub-blocks that hold points, and
+                // only the waves whose four points exist emit
+                const int npt = m - 16 * tile < 16 ? m - 16 * tile : 16;
+                const int nrs = (npt + 3) >> 2;                         // row sub-blocks in use: points 4 rs .. 4 rs + 3, four steps each
                 const int pt0 = 16 * tile + 4 * rg;                     // this thread's first point; rows beyond the patch: the last point
                 const float* xr[4];                                     // (emitted like any other, never looked at: masked in the maximum)
 #pragma unroll
@@ -1036,7 +1042,7 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_msc_kernel(const FdMscArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) xn[e] = xr[e][64 * chn];
                     float* tp = tap ? tap + c : nullptr;
-                    if (ch < 15) {
+                    if (ch < 15 && 4 * rg < npt) {
                         if (ch < 3) {                                   // blocks 0, 1: EIF (wave-uniform branches)
                             if (fast) fe_emit4<1, true>(x, p, 0, 4, pe, pt0, m, count, a.gate, nullptr, 0);
                             else if (GENERAL) fe_emit4<1, false>(x, p, t0, nemit, pe, pt0, m, count, a.gate, tp, tap_tstride);
@@ -1046,7 +1052,7 @@ __global__ __launch_bounds__(FE_NT, 1) void fd_msc_kernel(const FdMscArgs a) {
                         }
                     }
                     lds_barrier();
-                    fe_gemm16<6, 4, 2, false>(R2, FE_PR * 64, mscw, 30, css, lane, acc, 0, 4 * R, R < 7 ? 4 : 2, 30, &Wh, &Wl);
+                    fe_gemm16<6, 4, 2, false>(R2, FE_PR * 64, mscw, 30, css, lane, acc, 0, 4 * R, R < 7 ? 4 : 2, 30, &Wh, &Wl, (nrs + 1) >> 1);
                     lds_barrier();
                 }
                 const bool allv = 16 * (tile + 1) <= m;                 // (workgroup-uniform: every point of this tile exists)
