@@ -184,8 +184,8 @@ __device__ __forceinline__ f32x2 pk_clamp10(f32x2 d) { return f32x2{clampf(d.x, 
 // that the peeled loops and fd's dead-stage elimination rest on.  Un-clamped, both exponentials underflow for x below about -13.2
 // and the spike is exactly 0.  The VALUE path does not notice (1 - r and m * (1 - r) are the same f32 for r = 0 and r = 3.85e-23),
 // but a refractory state built from it would read "gate open" where the reference's gate is closed.  The stepping forms that
-// carry r and count gate violations (NeuronStep2 / NeuronStep2V) therefore floor the step-0 refractory at SPIKE_FLOOR, the
-// reference's own minimum: r is then >= the reference's r up to rounding, and gate_open() tests what the reference's gate tests.
+// carry r and count gate violations (NeuronStep2 / NeuronStep2V) therefore floor the refractory at SPIKE_FLOOR, the reference's
+// own minimum, after every step: r is then >= the reference's r up to rounding, and gate_open() tests what the reference's gate tests.
 constexpr float SPIKE_FLOOR = 3.8e-23f;      // just below 0.5 exp(-50) / sqrt(2 pi) + 0.5 sigmoid(-100) = 3.847e-23 (fn:135-146 at x = -10)
 __device__ __forceinline__ f32x2 soft_spike2(f32x2 d) {
 #if defined(SAPCU_LIF_EXACT_ORDER) || defined(SAPCU_SPIKE_CLAMP)     // (the second macro: same-box A/B builds, profiles/step_ab.py)
@@ -377,7 +377,11 @@ struct NeuronStep2 {
         }
         const f32x2 sp = soft_spike2(mm - s.th);
         s.m = pk_fma(-mm, sp, mm);
-        s.r = first ? f32x2{fmaxf(sp.x, SPIKE_FLOOR), fmaxf(sp.y, SPIKE_FLOOR)} : pk_fma(s.r, rdecay, sp);   // (floor: see soft_spike2)
+        {   // (floor: see soft_spike2.  At EVERY step, as the reference's r >= its spike >= 3.85e-23 at every step: floored at step 0
+            //  only, r * rdecay^t would underflow to 0 after ~15 silent steps at rdecay = 0.1 and read "gate open" at large T)
+            const f32x2 rn = first ? sp : pk_fma(s.r, rdecay, sp);
+            s.r = f32x2{fmaxf(rn.x, SPIKE_FLOOR), fmaxf(rn.y, SPIKE_FLOOR)};
+        }
         s.th = pk_fma(s.th, f32x2{0.95f, 0.95f}, pk_fma(sp, a95, thc));
         return sp;
 #endif
@@ -443,7 +447,11 @@ struct NeuronStep2V {
         }
         const f32x2 sp = soft_spike2(mm - s.th);
         s.m = pk_fma(-mm, sp, mm);
-        s.r = first ? f32x2{fmaxf(sp.x, SPIKE_FLOOR), fmaxf(sp.y, SPIKE_FLOOR)} : pk_fma(s.r, rdecay, sp);   // (floor: see soft_spike2)
+        {   // (floor: see soft_spike2.  At EVERY step, as the reference's r >= its spike >= 3.85e-23 at every step: floored at step 0
+            //  only, r * rdecay^t would underflow to 0 after ~15 silent steps at rdecay = 0.1 and read "gate open" at large T)
+            const f32x2 rn = first ? sp : pk_fma(s.r, rdecay, sp);
+            s.r = f32x2{fmaxf(rn.x, SPIKE_FLOOR), fmaxf(rn.y, SPIKE_FLOOR)};
+        }
         s.th = pk_fma(s.th, f32x2{0.95f, 0.95f}, pk_fma(sp, a95, thc));
         return sp;
 #endif

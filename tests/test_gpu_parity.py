@@ -178,6 +178,16 @@ def test_neuron_stepping_form_far_outside_the_spike_clamp():
         _lib.check(lib.sapcu_neuron_selfloop(_lib.ptr(x), rows, ch, T, _lib.ptr(raw[0]), _lib.ptr(raw[1]), _lib.ptr(raw[2]), _lib.ptr(raw[3]),
                                              _lib.ptr(dT), _lib.ptr(rh), _lib.ptr(out), None, None, None, _lib.current_stream()))
         np.testing.assert_allclose(out.cpu().numpy(), ref[T - 1], rtol=2e-5, atol=1e-6, err_msg=kind + " self-loop")
+        # many silent steps: with the floor at step 0 only, r * rdecay^t (rdecay clamps down to 0.1) would underflow to 0 after ~15 steps
+        # and the gate test would fire; the reference's r is >= 3.85e-23 at EVERY step
+        TL = 48
+        spk = torch.empty((TL, rows, ch), device=U.dev())
+        rr = torch.empty((rows, ch), device=U.dev())
+        gate = torch.zeros(1, dtype=torch.int32, device=U.dev())
+        _lib.check(lib.sapcu_neuron_drive(_lib.ptr(x), rows, ch, TL, _lib.ptr(raw[0]), _lib.ptr(raw[1]), _lib.ptr(raw[2]), _lib.ptr(raw[3]),
+                                          _lib.ptr(dT), _lib.ptr(rh), 0, _lib.ptr(spk), None, None, _lib.ptr(rr), _lib.ptr(gate), _lib.current_stream()))
+        assert int(gate.item()) == 0 and bool((rr > 0).all()), kind + ": gate test fired within %d steps" % TL
+        np.testing.assert_allclose(spk[:T].cpu().numpy(), ref, rtol=2e-5, atol=1e-6, err_msg=kind + " first steps of the long run")
 
 
 # ------------------------------------------------------------------------------- in-patch kNN
