@@ -620,6 +620,23 @@ def neuron_wide_fixture():
     save("neuron_wide.npz", **out)
 
 
+def e2e_default_fixture():
+    """e2e_default.npz (round 4): the reference's Generator3D6.upsample at the configuration `generate.py` + `config/*.yaml` really
+    run — k_neighbors = 100 (generation.py:68; generate.py:135 keeps it), batch_size = 256 (generate.py:135), fn time_steps_enc = 6
+    (config/fn.yaml:41), fd time_steps_enc = 7 (config/fd.yaml:47) — on the 2048-point sphere with dense_spacing 0.03 (901 seeds from
+    its own dense.cpp; the default spacing 0.004 gives ~60 000 seeds: hours of CPU).  Conditioned weights seed 0 with the T = 4
+    BatchNorm calibration (the variants fixture does the same).  ~10 min of CPU."""
+    bn_fn, bn_fd = dict(np.load(os.path.join(HERE, "bn_calib_fn.npz"))), dict(np.load(os.path.join(HERE, "bn_calib_fd.npz")))
+    fn, fd = build_models(bn_fn, bn_fd, dict(FN_KW, time_steps_enc=6), dict(FD_KW, time_steps_enc=7))
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    cloud = T.sphere_cloud(2048, 0)
+    with torch.no_grad():
+        seeds, unfiltered, filtered = _reference_upsample(fn, fd, cloud, 0.03, batch_size=256, k=100)
+    print("e2e at the reference defaults: %d seeds -> %d refined, %d after the outlier filter" % (seeds.shape[0], unfiltered.shape[0], filtered.shape[0]))
+    save("e2e_default.npz", seeds=seeds, unfiltered=unfiltered, filtered=filtered)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only-ref-vs-ref", action="store_true", help="only (re)generate ref_vs_ref.npz (reference 1 thread vs 8 threads)")
@@ -633,9 +650,13 @@ def main():
     ap.add_argument("--only-suite", action="store_true", help="only (re)generate shape_suite.npz (BASELINE config 3 stand-in)")
     ap.add_argument("--only-scale16", action="store_true", help="only (re)generate scale16.npz (BASELINE config 4 stand-in)")
     ap.add_argument("--only-neuron-wide", action="store_true", help="only (re)generate neuron_wide.npz (neurons out to |x| = 1e4)")
+    ap.add_argument("--only-e2e-default", action="store_true", help="only (re)generate e2e_default.npz (upsample at k = 100, fn T = 6, fd T = 7)")
     args = ap.parse_args()
     if args.only_neuron_wide:
         neuron_wide_fixture()
+        return
+    if args.only_e2e_default:
+        e2e_default_fixture()
         return
     if args.only_ref_vs_ref:
         ref_vs_ref_fixture()
