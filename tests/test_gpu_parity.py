@@ -1933,7 +1933,7 @@ def test_fd_forward_on_patches_of_128_points(models):
         fn.knn_cache_mode = mode
 
 
-@pytest.mark.parametrize("T", [4, 7])
+@pytest.mark.parametrize("T", [4, 7, 5, 10])
 def test_fd_x0_path_equals_the_spike_slab_path_bit_for_bit(weights, monkeypatch, T):
     """Round 4, patches of more than 48 points (the reference's default is 100, generation.py:68; config/fd.yaml runs T = 7): the
     per-stage kernels write the pre-activations x0 [points, 960] and the step-0 spikes only, and fd_msc_kernel (csrc/fd_encoder.hip)
@@ -1941,7 +1941,8 @@ def test_fd_x0_path_equals_the_spike_slab_path_bit_for_bit(weights, monkeypatch,
     through HBM and the big-tile GEMM (handles created under SAPCU_FD_X0=0) or the whole old per-stage path (SAPCU_FD_FUSED=0).
     Every tap — scale fusion, neighbour tables, x0, every spike of every step, pooled, encoding — and the distances must agree
     BIT FOR BIT: 100, 128, 64, 49 and 77 points, one patch, T = 4 (two kernels: production / general) and the reference's T = 7
-    (two groups of steps), with and without taps, free-running and under forced tables."""
+    (fd_msc8_kernel: eight step slots per point, one group), T = 5 and T = 10 (two groups of eight slots), with and without taps,
+    free-running and under forced tables."""
     over = {"time_steps_enc": T}
     _, fd, _, sdd = U.build_gpu_models_under(weights, monkeypatch, {}, None, over)
     _, fd_slab, _, _ = U.build_gpu_models_under(weights, monkeypatch, {"SAPCU_FD_X0": "0"}, None, over)
